@@ -1,0 +1,206 @@
+/*
+ * vr180_remap.h -- C ABI of the MI355X-native fisheye -> equirectangular remap engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of 34j/vr180-convert:
+ *
+ *     apply_lr() -> apply() -> get_map() -> MultiTransformer.transform() -> cv2.remap()
+ *     (reference: src/vr180_convert/remapper.py:406,324,23 ; transformer.py:93 ; remapper.py:388-398)
+ *
+ * The reference has no FFI of its own (it is pure Python over NumPy + OpenCV); what a
+ * maintainer would bind is exactly the pair "evaluate the transformer chain on the output
+ * grid" + "cv2.remap the image through it".  Every entry point below names the reference
+ * lines it replaces.  Plain pointers and sizes only: no torch / numpy / C++ types.
+ *
+ * All `src`, `dst`, `xmap`, `ymap` pointers are DEVICE pointers (HBM) owned by the caller.
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls enqueue work
+ * on that stream and return without synchronising, except where stated.
+ *
+ * Return value: 0 on success, a negative V1C_E_* code otherwise; v1c_last_error() returns
+ * a thread-local human-readable message for the last failing call on this thread.
+ */
+#ifndef VR180_REMAP_H
+#define VR180_REMAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V1C_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------------- */
+#define V1C_OK             0
+#define V1C_E_INVALID     -1   /* bad argument (NULL pointer, size <= 0, unknown enum ...)   */
+#define V1C_E_UNSUPPORTED -2   /* valid request the engine cannot lower (caller falls back
+                                  to v1c_remap_lut with a map it computed itself)           */
+#define V1C_E_HIP         -3   /* a HIP runtime call failed (message has hipGetErrorString)  */
+#define V1C_E_NODEVICE    -4   /* no usable gfx950 device                                    */
+
+/* ---- cv2 enum values the reference passes straight through ---------------------------
+ * remapper.py:330-331 (defaults INTER_LANCZOS4 / BORDER_CONSTANT), cli.py:57-79 (mirrors). */
+#define V1C_INTER_NEAREST  0
+#define V1C_INTER_LINEAR   1
+#define V1C_INTER_CUBIC    2
+#define V1C_INTER_AREA     3   /* cv2.remap treats AREA as LINEAR */
+#define V1C_INTER_LANCZOS4 4
+
+#define V1C_BORDER_CONSTANT    0
+#define V1C_BORDER_REPLICATE   1
+#define V1C_BORDER_REFLECT     2
+#define V1C_BORDER_WRAP        3
+#define V1C_BORDER_REFLECT_101 4
+#define V1C_BORDER_TRANSPARENT 5
+
+/* ---- the lowered transformer chain ----------------------------------------------------
+ * One v1c_op per stage of the reference's MultiTransformer (transformer.py:87-105), in
+ * application order, INCLUDING the NormalizeTransformer that get_map() prepends and the
+ * DenormalizeTransformer it appends (remapper.py:51-57).  Stage semantics follow the
+ * reference line by line; see DESIGN.md "Op list".                                         */
+#define V1C_MAX_OPS    16
+#define V1C_MAX_PARAMS 16
+
+enum v1c_opcode {
+    /* x=(x-p0)/p2*2 ; y=(y-p1)/p2*2            NormalizeTransformer.transform  transformer.py:153-164 */
+    V1C_OP_NORMALIZE = 1,
+    /* x=x*p0+p2 ; y=y*p1+p3                    DenormalizeTransformer.transform         :197-204 */
+    V1C_OP_DENORMALIZE = 2,
+    /* x=(x-p2)/p0 ; y=(y-p3)/p1                DenormalizeTransformer.inverse_transform :206-213 */
+    V1C_OP_DENORMALIZE_INV = 3,
+    /* x=x/p0 ; y=y/p0                          ZoomTransformer.transform                :468-473 */
+    V1C_OP_ZOOM = 4,
+    /* x=x*p0 ; y=y*p0                          ZoomTransformer.inverse_transform        :475-480 */
+    V1C_OP_ZOOM_INV = 5,
+    /* iparam = is_latitude_y                   EquirectangularEncoder.transform         :540-568 */
+    V1C_OP_EQUIRECT_ENC = 6,
+    /* iparam = is_latitude_y                   EquirectangularEncoder.inverse_transform :570-584 */
+    V1C_OP_EQUIRECT_DEC = 7,
+    /* iparam = v1c_radial kind, nparam/p = its parameters
+                                                PolarRollTransformer.transform           :268-286 */
+    V1C_OP_RADIAL = 8,
+    /* p[0..8] = row-major 3x3 M, v' = M v      Euclidean3DTransformer.transform         :651-657
+       (M = numpy-quaternion as_rotation_matrix(q), built by the host: quat.py)                  */
+    V1C_OP_ROTATE = 9
+};
+
+/* radial function theta' = f(theta) applied by a V1C_OP_RADIAL stage */
+enum v1c_radial {
+    /* FisheyeEncoder.transform_polar, transformer.py:359-377 */
+    V1C_RAD_ENC_RECTILINEAR   = 1,  /* arctan(t)                  */
+    V1C_RAD_ENC_STEREOGRAPHIC = 2,  /* 2*arctan(t)                */
+    V1C_RAD_ENC_EQUIDISTANT   = 3,  /* t*(pi/2)                   */
+    V1C_RAD_ENC_EQUISOLID     = 4,  /* 2*arcsin(t/sqrt(2))        */
+    V1C_RAD_ENC_ORTHOGRAPHIC  = 5,  /* arcsin(t)                  */
+    /* FisheyeEncoder.inverse_transform_polar (= FisheyeDecoder), transformer.py:379-397 */
+    V1C_RAD_DEC_RECTILINEAR   = 6,  /* tan(t)                     */
+    V1C_RAD_DEC_STEREOGRAPHIC = 7,  /* 2*tan(t/2)                 */
+    V1C_RAD_DEC_EQUIDISTANT   = 8,  /* t/(pi/2)                   */
+    V1C_RAD_DEC_EQUISOLID     = 9,  /* sqrt(2)*sin(t/2)           */
+    V1C_RAD_DEC_ORTHOGRAPHIC  = 10, /* sin(t)                     */
+    /* PolynomialScaler.transform_polar, transformer.py:448-451: p[0..nparam) = coefs_reverse
+       (lowest order first); Horner from the highest, starting at 0 like np.polyval.              */
+    V1C_RAD_POLYNOMIAL        = 11,
+    /* RectilinearDecoder.transform_polar / inverse_transform_polar, transformer.py:338-347,
+       p[0] = factor = 2*focal_length/sensor_width_mm                                             */
+    V1C_RAD_RECTDEC_FWD       = 12, /* tan(t)*p0                  */
+    V1C_RAD_RECTDEC_INV       = 13  /* arctan(t/p0)               */
+};
+
+typedef struct v1c_op {
+    int32_t opcode;               /* enum v1c_opcode */
+    int32_t iparam;               /* integer parameter (kind / flag) */
+    int32_t nparam;               /* number of valid entries in p */
+    int32_t reserved;
+    double  p[V1C_MAX_PARAMS];
+} v1c_op;
+
+typedef struct v1c_chain {
+    int32_t n_ops;
+    int32_t reserved;
+    v1c_op  ops[V1C_MAX_OPS];
+} v1c_chain;
+
+/* One independent unit of work: an eye of a frame.  remapper.py:388-398 iterates these as
+ * `for img in images`; apply_lr concatenates two of them (remapper.py:517-518), which the
+ * engine does in place by pointing `dst` at each half of the SBS buffer with dst_pitch = row
+ * bytes of the whole SBS image.                                                             */
+typedef struct v1c_unit {
+    const uint8_t* src;           /* (src_h, src_w, cn) uint8, row pitch src_pitch bytes */
+    uint8_t*       dst;           /* (dst_h, dst_w, cn) uint8, row pitch dst_pitch bytes */
+    int64_t        src_pitch;
+    int64_t        dst_pitch;
+    /* optional per-unit rotation (row-major 3x3) REPLACING the matrix of the chain's first
+       V1C_OP_ROTATE stage; ignored unless has_rot != 0.  BASELINE config 5: per-frame, per-eye
+       calibration rotations (cli.py:308-319) share every other chain parameter.              */
+    double         rot[9];
+    int32_t        has_rot;
+    int32_t        reserved;
+} v1c_unit;
+
+typedef struct v1c_plan v1c_plan;   /* opaque */
+
+/* ---- entry points -------------------------------------------------------------------- */
+
+/* ABI / build identification. */
+int v1c_abi_version(void);
+/* Number of visible HIP devices (<0 on error). Does not create a context. */
+int v1c_device_count(void);
+/* Thread-local message of the last failing call ("" if none). */
+const char* v1c_last_error(void);
+
+/* Build a reusable plan for one (chain, geometry, interpolation, border) combination.
+ * Replaces: chain construction + np.meshgrid + MultiTransformer.transform + astype(float32)
+ * of get_map() (remapper.py:50-58) -- here nothing is materialised: the plan only holds the
+ * O(W+H) separable tables and the O(1 KiB..32 KiB) radial table the fused kernel reads.
+ * `chain` must start with the stage get_map prepends and end with the stage it appends.
+ * Synchronous (uploads tables); not graph-capturable.  cn must be 1, 3 or 4.               */
+int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chain,
+                    int src_h, int src_w, int dst_h, int dst_w, int cn,
+                    int interp, int border_mode, const uint8_t border_val[4]);
+int v1c_plan_destroy(v1c_plan* plan);
+
+/* Which device code path the plan selected: 0 = generic fp64 interpreter, 1 = fused
+ * "ray" path (separable tables + radial table), 2 = fused "planar" path.  For tests/bench. */
+int v1c_plan_path(const v1c_plan* plan);
+
+/* Enqueue the fused chain+gather for n_units independent units (one launch, grid.z = units).
+ * Replaces: get_map() + the cv.remap list comprehension, remapper.py:381-398, and the SBS
+ * concatenate of apply_lr, remapper.py:517-518 (via dst/dst_pitch).
+ * `units` is a HOST array; it is copied into a plan-owned device ring slot asynchronously on
+ * `stream`, so the call is launch-only (no allocation, no sync).                            */
+int v1c_plan_run(v1c_plan* plan, void* stream, const v1c_unit* units, int n_units);
+
+/* Evaluate only the coordinate chain on the output grid and store float32 maps (device
+ * pointers, row pitch map_pitch bytes).  Replaces get_map(), remapper.py:23-59.  Used for
+ * coordinate-parity tests and for callers that want the map itself.                         */
+int v1c_plan_get_map(v1c_plan* plan, void* stream, float* xmap, float* ymap,
+                     int64_t map_pitch, const double* rot_or_null);
+
+/* One-shot convenience: plan lookup/creation in an internal cache keyed on every argument
+ * but the pointers, then v1c_plan_run on one unit.  Same replacement as above.              */
+int v1c_remap_fused(int device, void* stream,
+                    const uint8_t* src, int src_h, int src_w, int64_t src_pitch, int cn,
+                    uint8_t* dst, int dst_h, int dst_w, int64_t dst_pitch,
+                    const v1c_chain* chain, int interp, int border_mode,
+                    const uint8_t border_val[4]);
+
+/* cv2.remap with caller-supplied float32 maps (device pointers).  Replaces the cv.remap call
+ * itself, remapper.py:388-398, for transformer chains the engine cannot lower (user-defined
+ * TransformerBase subclasses, README.md:204-219): the caller evaluates the chain.           */
+int v1c_remap_lut(int device, void* stream,
+                  const uint8_t* src, int src_h, int src_w, int64_t src_pitch, int cn,
+                  uint8_t* dst, int dst_h, int dst_w, int64_t dst_pitch,
+                  const float* xmap, const float* ymap, int64_t map_pitch,
+                  int interp, int border_mode, const uint8_t border_val[4]);
+
+/* Auto-radius estimate of one device-resident image, get_radius() transformer.py:108-140
+ * (centre row / column scan, threshold on the channel mean, sign quirk preserved).
+ * Synchronous: returns the value through *radius.  Returns V1C_E_INVALID with the message
+ * "no black border" where the reference raises IndexError.                                  */
+int v1c_get_radius(int device, void* stream, const uint8_t* img, int h, int w,
+                   int64_t pitch, int cn, int threshold, double* radius);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR180_REMAP_H */
