@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: dual-fisheye -> side-by-side equirect remap (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one apply_lr-shaped pass over one batch of synthetic input that is already resident in
+HBM: L+R 4096x4096 fisheye -> 8192x4096 SBS equirect, EquirectangularEncoder *
+PolynomialScaler([0,1,-0.1]) * FisheyeDecoder("equidistant"), INTER_LINEAR, BORDER_CONSTANT,
+radius "max" (BASELINE.json configs[1], "C2").  With N > 1 every rank (one process per GPU,
+launched by torch.distributed.run) remaps its own L+R pair per step: the path shards by frame
+with no data-path collective, so scaling is weak and the value is N pairs per step time.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused remap launch):
+algorithmic bytes per launch (3 B * (source + destination pixels), both eyes: SURVEY.md 8d)
+over its average duration measured with events on the launch stream.  `cpu_baseline` is the
+oracle (plain-C port of the reference path, oracle/) timed on this box's host cores on the same
+workload, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (eye size, transformer spec, interpolation)
+    "C2": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1,
+               desc="L+R 4096x4096 fisheye -> 8192x4096 SBS equirect, PolynomialScaler([0,1,-0.1]), bilinear"),
+    "C1": dict(size=2048, poly=None, rot=None, interp=1,
+               desc="L+R 2048x2048 fisheye -> 4096x2048 SBS equirect, equidistant, bilinear"),
+    "C4": dict(size=8192, poly=[0, 1, -0.1], rot="ry45", interp=4,
+               desc="L+R 8192x8192 -> 16384x8192 SBS, Euler rotation + PolynomialScaler, Lanczos4"),
+}
+
+
+def allreduce_max(value: float, device: torch.device) -> float:
+    """MAX over ranks of a host scalar (identity when not distributed)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def build_transformer(cfg):
+    import math
+
+    from vr180_convert_amd.quat import from_euler_angles
+    from vr180_convert_amd.transformer import (EquirectangularEncoder, Euclidean3DRotator, FisheyeDecoder,
+                                               PolynomialScaler)
+
+    t = EquirectangularEncoder()
+    if cfg["rot"] == "ry45":
+        t = t * Euclidean3DRotator(from_euler_angles(0.0, math.pi / 4, 0.0))
+    if cfg["poly"] is not None:
+        t = t * PolynomialScaler(cfg["poly"])
+    return t * FisheyeDecoder("equidistant")
+
+
+def oracle_spec(cfg):
+    import math
+
+    spec = [("equirect_enc", True)]
+    if cfg["rot"] == "ry45":
+        c, s = math.cos(math.pi / 4), math.sin(math.pi / 4)
+        spec.append(("rot", [[c, 0, s], [0, 1, 0], [-s, 0, c]]))
+    if cfg["poly"] is not None:
+        spec.append(("poly", cfg["poly"]))
+    spec.append(("fisheye_dec", "equidistant"))
+    return spec
+
+
+def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray | None):
+    """Oracle (C port of the reference path) on this box's host cores, same workload; also the
+    bit-for-bit parity of the GPU result on the bench inputs."""
+    from oracle import oracle as O
+
+    O.build()
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    size = cfg["size"]
+    spec = oracle_spec(cfg)
+    kw = dict(size_output=(size, size), interpolation=cfg["interp"], radius="max")
+    out = O.apply_lr(spec, left, right, **kw)  # warm (page faults, table build)
+    times = []
+    t_end = time.perf_counter() + 12.0
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 10):
+        t0 = time.perf_counter()
+        out = O.apply_lr(spec, left, right, **kw)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    mpx = 2 * size * size / 1e6
+    res = {
+        "value": round(mpx / best, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "sample": f"{len(times)} full passes of the bench workload ({mpx:.1f} Mpx each: fp64 chain per pixel + "
+                  f"fixed-point remap, both eyes, one shared map), best of them, OpenMP {cores} threads",
+    }
+    parity = None
+    if gpu_out is not None:
+        diff = np.abs(gpu_out.astype(np.int16) - out.astype(np.int16))
+        parity = {"max_abs_diff": int(diff.max()), "bytes_differing": int((diff != 0).sum()), "bytes": int(diff.size)}
+    return res, parity
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import vr180_convert_amd as V
+    from vr180_convert_amd import _native
+    from vr180_convert_amd.synth import noise_disc
+
+    _native.lib()  # fail loudly if the HIP engine is missing
+    cfg = WORKLOADS[args.workload]
+    size = cfg["size"]
+    transformer = build_transformer(cfg)
+    # seeded noise-disc frames; frame index = rank so ranks hold different pixels
+    left_h, right_h = noise_disc(size, size, 2 * rank), noise_disc(size, size, 2 * rank + 1)
+    left, right = torch.from_numpy(left_h).to(dev), torch.from_numpy(right_h).to(dev)
+    sbs = torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)
+
+    def step():
+        V.apply_lr_tensors(transformer, left, right, out=sbs, size_output=(size, size), interpolation=cfg["interp"],
+                           radius="max")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = allreduce_max(elapsed, dev)
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+    kernel_ms_max = allreduce_max(kernel_ms, dev)
+
+    px_per_step = 2 * size * size * world
+    value = px_per_step * args.steps / elapsed / 1e6
+    alg_bytes = 2 * 3 * (size * size + size * size)  # both eyes: source read once + destination written once
+    achieved = alg_bytes / (kernel_ms_max * 1e-3) / 1e9
+
+    if rank == 0:
+        from vr180_convert_amd.remapper import _PLANS
+
+        paths = sorted({p.path for p in _PLANS.values()})
+        traffic = None
+        tfile = ROOT / "profiles" / "pmc_traffic_latest.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(args.workload)
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "Mpixels/s dual-fisheye->SBS-equirect remap; achieved HBM GB/s vs peak",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 coordinates (fused chain), u8 pixels with int32 fixed-point blend",
+            "data": "synthetic (seeded uint8 noise inside the fisheye circle, black outside), resident in HBM",
+            "config": {"workload": f"{args.workload}: {cfg['desc']}", "units_per_step_per_gpu": 2,
+                       "sharding": "frames over ranks, no collective", "kernel_path": paths},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel_ms": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            torch.cuda.synchronize(dev)
+            cb, parity = cpu_baseline(cfg, left_h, right_h, sbs.cpu().numpy())
+            line["cpu_baseline"] = cb
+            line["parity_vs_oracle"] = parity
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

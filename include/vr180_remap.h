@@ -200,6 +200,12 @@ int v1c_remap_lut(int device, void* stream,
 int v1c_get_radius(int device, void* stream, const uint8_t* img, int h, int w,
                    int64_t pitch, int cn, int threshold, double* radius);
 
+/* The int16 fixed-point weight table the engine uses for INTER_CUBIC (1024*4*4 entries) or
+ * INTER_LANCZOS4 (1024*8*8 entries), laid out [fy*32+fx][ky][kx]: OpenCV's initInterTab2D
+ * (SURVEY.md Appendix A item 3).  Host-only (no device needed); `out` is a HOST buffer.
+ * Lets callers and tests inspect exactly what the kernels read.                            */
+int v1c_build_itab(int interp, int16_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,51 @@
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+for p in (ROOT, ROOT / "tests"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle as O
+
+    O.build()
+    O.set_threads(min(8, os.cpu_count() or 1))
+    return O
+
+
+@pytest.fixture(scope="session")
+def product_lib():
+    """libvr180remap.so (built by __graft_entry__.build(); hipcc cross-compiles without a GPU)."""
+    from vr180_convert_amd import _native
+
+    if not _native.LIB_PATH.exists():
+        subprocess.run(["make", "-C", str(_native.LIB_PATH.parent), "-j2"], check=True, capture_output=True)
+    return _native.lib()
+
+
+@pytest.fixture(scope="session")
+def emul_lib(product_lib):
+    """Host build of the product's __host__ __device__ per-pixel code (tests/host_emul)."""
+    import ctypes
+
+    from host_emul.build import build
+
+    return ctypes.CDLL(str(build()))

@@ -1,0 +1,124 @@
+// emul.hip -- TEST HARNESS: runs the product's __host__ __device__ per-pixel code on the CPU.
+//
+// The build container has no GPU.  This file includes the very headers the gfx950 kernels are
+// made of (vr180_convert_amd/csrc/v1c_core.hpp, radial_fit.hpp) and drives them with plain loops,
+// so that the interpreter, the fused ray path (tables + radial fit + fallback rule) and the
+// cv2.remap-exact sampler can be checked against the oracle before any GPU minute is spent.
+// It is NOT part of the product: nothing in vr180_convert_amd/ loads it.
+// Build: hipcc --cuda-host-only -O2 -shared -fPIC (see tests/host_emul/build.py).
+#include <cstring>
+#include <vector>
+
+#include "../../vr180_convert_amd/csrc/radial_fit.hpp"
+#include "../../vr180_convert_amd/csrc/v1c_core.hpp"
+
+using namespace v1c;
+
+template <int CN>
+static void remap_cn(const Image& s, const Geom& g, const short* itab, const float* xm, const float* ym, uint8_t* dst,
+                     int64_t dst_pitch)
+{
+    for (int j = 0; j < g.dst_h; j++)
+        for (int i = 0; i < g.dst_w; i++) {
+            uint8_t px[4] = {0, 0, 0, 0};
+            const float x = xm[(size_t)j * g.dst_w + i], y = ym[(size_t)j * g.dst_w + i];
+            bool wr;
+            switch (g.interp) {
+            case V1C_INTER_NEAREST: wr = sample<CN, V1C_INTER_NEAREST>(s, g, itab, x, y, px); break;
+            case V1C_INTER_LINEAR: wr = sample<CN, V1C_INTER_LINEAR>(s, g, itab, x, y, px); break;
+            case V1C_INTER_CUBIC: wr = sample<CN, V1C_INTER_CUBIC>(s, g, itab, x, y, px); break;
+            default: wr = sample<CN, V1C_INTER_LANCZOS4>(s, g, itab, x, y, px); break;
+            }
+            if (wr)
+                for (int c = 0; c < CN; c++)
+                    dst[j * dst_pitch + (int64_t)i * CN + c] = px[c];
+        }
+}
+
+extern "C" {
+
+// mode 0: literal interpreter; mode 1: ray path with per-pixel literal fix-up (as the kernels do).
+// stats[0] = 1 if the ray path was usable, stats[1] = pixels that needed the fix-up,
+// stats[2] = table variable (0 m / 1 w), stats[3] = flagged intervals, stats[4] = "no fix-up
+// launch needed" verdict of the plan (unrotated reach analysis)
+int emul_get_map(const v1c_chain* ch, const double* rot_or_null, int w, int h, int mode, float* xmap, float* ymap,
+                 long long* stats)
+{
+    if (stats)
+        std::memset(stats, 0, 5 * sizeof(long long));
+    if (mode == 0) {
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                double x, y;
+                eval_chain_literal(ch, rot_or_null, i, j, x, y);
+                xmap[(size_t)j * w + i] = (float)x;
+                ymap[(size_t)j * w + i] = (float)y;
+            }
+        return 0;
+    }
+    RayAnalysis a = analyze_chain(*ch);
+    if (!a.ok)
+        return 1;
+    RadialTable T = build_radial_table(a.radial);
+    if (stats) {
+        stats[2] = T.var_is_w;
+        stats[3] = T.n_invalid;
+    }
+    if (!ray_table_usable(T))
+        return 2;
+    RayHostTables ht = build_ray_host_tables(a, w, h);
+    RayParams P{};
+    P.col_s = ht.col_s.data(), P.col_c = ht.col_c.data(), P.col_h = ht.col_h.data();
+    P.row_s = ht.row_s.data(), P.row_c = ht.row_c.data(), P.row_h = ht.row_h.data();
+    P.radial = T.coef.data();
+    P.inv_step = T.inv_step, P.n_int = T.n_int, P.var_is_w = T.var_is_w, P.has_rot = a.has_rot;
+    for (int q = 0; q < 9; q++)
+        P.rot[q] = a.rot[q];
+    P.rx = a.rx, P.ry = a.ry, P.cx = a.cx, P.cy = a.cy;
+    double R[9];
+    const bool use_rot = rot_or_null || a.has_rot;
+    for (int q = 0; q < 9; q++)
+        R[q] = rot_or_null ? rot_or_null[q] : a.rot[q];
+    long long nfix = 0;
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            double x, y;
+            if (!ray_eval(P, use_rot, R, ht.row_s[j], ht.row_c[j], ht.row_h[j], ht.col_s[i], ht.col_c[i], ht.col_h[i], x, y)) {
+                eval_chain_literal(ch, rot_or_null, i, j, x, y);
+                nfix++;
+            }
+            xmap[(size_t)j * w + i] = (float)x;
+            ymap[(size_t)j * w + i] = (float)y;
+        }
+    if (stats) {
+        stats[0] = 1;
+        stats[1] = nfix;
+        stats[4] = !a.has_rot && !rot_or_null && ray_reach_is_safe(T, ht.m_reach);
+    }
+    return 0;
+}
+
+// `itab` = the fixed-point table of the PRODUCT (v1c_build_itab of libvr180remap.so), passed in by
+// the test; null for NEAREST / LINEAR.
+int emul_remap(const uint8_t* src, int src_h, int src_w, int64_t src_pitch, int cn, uint8_t* dst, int dst_h, int dst_w,
+               int64_t dst_pitch, const float* xm, const float* ym, int interp, int border, const uint8_t* cval,
+               const short* itab)
+{
+    Geom g{};
+    g.src_h = src_h, g.src_w = src_w, g.dst_h = dst_h, g.dst_w = dst_w, g.cn = cn;
+    g.interp = interp == V1C_INTER_AREA ? V1C_INTER_LINEAR : interp;
+    g.border = border;
+    for (int k = 0; k < 4; k++)
+        g.cval[k] = cval[k];
+    Image s{src, src_pitch, src_h, src_w};
+    if (cn == 1)
+        remap_cn<1>(s, g, itab, xm, ym, dst, dst_pitch);
+    else if (cn == 3)
+        remap_cn<3>(s, g, itab, xm, ym, dst, dst_pitch);
+    else if (cn == 4)
+        remap_cn<4>(s, g, itab, xm, ym, dst, dst_pitch);
+    else
+        return 1;
+    return 0;
+}
+}

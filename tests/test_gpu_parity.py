@@ -1,0 +1,341 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle and the reference
+goldens on a real MI355X.  Bar: coordinates land in identical cv2 1/32-pixel buckets as the
+reference's float32 maps; pixels are BIT-EXACT against the oracle (stricter than the north star's
++-1 per uint8 channel)."""
+import hashlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import chainspecs as CS
+from test_oracle_golden import assert_maps_match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def V():
+    import vr180_convert_amd as V
+    from vr180_convert_amd import _native
+
+    _native.lib()
+    assert torch.cuda.is_available()
+    return V
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def dmap(V, spec, out, inp, radius):
+    return V.get_map(CS.to_product(spec), radius=radius, size_input=inp, size_output=out)
+
+
+# ---------------------------------------------------------------------------- coordinates
+@pytest.mark.parametrize("name", list(CS.SMALL_CASES))
+def test_device_maps_vs_reference_goldens(V, golden_dir, name):
+    g = np.load(golden_dir / "maps_small.npz")
+    spec, out, inp, radius = CS.SMALL_CASES[name]
+    xm, ym = dmap(V, spec, out, inp, radius)
+    assert_maps_match(xm, ym, g[f"{name}__x"], g[f"{name}__y"], name)
+
+
+@pytest.mark.parametrize("name", list(CS.FULL_CASES))
+def test_device_maps_full_size_sha(V, golden_dir, name):
+    g = np.load(golden_dir / "maps_full.npz")
+    spec, out, inp, radius = CS.FULL_CASES[name]
+    xm, ym = dmap(V, spec, out, inp, radius)
+    s = CS.FULL_STRIDE
+    assert_maps_match(xm[::s], ym[::s], g[f"{name}__rows_x"], g[f"{name}__rows_y"], name + " rows")
+    assert hashlib.sha256(CS.buckets(xm).tobytes()).digest() == g[f"{name}__sha_bx"].tobytes()
+    assert hashlib.sha256(CS.buckets(ym).tobytes()).digest() == g[f"{name}__sha_by"].tobytes()
+
+
+def test_device_maps_c5_per_unit_rotation(V, golden_dir, dev):
+    from vr180_convert_amd.chain import lower_for_get_map
+    from vr180_convert_amd.remapper import _plan_for, _split_single_rotation
+
+    g = np.load(golden_dir / "maps_c5.npz")
+    plans = set()
+    for frame in (0, 1, 7):
+        for eye in (0, 1):
+            ch = lower_for_get_map(CS.to_product(CS.c5_spec(frame, eye)), radius=96.0, size_input=(192, 192), size_output=(192, 192))
+            shared, rot = _split_single_rotation(ch)
+            plan = _plan_for(shared, src_hw=(192, 192), dst_wh=(192, 192), cn=3, interpolation=1, border_mode=0,
+                             border_value=0, device=dev)
+            plans.add(id(plan))
+            assert plan.path == "ray"
+            xm, ym = plan.get_map(rot)
+            assert_maps_match(xm.cpu().numpy(), ym.cpu().numpy(), g[f"f{frame}_e{eye}__x"], g[f"f{frame}_e{eye}__y"], f"c5 {frame} {eye}")
+    assert len(plans) == 1  # one plan serves every calibration rotation
+
+
+# ---------------------------------------------------------------------------- sampler (LUT entry)
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_remap_lut_all_modes_vs_oracle(V, oracle_mod, dev, cn):
+    import ctypes as C
+
+    from vr180_convert_amd import _native
+    from vr180_convert_amd.remapper import border_scalar
+
+    O = oracle_mod
+    rng = np.random.default_rng(1)
+    Hs, Ws, H, W = 61, 83, 70, 90
+    src = rng.integers(0, 256, (Hs, Ws, cn), dtype=np.uint8)
+    xm = (rng.random((H, W)) * (Ws + 24) - 12).astype(np.float32)
+    ym = (rng.random((H, W)) * (Hs + 24) - 12).astype(np.float32)
+    xm[0, :5] = [np.nan, np.inf, -np.inf, 1e30, -1e30]
+    ym[1, :3] = [np.nan, 3e9, -3e9]
+    xm[2, :8] = np.arange(8)
+    ym[2, :8] = np.arange(8)
+    xm[3, :4] = [0.5 / 32, 1.5 / 32, 2.5 / 32, -0.5 / 32]
+    s_d, x_d, y_d = (torch.from_numpy(a).to(dev) for a in (src, xm, ym))
+    for interp in (0, 1, 2, 3, 4):
+        for border in range(6):
+            for bv in (0, (10, 200, 30, 77)):
+                ref = np.full((H, W, cn), 123, np.uint8)
+                O.remap(src, xm, ym, interp, border, bv, dst=ref)
+                out = torch.full((H, W, cn), 123, dtype=torch.uint8, device=dev)
+                cv = border_scalar(bv)
+                rc = _native.lib().v1c_remap_lut(0, None, s_d.data_ptr(), Hs, Ws, s_d.stride(0), cn, out.data_ptr(), H, W,
+                                                 out.stride(0), x_d.data_ptr(), y_d.data_ptr(), W * 4, interp, border, cv.ctypes.data)
+                assert rc == 0, _native.lib().v1c_last_error()
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy(), ref), (cn, interp, border, bv)
+
+
+# ---------------------------------------------------------------------------- fused path vs oracle
+CUTS = {
+    # 1024^2 cuts of every BASELINE config (SURVEY.md 8d "Parity gate") + C1 in full
+    "C1_full": (CS.FULL_CASES["C1"][0], 2048, 1, "ray"),
+    "C2_cut": (CS.FULL_CASES["C2"][0], 1024, 1, "ray"),
+    "C3_cut": (CS.FULL_CASES["C3"][0], 1024, 1, "ray"),
+    "C4_cut_lanczos": (CS.FULL_CASES["C4"][0], 1024, 4, "ray"),
+    "C4_cut_cubic": (CS.FULL_CASES["C4"][0], 512, 2, "ray"),
+    "C5_cut": (CS.c5_spec(3, 1), 1024, 1, "ray"),
+    "nearest": (CS.FULL_CASES["C2"][0], 512, 0, "ray"),
+    "fixup_back_hemisphere": (CS.SMALL_CASES["back_hemisphere"][0], 512, 1, "ray"),
+    "fixup_poly_c0": (CS.SMALL_CASES["poly_c0"][0], 512, 1, "ray"),
+    "literal_fisheye_to_fisheye": (CS.SMALL_CASES["transformer_rotator"][0], 512, 4, "literal"),
+    "literal_rot_after_radial": (CS.SMALL_CASES["rot_after_radial"][0], 512, 1, "literal"),
+    "literal_orthographic_nan": (CS.SMALL_CASES["apply_orthographic"][0], 512, 1, "literal"),
+}
+
+
+@pytest.mark.parametrize("name", list(CUTS))
+def test_fused_apply_bit_exact_vs_oracle(V, oracle_mod, dev, name):
+    from vr180_convert_amd.synth import noise_disc
+
+    spec, size, interp, want_path = CUTS[name]
+    img = noise_disc(size, size, frame=7)
+    want = oracle_mod.apply(spec, [img], size_output=(size, size), interpolation=interp, radius="max")[0]
+    src = torch.from_numpy(img).to(dev)
+    dst = torch.empty_like(src)
+    paths = V.remap_tensors(CS.to_product(spec), [src], [dst], radius=size / 2, interpolation=interp)
+    torch.cuda.synchronize()
+    assert paths == [want_path]
+    got = dst.cpu().numpy()
+    nd = int((got != want).sum())
+    assert nd == 0, f"{name}: {nd} bytes differ, max |d| = {int(np.abs(got.astype(int) - want).max())}"
+
+
+def test_c2_full_size_apply_lr_vs_oracle(V, oracle_mod, dev):
+    """BASELINE config C2 end to end: L+R 4096^2 -> 8192x4096 SBS, one launch."""
+    from vr180_convert_amd.synth import noise_disc
+
+    spec, out, inp, radius = CS.FULL_CASES["C2"]
+    left, right = noise_disc(4096, 4096, 0), noise_disc(4096, 4096, 1)
+    want = oracle_mod.apply_lr(spec, left, right, size_output=out, interpolation=1, radius="max")
+    sbs = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev),
+                             size_output=out, interpolation=1, radius="max")
+    got = sbs.cpu().numpy()
+    assert got.shape == (4096, 8192, 3)
+    assert np.array_equal(got, want)
+
+
+def test_full_size_properties(V, dev):
+    """Size-independent properties at BASELINE's largest single-GPU size (C4: 8192^2, Lanczos4)."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc_torch
+
+    n = 8192
+    img = noise_disc_torch(n, n, 0, dev)
+    # (1) the identity chain reproduces the input for every interpolation: FisheyeEncoder("equidistant")
+    #     * FisheyeDecoder("equidistant") with radius = n/2 maps pixel i to i (|err| ~1e-13 px)
+    ident = T.FisheyeEncoder("equidistant") * T.FisheyeDecoder("equidistant")
+    for interp in (4, 1):
+        out = torch.empty_like(img)
+        V.remap_tensors(ident, [img], [out], radius=n / 2, interpolation=interp)
+        assert torch.equal(out, img), interp
+    # (2) identical eyes give identical halves; (3) an all-outside map gives pure border colour
+    t = T.EquirectangularEncoder() * T.PolynomialScaler([0, 1, -0.1]) * T.FisheyeDecoder("equidistant")
+    sbs = V.apply_lr_tensors(t, img, img, size_output=(n, n), interpolation=4, radius="max")
+    assert torch.equal(sbs[:, :n], sbs[:, n:])
+    far = T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant") * T.ZoomTransformer(1e-3)
+    out = torch.empty((64, 64, 3), dtype=torch.uint8, device=dev)
+    V.remap_tensors(far, [img], [out], radius=n / 2, interpolation=1, boarder_value=(9, 8, 7))
+    torch.cuda.synchronize()
+    inner = out.cpu().numpy()
+    inner[32, 32] = (9, 8, 7)  # the centre pixel maps to the image centre
+    assert np.all(inner == np.array([9, 8, 7], np.uint8))
+
+
+# ---------------------------------------------------------------------------- API behaviour
+def test_apply_numpy_inputs_views_and_borders(V, oracle_mod):
+    from vr180_convert_amd.synth import noise_disc, pattern
+
+    O = oracle_mod
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    t = CS.to_product(spec)
+    sbs = np.concatenate([noise_disc(300, 260, 1), pattern(300, 260)], axis=1)
+    halves = [sbs[:, :260], sbs[:, 260:]]  # non-contiguous column views (remapper.py:455-456)
+    for border, bv in ((0, 0), (0, 77), (0, (1, 2, 3)), (1, 0), (2, 0), (3, 0), (4, 0)):
+        for interp in (1, 4):
+            got = V.apply(t, in_paths=halves, size_output=(200, 240), interpolation=interp, boarder_mode=border,
+                          boarder_value=bv, radius="max")
+            want = O.apply(spec, halves, size_output=(200, 240), interpolation=interp, border_mode=border,
+                           border_value=bv, radius="max")
+            assert len(got) == 2 and got[0].shape == (240, 200, 3) and got[0].dtype == np.uint8
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (border, bv, interp)
+    # single ndarray input, numeric and negative radius, grayscale
+    one = V.apply(t, in_paths=halves[0], size_output=(96, 96), interpolation=1, radius=-120.5)
+    assert np.array_equal(one[0], O.apply(spec, [halves[0]], size_output=(96, 96), interpolation=1, radius=-120.5)[0])
+    gray = np.ascontiguousarray(halves[0][..., 1])
+    g1 = V.apply(t, in_paths=gray, size_output=(96, 96), interpolation=2, radius="max")[0]
+    assert g1.shape == (96, 96) and np.array_equal(g1, O.apply(spec, [gray], size_output=(96, 96), interpolation=2, radius="max")[0])
+    # transparent border: untouched pixels stay as allocated (zeros here)
+    tr = V.apply(t * CS.to_product([("zoom", 0.5)]), in_paths=halves[0], size_output=(96, 96), interpolation=1, boarder_mode=5, radius="max")[0]
+    ref = np.zeros((96, 96, 3), np.uint8)
+    xm, ym = O.get_map(spec + [("zoom", 0.5)], radius=130.0, size_input=(300, 260), size_output=(96, 96))
+    O.remap(np.ascontiguousarray(halves[0]), xm, ym, 1, 5, 0, dst=ref)
+    assert np.array_equal(tr, ref)
+
+
+def test_apply_lr_files_auto_radius_and_tuple(V, oracle_mod, tmp_path):
+    from PIL import Image
+
+    from vr180_convert_amd import _io
+    from vr180_convert_amd.synth import pattern
+
+    O = oracle_mod
+    img = pattern(256, 256)
+    img[:, :20] = 0
+    img[:, -20:] = 0  # black border so that radius="auto" finds edges
+    sbs_in = np.concatenate([img, img[:, ::-1]], axis=1)
+    p = tmp_path / "in.png"
+    _io.imwrite(p, sbs_in)
+    assert np.array_equal(_io.imread(p), sbs_in)
+    spec = [("equirect_enc", True), CS.EQUI]
+    out_p = tmp_path / "out.png"
+    # same path for both eyes -> split in halves (remapper.py:448-456); auto radius = max over eyes
+    assert V.apply_lr(CS.to_product(spec), left_path=p, right_path=p, out_path=out_p, size_output=(128, 128),
+                      interpolation=1, radius="auto") is None
+    want = O.apply_lr(spec, sbs_in[:, :256], sbs_in[:, 256:], size_output=(128, 128), interpolation=1, radius="auto")
+    assert np.array_equal(_io.imread(out_p), want)
+    # per-eye transformer tuple: per-eye map AND per-eye radius estimate (remapper.py:460-473)
+    specs = ([("equirect_enc", True), ("rot", CS.ry(0.05)), CS.EQUI], [("equirect_enc", True), ("rot", CS.ry(-0.05)), CS.EQUI])
+    left, right = sbs_in[:, :256], np.ascontiguousarray(sbs_in[:, 256:])
+    right[:, :30] = 0
+    V.apply_lr(tuple(CS.to_product(s) for s in specs), left_path=left, right_path=right, out_path=out_p,
+               size_output=(128, 128), interpolation=4, radius="auto")
+    want = O.apply_lr(specs, left, right, size_output=(128, 128), interpolation=4, radius="auto")
+    assert np.array_equal(_io.imread(out_p), want)
+    # device-side auto radius == host estimate, including the IndexError
+    d = torch.from_numpy(np.ascontiguousarray(left)).cuda()
+    from vr180_convert_amd.remapper import get_radius_smart
+
+    assert get_radius_smart("auto", [d]) == O.get_radius(np.ascontiguousarray(left))
+    with pytest.raises(IndexError):
+        get_radius_smart("auto", [torch.full((64, 80, 3), 90, dtype=torch.uint8, device="cuda")])
+
+
+def test_user_defined_transformer_takes_lut_path(V, oracle_mod, dev):
+    """README.md:204-219: any TransformerBase subclass must work; its map comes from its own
+    transform(), the gather runs on the GPU (v1c_remap_lut)."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    class Swirl(T.TransformerBase):
+        def transform(self, x, y, **kw):
+            r = np.sqrt(x**2 + y**2)
+            a = 0.3 * r
+            return x * np.cos(a) - y * np.sin(a), x * np.sin(a) + y * np.cos(a)
+
+        def inverse_transform(self, x, y, **kw):
+            raise NotImplementedError
+
+    img = noise_disc(200, 200, 3)
+    t = T.EquirectangularEncoder() * Swirl() * T.FisheyeDecoder("equidistant")
+    src = torch.from_numpy(img).to(dev)
+    dst = torch.empty((150, 160, 3), dtype=torch.uint8, device=dev)
+    assert V.remap_tensors(t, [src], [dst], radius=100.0, interpolation=4) == ["lut"]
+    xm, ym = V.get_map(t, radius=100.0, size_input=(200, 200), size_output=(160, 150))
+    want = oracle_mod.remap(img, xm, ym, 4)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), want)
+
+
+def test_batch_per_unit_rotation_shares_one_plan(V, oracle_mod, dev):
+    """BASELINE config 5 in small: frames x eyes, each with its own calibration rotation, one plan."""
+    from vr180_convert_amd.remapper import _PLANS
+    from vr180_convert_amd.synth import noise_disc
+
+    n_frames, size = 10, 256  # 20 units: exercises the 16-units-per-launch chunking
+    sbs_in = [noise_disc(size, 2 * size, f) for f in range(n_frames)]
+    srcs_d, dsts_d, ts, want = [], [], [], []
+    outs = [torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev) for _ in range(n_frames)]
+    for f in range(n_frames):
+        frame_d = torch.from_numpy(sbs_in[f]).to(dev)
+        for eye in (0, 1):
+            srcs_d.append(frame_d[:, eye * size:(eye + 1) * size])  # pitched views of the SBS frame
+            dsts_d.append(outs[f][:, eye * size:(eye + 1) * size])
+            ts.append(CS.to_product(CS.c5_spec(f, eye)))
+    before = len(_PLANS)
+    paths = V.remap_tensors(ts, srcs_d, dsts_d, radius=size / 2, interpolation=1)
+    torch.cuda.synchronize()
+    assert paths == ["ray"] and len(_PLANS) == before + 1
+    for f in range(n_frames):
+        specs = (CS.c5_spec(f, 0), CS.c5_spec(f, 1))
+        w = oracle_mod.apply_lr(specs, sbs_in[f][:, :size], sbs_in[f][:, size:], size_output=(size, size), interpolation=1, radius=size / 2)
+        assert np.array_equal(outs[f].cpu().numpy(), w), f
+
+
+def test_errors(V, dev):
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.remapper import Plan
+    from vr180_convert_amd.chain import lower_for_get_map
+
+    t = T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant")
+    a = torch.zeros((32, 32, 3), dtype=torch.uint8, device=dev)
+    with pytest.raises(TypeError):
+        V.remap_tensors(t, [a.float()], [a], radius=16.0)
+    with pytest.raises(ValueError):
+        V.remap_tensors(t, [a[:, ::2]], [a[:, :16]], radius=16.0)  # pixel stride != channels
+    ch = lower_for_get_map(t, radius=16.0, size_input=(32, 32), size_output=(32, 32))
+    plan = Plan(ch, src_hw=(32, 32), dst_wh=(32, 32), cn=3, interpolation=1, border_mode=0, border_value=0, device=dev)
+    with pytest.raises(ValueError):
+        plan.run([a], [torch.zeros((16, 16, 3), dtype=torch.uint8, device=dev)])
+    with pytest.raises(ValueError, match="rotate"):
+        plan.run([a], [torch.empty_like(a)], [np.eye(3)])
+    with pytest.raises(ValueError, match="Unknown mapping type"):
+        V.apply(T.FisheyeEncoder("nope") * T.FisheyeDecoder("equidistant"), in_paths=np.zeros((8, 8, 3), np.uint8), radius="max")
+    with pytest.raises(IndexError):
+        V.apply(t, in_paths=np.full((16, 20, 3), 200, np.uint8), radius="auto")  # no black border
+
+
+def test_known_answer_reference_docs_pair_gpu(V, golden_dir):
+    from PIL import Image
+
+    from vr180_convert_amd import transformer as T
+
+    src = np.asarray(Image.open(golden_dir / "ref_docs" / "test.jpg").convert("RGB"))[..., ::-1].copy()
+    ref = np.asarray(Image.open(golden_dir / "ref_docs" / "test.lr.PolynomialScaler.jpg").convert("RGB"))[..., ::-1]
+    t = T.EquirectangularEncoder() * T.PolynomialScaler() * T.FisheyeDecoder("equidistant")
+    out = V.apply(t, in_paths=[src, src], size_output=(2048, 2048), radius="max")  # library defaults: Lanczos4
+    sbs = np.concatenate(out, axis=1)
+    d = sbs.astype(np.float64) - ref
+    assert 10 * np.log10(255.0**2 / np.mean(d * d)) >= 30.0

@@ -1,0 +1,113 @@
+"""Runs the product's per-pixel device code (v1c_core.hpp: interpreter, fused ray path, sampler)
+compiled for the HOST (tests/host_emul) against the oracle / the reference goldens.  This is how
+the kernels' arithmetic is validated in the GPU-less build container; the -m gpu tests repeat the
+comparisons through the real kernels."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import chainspecs as CS
+from test_oracle_golden import assert_maps_match
+
+
+def emul_map(E, ch, W, H, mode, rot=None):
+    xm = np.empty((H, W), np.float32)
+    ym = np.empty((H, W), np.float32)
+    st = (C.c_longlong * 5)()
+    r = None if rot is None else np.ascontiguousarray(rot, np.float64)
+    rc = E.emul_get_map(C.byref(ch), C.c_void_p(None if r is None else r.ctypes.data), W, H, mode,
+                        C.c_void_p(xm.ctypes.data), C.c_void_p(ym.ctypes.data), st)
+    return rc, xm, ym, list(st)
+
+
+@pytest.mark.parametrize("name", list(CS.SMALL_CASES))
+def test_interpreter_and_ray_path_vs_reference(emul_lib, oracle_mod, golden_dir, name):
+    g = np.load(golden_dir / "maps_small.npz")
+    spec, out, inp, radius = CS.SMALL_CASES[name]
+    ch = oracle_mod.chain_from_spec(spec, radius=radius, size_input=inp, size_output=out)
+    rc, xm, ym, _ = emul_map(emul_lib, ch, out[0], out[1], 0)
+    assert rc == 0
+    assert_maps_match(xm, ym, g[f"{name}__x"], g[f"{name}__y"], name + " literal")
+    rc, xm, ym, st = emul_map(emul_lib, ch, out[0], out[1], 1)
+    if rc == 0:  # chain has the ray shape
+        assert_maps_match(xm, ym, g[f"{name}__x"], g[f"{name}__y"], name + " ray")
+        if st[4]:  # plan says "no fix-up launch needed": then no pixel may have needed it
+            assert st[1] == 0
+
+
+def test_ray_path_expected_coverage(emul_lib, oracle_mod):
+    """Which chains take the fused path, with which table variable, and how much fix-up."""
+    expect = {  # name: (ray?, var_is_w, needs fix-up pixels?)
+        "apply_equirectangular": (True, 0, False), "c2_poly": (True, 1, False), "c4_rot_poly": (True, 1, False),
+        "c5_calib_left": (True, 0, False), "zoom": (True, 0, False), "nonsquare": (True, 0, False),
+        "poly_c0": (True, 0, True), "poly_signchange": (True, 0, True), "back_hemisphere": (True, 0, True),
+        "apply_rectilinear": (False, 0, False), "rot_after_radial": (False, 0, False), "equirect_lat_x": (False, 0, False),
+    }
+    for name, (ray, var_w, fix) in expect.items():
+        spec, out, inp, radius = CS.SMALL_CASES[name]
+        ch = oracle_mod.chain_from_spec(spec, radius=radius, size_input=inp, size_output=out)
+        rc, _, _, st = emul_map(emul_lib, ch, out[0], out[1], 1)
+        assert (rc == 0) == ray, name
+        if ray:
+            assert st[2] == var_w, name
+            assert (st[1] > 0) == fix, (name, st)
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3"])
+def test_ray_path_full_size_sha(emul_lib, oracle_mod, golden_dir, name):
+    g = np.load(golden_dir / "maps_full.npz")
+    spec, out, inp, radius = CS.FULL_CASES[name]
+    ch = oracle_mod.chain_from_spec(spec, radius=radius, size_input=inp, size_output=out)
+    rc, xm, ym, st = emul_map(emul_lib, ch, out[0], out[1], 1)
+    assert rc == 0 and st[0] == 1 and st[1] == 0 and st[4] == 1
+    assert hashlib.sha256(CS.buckets(xm).tobytes()).digest() == g[f"{name}__sha_bx"].tobytes()
+    assert hashlib.sha256(CS.buckets(ym).tobytes()).digest() == g[f"{name}__sha_by"].tobytes()
+
+
+def test_per_unit_rotation_override(emul_lib, oracle_mod, golden_dir):
+    """BASELINE config 5: one plan, the rotation arrives per unit."""
+    g = np.load(golden_dir / "maps_c5.npz")
+    base = oracle_mod.chain_from_spec([("equirect_enc", True), ("rot", np.eye(3)), CS.EQUI], radius=96.0,
+                                      size_input=(192, 192), size_output=(192, 192))
+    for frame in (0, 1, 7):
+        for eye in (0, 1):
+            rot = oracle_mod.quat_to_matrix(CS.c5_spec(frame, eye)[1][1])
+            for mode in (0, 1):
+                rc, xm, ym, _ = emul_map(emul_lib, base, 192, 192, mode, rot)
+                assert rc == 0
+                assert_maps_match(xm, ym, g[f"f{frame}_e{eye}__x"], g[f"f{frame}_e{eye}__y"], f"c5 {frame} {eye} mode {mode}")
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_sampler_equals_oracle(emul_lib, product_lib, oracle_mod, cn):
+    O = oracle_mod
+    rng = np.random.default_rng(1)
+    tabs = {}
+    for interp, k in ((2, 4), (4, 8)):
+        tabs[interp] = np.zeros(1024 * k * k, np.int16)
+        assert product_lib.v1c_build_itab(interp, tabs[interp].ctypes.data) == 0
+    Hs, Ws, H, W = 61, 83, 70, 90
+    src = rng.integers(0, 256, (Hs, Ws, cn), dtype=np.uint8)
+    xm = (rng.random((H, W)) * (Ws + 24) - 12).astype(np.float32)
+    ym = (rng.random((H, W)) * (Hs + 24) - 12).astype(np.float32)
+    xm[0, :5] = [np.nan, np.inf, -np.inf, 1e30, -1e30]
+    ym[1, :3] = [np.nan, 3e9, -3e9]
+    xm[2, :8] = np.arange(8)
+    ym[2, :8] = np.arange(8)
+    xm[3, :4] = [0.5 / 32, 1.5 / 32, 2.5 / 32, -0.5 / 32]  # round-half-even ties
+    for interp in (0, 1, 2, 3, 4):
+        for border in range(6):
+            for bv in (0, (10, 200, 30, 77)):
+                ref = np.full((H, W, cn), 123, np.uint8)
+                out = ref.copy()
+                O.remap(src, xm, ym, interp, border, bv, dst=ref)
+                cv = O.border_scalar(bv)
+                it = tabs.get(interp)
+                rc = emul_lib.emul_remap(
+                    C.c_void_p(src.ctypes.data), Hs, Ws, C.c_int64(src.strides[0]), cn, C.c_void_p(out.ctypes.data), H, W,
+                    C.c_int64(out.strides[0]), C.c_void_p(xm.ctypes.data), C.c_void_p(ym.ctypes.data), interp, border,
+                    C.c_void_p(cv.ctypes.data), C.c_void_p(None if it is None else it.ctypes.data))
+                assert rc == 0
+                assert np.array_equal(ref, out), (cn, interp, border, bv)

@@ -1,0 +1,124 @@
+"""Self-consistency checks of the oracle's cv2.remap restatement (parity with cv2 itself is
+UNPINNED: cv2 is not installed and the reference's tests assert no pixel).  These tests pin what
+can be pinned without cv2: the published table properties, an independent NumPy formulation of
+the fixed-point bilinear, border semantics against numpy.pad, and the reference's only
+pixel-level artefact (docs/_static example pair) as a coarse known-answer test."""
+import numpy as np
+import pytest
+
+BORDER_TO_PAD = {1: "edge", 2: "symmetric", 3: "wrap", 4: "reflect"}
+
+
+def test_weight_tables(oracle_mod):
+    O = oracle_mod
+    lin = O.build_itab(O.INTER_LINEAR)
+    fy, fx = np.divmod(np.arange(1024), 32)
+    closed = np.stack([32 * (32 - fx) * (32 - fy), 32 * fx * (32 - fy), 32 * (32 - fx) * fy, 32 * fx * fy], -1).reshape(1024, 2, 2)
+    # the one entry where saturate_cast<short>(32768) bites (and the fix-up lands in the last tap)
+    assert lin[0].tolist() == [[32767, 0], [0, 1]]
+    assert np.array_equal(lin[1:], closed[1:])
+    for interp in (O.INTER_LINEAR, O.INTER_CUBIC, O.INTER_LANCZOS4):
+        t = O.build_itab(interp)
+        assert np.all(t.reshape(1024, -1).astype(np.int64).sum(1) == 32768)
+    lz = O.build_itab(O.INTER_LANCZOS4)
+    assert lz[0, 3, 3] == 32767 and lz[0, 4, 4] == 1 and np.count_nonzero(lz[0]) == 2
+    cu = O.build_itab(O.INTER_CUBIC)
+    assert cu[0, 1, 1] == 32767 and cu[0].sum() == 32768
+    # symmetry of the 1-D kernels: weights at fraction f mirrored equal weights at 1-f
+    assert np.array_equal(cu[16 * 32 + 16], cu[16 * 32 + 16][::-1, ::-1])
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2, 4])
+def test_identity_and_integer_shift(oracle_mod, interp):
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[:37, :53].astype(np.float32)
+    assert np.array_equal(oracle_mod.remap(src, xx, yy, interp), src)
+    out = oracle_mod.remap(src, xx + 5, yy - 3, interp, oracle_mod.BORDER_CONSTANT, (7, 8, 9))
+    exp = np.empty_like(src)
+    exp[...] = (7, 8, 9)
+    exp[3:, :48] = src[:34, 5:]
+    # cubic / lanczos footprints straddling the border mix border colour in: compare the interior
+    m = 8 if interp in (2, 4) else 0
+    assert np.array_equal(out[3 + m:37 - m, m:48 - m], exp[3 + m:37 - m, m:48 - m])
+    if interp in (0, 1):
+        assert np.array_equal(out, exp)
+
+
+def test_bilinear_matches_independent_numpy(oracle_mod):
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    xm = (rng.random((50, 70)) * 70 - 5).astype(np.float32)
+    ym = (rng.random((50, 70)) * 50 - 5).astype(np.float32)
+    out = oracle_mod.remap(src, xm, ym, 1, 0, (11, 22, 33))
+    sx = np.rint(xm * np.float32(32)).astype(np.int64)
+    sy = np.rint(ym * np.float32(32)).astype(np.int64)
+    ix, iy, fx, fy = sx >> 5, sy >> 5, sx & 31, sy & 31
+    pad = np.empty((40 + 2, 60 + 2, 3), np.int64)
+    pad[...] = (11, 22, 33)
+    pad[1:-1, 1:-1] = src
+    cx, cy = np.clip(ix + 1, 0, 60), np.clip(iy + 1, 0, 40)
+    cx1, cy1 = np.clip(ix + 2, 0, 61), np.clip(iy + 2, 0, 41)
+    acc = (pad[cy, cx] * (32 * (32 - fx) * (32 - fy))[..., None] + pad[cy, cx1] * (32 * fx * (32 - fy))[..., None]
+           + pad[cy1, cx] * (32 * (32 - fx) * fy)[..., None] + pad[cy1, cx1] * (32 * fx * fy)[..., None])
+    exp = ((acc + 16384) >> 15).astype(np.uint8)
+    outside = (ix >= 60) | (ix + 1 < 0) | (iy >= 40) | (iy + 1 < 0)
+    exp[outside] = (11, 22, 33)
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("border", [1, 2, 3, 4])
+@pytest.mark.parametrize("interp", [0, 1, 2, 4])
+def test_border_modes_equal_numpy_pad(oracle_mod, border, interp):
+    """remap through border mode B == remap of the np.pad(mode=B)-extended image with CONSTANT."""
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8)
+    P = 12
+    big = np.pad(src, ((P, P), (P, P), (0, 0)), mode=BORDER_TO_PAD[border])
+    xm = (rng.random((40, 40)) * (31 + 8) - 4).astype(np.float32)
+    ym = (rng.random((40, 40)) * (23 + 8) - 4).astype(np.float32)
+    a = oracle_mod.remap(src, xm, ym, interp, border)
+    b = oracle_mod.remap(big, xm + P, ym + P, interp, oracle_mod.BORDER_CONSTANT)
+    assert np.array_equal(a, b)
+
+
+def test_transparent_and_scalar_border(oracle_mod):
+    O = oracle_mod
+    rng = np.random.default_rng(6)
+    src = rng.integers(0, 256, (20, 20, 3), dtype=np.uint8)
+    xm = (rng.random((30, 30)) * 30 - 5).astype(np.float32)
+    ym = (rng.random((30, 30)) * 30 - 5).astype(np.float32)
+    dst = np.full((30, 30, 3), 99, np.uint8)
+    O.remap(src, xm, ym, O.INTER_LINEAR, O.BORDER_TRANSPARENT, 0, dst=dst)
+    sx, sy = np.rint(xm * 32).astype(int) >> 5, np.rint(ym * 32).astype(int) >> 5
+    inside = (sx >= 0) & (sx < 19) & (sy >= 0) & (sy < 19)
+    assert np.all(dst[~inside] == 99)
+    ref = O.remap(src, xm, ym, O.INTER_LINEAR, O.BORDER_CONSTANT, 0)
+    assert np.array_equal(dst[inside], ref[inside])
+    # Python int borderValue -> Scalar(v, 0, 0, 0): only channel 0 gets it
+    far = np.full((4, 4), -100, np.float32)
+    assert np.array_equal(O.remap(src, far, far, O.INTER_LINEAR, O.BORDER_CONSTANT, 200)[0, 0], [200, 0, 0])
+    assert np.array_equal(O.remap(src, far, far, O.INTER_NEAREST, O.BORDER_CONSTANT, (1, 2, 3))[0, 0], [1, 2, 3])
+    nanmap = np.full((4, 4), np.nan, np.float32)
+    assert np.array_equal(O.remap(src, nanmap, nanmap, O.INTER_LANCZOS4, O.BORDER_CONSTANT, (5, 6, 7))[1, 1], [5, 6, 7])
+
+
+def test_known_answer_reference_docs_pair(oracle_mod, golden_dir):
+    """The reference's README example (README.md:59-61): our chain + remap on its input must
+    reproduce its published output (both JPEG-compressed) to >= 30 dB PSNR."""
+    from PIL import Image
+
+    O = oracle_mod
+    src = np.asarray(Image.open(golden_dir / "ref_docs" / "test.jpg").convert("RGB"))[..., ::-1].copy()
+    ref = np.asarray(Image.open(golden_dir / "ref_docs" / "test.lr.PolynomialScaler.jpg").convert("RGB"))[..., ::-1]
+    spec = [("equirect_enc", True), ("poly", [0, 1]), ("fisheye_dec", "equidistant")]
+    sbs = O.apply_lr(spec, src, src, size_output=(2048, 2048), interpolation=O.INTER_LINEAR, radius="max")
+    assert sbs.shape == ref.shape == (2048, 4096, 3)
+    d = sbs.astype(np.float64) - ref
+    psnr = 10 * np.log10(255.0**2 / np.mean(d * d))
+    assert psnr >= 30.0, psnr
+    # and the wrong polynomial is clearly told apart (identifies the parameters)
+    bad = O.apply([("equirect_enc", True), ("poly", [0, 1, -0.1]), ("fisheye_dec", "equidistant")], [src],
+                  size_output=(2048, 2048), interpolation=O.INTER_LINEAR, radius="max")[0]
+    d = bad.astype(np.float64) - ref[:, :2048]
+    assert 10 * np.log10(255.0**2 / np.mean(d * d)) < 20.0

@@ -1,0 +1,38 @@
+"""MI355X-native drop-in for the hot path of 34j/vr180-convert: ``apply`` / ``apply_lr`` /
+``get_map`` and the Transformer classes (reference src/vr180_convert/__init__.py:1-32)."""
+__version__ = "0.1.0"
+
+from .chain import (
+    DenormalizeTransformer,
+    EquirectangularEncoder,
+    Euclidean3DRotator,
+    Euclidean3DTransformer,
+    FisheyeDecoder,
+    FisheyeEncoder,
+    MultiTransformer,
+    NormalizeTransformer,
+    PolarRollTransformer,
+    TransformerBase,
+    ZoomTransformer,
+)
+from .remapper import apply, apply_lr, apply_lr_tensors, get_map, remap_tensors
+
+__all__ = [
+    "TransformerBase",
+    "ZoomTransformer",
+    "MultiTransformer",
+    "NormalizeTransformer",
+    "PolarRollTransformer",
+    "DenormalizeTransformer",
+    "FisheyeDecoder",
+    "FisheyeEncoder",
+    "EquirectangularEncoder",
+    "Euclidean3DRotator",
+    "Euclidean3DTransformer",
+    "apply",
+    "apply_lr",
+    "get_map",
+    # additions of this engine (device-resident entry points)
+    "apply_lr_tensors",
+    "remap_tensors",
+]

@@ -1,0 +1,57 @@
+"""Image file I/O either side of the hot path (reference remapper.py:373,402,453,519 use
+``cv.imread`` / ``cv.imwrite``).  cv2 is used when it is importable, Pillow otherwise; arrays are
+BGR like cv2's.  Codec work is outside the measured path."""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+
+try:  # pragma: no cover - not installed in the build / GPU image
+    import cv2 as _cv
+except Exception:  # noqa: BLE001
+    _cv = None
+
+
+def imread(path: Any):
+    """BGR uint8 (H, W, 3) array, or ``None`` when the file cannot be read (cv2.imread's contract)."""
+    p = Path(path).as_posix()
+    if _cv is not None:
+        return _cv.imread(p)
+    from PIL import Image
+
+    try:
+        with Image.open(p) as im:
+            rgb = np.asarray(im.convert("RGB"))
+    except (OSError, ValueError):
+        return None
+    return np.ascontiguousarray(rgb[..., ::-1])
+
+
+def imwrite(path: Any, image: np.ndarray) -> bool:
+    p = Path(path).as_posix()
+    if image.dtype != np.uint8:
+        image = np.clip(np.rint(image), 0, 255).astype(np.uint8)  # cv2.imwrite converts with saturation
+    if _cv is not None:
+        return bool(_cv.imwrite(p, image))
+    from PIL import Image
+
+    arr = image if image.ndim == 2 else image[..., ::-1] if image.shape[2] == 3 else image[..., [2, 1, 0, 3]]
+    Image.fromarray(np.ascontiguousarray(arr)).save(p)
+    return True
+
+
+def anaglyph(left: np.ndarray, right: np.ndarray) -> np.ndarray:
+    """``merge=True`` of apply_lr (reference remapper.py:485-516): per-eye channel mean times a
+    colour, summed, / 255.  The "L" / "R" labels need cv2.putText and are drawn only when cv2 is
+    importable."""
+    colors = [(0, 128, 255), (255, 128, 0)]
+    combine = np.mean(left, axis=-1)[..., None] * np.array(colors[0]).reshape(1, 1, 3) + (
+        np.mean(right, axis=-1)[..., None] * np.array(colors[1]).reshape(1, 1, 3)
+    )
+    combine /= 255
+    if _cv is not None:  # pragma: no cover
+        _cv.putText(combine, "L", (0, len(combine[1]) // 10), _cv.FONT_HERSHEY_SIMPLEX, len(combine) // 1000, colors[0], 2, _cv.LINE_AA)
+        _cv.putText(combine, "R", (len(combine[1]) // 2, len(combine[0]) // 10), _cv.FONT_HERSHEY_SIMPLEX, len(combine) // 1000, colors[1], 2, _cv.LINE_AA)
+    return combine

@@ -1,0 +1,290 @@
+// kernels.hip -- gfx950 kernels of the fused remap engine.
+//
+// One launch covers up to kMaxUnitsPerLaunch independent units (eyes / frames) on grid.z.  A
+// workgroup is 64 x 4 threads = 4 waves; every lane produces kPX horizontally adjacent output
+// pixels of one row, so a wave writes 64*kPX*3 contiguous bytes with dword stores.
+//
+// Coordinate producers (template parameter MODE):
+//   MODE_LITERAL  fp64 interpreter of the lowered chain (any lowerable chain)
+//   MODE_RAY      separable tables + radial table.  Pixels outside the table's validated domain
+//                 are NOT written; their tile is flagged and
+//   MODE_FIXUP    (a second, normally empty launch) re-evaluates exactly those pixels with the
+//                 interpreter.  Keeping the interpreter out of MODE_RAY keeps its register
+//                 footprint small.
+//   MODE_LUT      caller-supplied float32 maps (v1c_remap_lut)
+// All of them feed the same cv2.remap-exact sampler (v1c_core.hpp).
+#include "kernels.hpp"
+
+namespace v1c {
+
+// Per-unit data pulled out of the kernel-argument block into registers.  (Taking the address of
+// anything inside UnitArgs would make the compiler spill the whole 2 KB argument block to scratch.)
+struct UnitView {
+    const uint8_t* src;
+    uint8_t* dst;
+    int64_t src_pitch, dst_pitch;
+    double rot[9];
+    bool has_rot;       // the unit overrides the chain's first rotation
+    bool use_rot;       // a rotation applies in ray mode (unit's or the chain's composed one)
+};
+
+__device__ __forceinline__ UnitView load_unit(const UnitArgs& ua, const RayParams& rp, int z)
+{
+    UnitView v;
+    v.src = ua.u[z].src;
+    v.dst = ua.u[z].dst;
+    v.src_pitch = ua.u[z].src_pitch;
+    v.dst_pitch = ua.u[z].dst_pitch;
+    v.has_rot = ua.u[z].has_rot != 0;
+    v.use_rot = v.has_rot || rp.has_rot;
+#pragma unroll
+    for (int q = 0; q < 9; q++)
+        v.rot[q] = v.has_rot ? ua.u[z].rot[q] : rp.rot[q];
+    return v;
+}
+
+template <int MODE>
+struct Coords;
+
+template <>
+struct Coords<MODE_LITERAL> {
+    __device__ static unsigned eval(const KernelCtx& c, const UnitView& u, int x0, int j, float* fx, float* fy)
+    {
+        const double* rot = u.has_rot ? u.rot : nullptr;
+        for (int k = 0; k < kPX; k++) {
+            double x, y;
+            eval_chain_literal(c.chain, rot, x0 + k, j, x, y);
+            fx[k] = (float)x;  // astype(np.float32), remapper.py:58
+            fy[k] = (float)y;
+        }
+        return (1u << kPX) - 1;
+    }
+};
+
+template <>
+struct Coords<MODE_RAY> {
+    __device__ static unsigned eval(const KernelCtx& c, const UnitView& u, int x0, int j, float* fx, float* fy)
+    {
+        const RayParams& rp = c.ray;
+        // the row index is wave-uniform (blockDim.x == 64): tell the compiler, so the row table
+        // reads become scalar loads
+        const int ju = __builtin_amdgcn_readfirstlane(j);
+        const double sl = rp.row_s[ju], cl = rp.row_c[ju], hl = rp.row_h[ju];
+        unsigned ok = 0;
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const int i = min(x0 + k, c.g.dst_w - 1);
+            double x, y;
+            if (ray_eval(rp, u.use_rot, u.rot, sl, cl, hl, rp.col_s[i], rp.col_c[i], rp.col_h[i], x, y)) {
+                fx[k] = (float)x;
+                fy[k] = (float)y;
+                ok |= 1u << k;
+            }
+        }
+        return ok;
+    }
+};
+
+template <>
+struct Coords<MODE_FIXUP> {
+    __device__ static unsigned eval(const KernelCtx& c, const UnitView& u, int x0, int j, float* fx, float* fy)
+    {
+        float rx[kPX], ry[kPX];
+        const unsigned ok = Coords<MODE_RAY>::eval(c, u, x0, j, rx, ry);
+        const double* rot = u.has_rot ? u.rot : nullptr;
+        unsigned todo = ~ok & ((1u << kPX) - 1);
+        for (int k = 0; k < kPX; k++) {
+            if (todo & (1u << k)) {
+                double x, y;
+                eval_chain_literal(c.chain, rot, min(x0 + k, c.g.dst_w - 1), j, x, y);
+                fx[k] = (float)x;
+                fy[k] = (float)y;
+            }
+        }
+        return todo;
+    }
+};
+
+template <>
+struct Coords<MODE_LUT> {
+    __device__ static unsigned eval(const KernelCtx& c, const UnitView&, int x0, int j, float* fx, float* fy)
+    {
+        const float* xr = (const float*)((const char*)c.xmap + (int64_t)j * c.map_pitch);
+        const float* yr = (const float*)((const char*)c.ymap + (int64_t)j * c.map_pitch);
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const int i = min(x0 + k, c.g.dst_w - 1);
+            fx[k] = xr[i];
+            fy[k] = yr[i];
+        }
+        return (1u << kPX) - 1;
+    }
+};
+
+template <int CN, int INTERP, int MODE>
+__global__ __launch_bounds__(kBlockX* kBlockY) void k_remap(KernelCtx c, UnitArgs ua)
+{
+    const UnitView u = load_unit(ua, c.ray, blockIdx.z);
+    const Geom& g = c.g;
+    const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (MODE == MODE_FIXUP) {
+        // uniform early exit for tiles the ray pass completed; self-cleaning flag
+        const uint32_t flagged = c.tile_flags[tile];
+        if (!flagged)
+            return;
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0)
+            c.tile_flags[tile] = 0;
+    }
+    const int x0 = (blockIdx.x * kBlockX + threadIdx.x) * kPX;
+    const int j = blockIdx.y * kBlockY + threadIdx.y;
+    if (x0 >= g.dst_w || j >= g.dst_h)
+        return;
+
+    float fx[kPX], fy[kPX];
+    const unsigned npx_mask = (1u << min(kPX, g.dst_w - x0)) - 1;
+    unsigned valid = Coords<MODE>::eval(c, u, x0, j, fx, fy) & npx_mask;
+    if (MODE == MODE_RAY && valid != npx_mask)
+        c.tile_flags[tile] = 1;
+
+    const Image src{u.src, u.src_pitch, g.src_h, g.src_w};
+    uint8_t* drow = u.dst + (int64_t)j * u.dst_pitch + (int64_t)x0 * CN;
+
+    uint32_t words[kPX * CN / 4];
+#pragma unroll
+    for (int q = 0; q < kPX * CN / 4; q++)
+        words[q] = 0;
+    unsigned written = 0;
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        uint8_t px[CN];
+#pragma unroll
+        for (int ch = 0; ch < CN; ch++)
+            px[ch] = 0;
+        if ((valid & (1u << k)) && sample<CN, INTERP>(src, g, c.itab, fx[k], fy[k], px))
+            written |= 1u << k;
+#pragma unroll
+        for (int ch = 0; ch < CN; ch++) {
+            const int b = k * CN + ch;
+            words[b / 4] |= (uint32_t)px[ch] << (8 * (b % 4));
+        }
+    }
+    if (written == (1u << kPX) - 1 && (((uintptr_t)drow) & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < kPX * CN / 4; q++)
+            ((uint32_t*)drow)[q] = words[q];
+    } else {
+        // ragged right edge, BORDER_TRANSPARENT holes, fix-up pixels, unaligned destination
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            if (written & (1u << k)) {
+#pragma unroll
+                for (int ch = 0; ch < CN; ch++) {
+                    const int b = k * CN + ch;
+                    drow[b] = (uint8_t)(words[b / 4] >> (8 * (b % 4)));
+                }
+            }
+        }
+    }
+}
+
+// coordinate maps only (v1c_plan_get_map): float32 like remapper.py:58.  The ray variant falls
+// back to the interpreter in place (performance is irrelevant here).
+template <int MODE>
+__global__ __launch_bounds__(kBlockX* kBlockY) void k_get_map(KernelCtx c, UnitArgs ua, float* xmap, float* ymap, int64_t pitch)
+{
+    const UnitView u = load_unit(ua, c.ray, 0);
+    const int x0 = (blockIdx.x * kBlockX + threadIdx.x) * kPX;
+    const int j = blockIdx.y * kBlockY + threadIdx.y;
+    if (x0 >= c.g.dst_w || j >= c.g.dst_h)
+        return;
+    float fx[kPX], fy[kPX];
+    Coords<MODE>::eval(c, u, x0, j, fx, fy);
+    if (MODE == MODE_RAY) {
+        float lx[kPX], ly[kPX];
+        const unsigned todo = Coords<MODE_FIXUP>::eval(c, u, x0, j, lx, ly);
+        for (int k = 0; k < kPX; k++)
+            if (todo & (1u << k))
+                fx[k] = lx[k], fy[k] = ly[k];
+    }
+    float* xr = (float*)((char*)xmap + (int64_t)j * pitch);
+    float* yr = (float*)((char*)ymap + (int64_t)j * pitch);
+    for (int k = 0; k < kPX && x0 + k < c.g.dst_w; k++) {
+        xr[x0 + k] = fx[k];
+        yr[x0 + k] = fy[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-callable launchers (used by plan.hip)
+// ------------------------------------------------------------------------------------------
+static dim3 grid_for(const Geom& g, int n_units)
+{
+    return dim3((g.dst_w + kBlockX * kPX - 1) / (kBlockX * kPX), (g.dst_h + kBlockY - 1) / kBlockY, n_units);
+}
+
+int tiles_per_unit(const Geom& g)
+{
+    const dim3 d = grid_for(g, 1);
+    return (int)(d.x * d.y);
+}
+
+template <int CN, int MODE>
+static hipError_t launch_interp(const KernelCtx& c, const UnitArgs& ua, int n_units, hipStream_t stream)
+{
+    const dim3 block(kBlockX, kBlockY, 1);
+    const dim3 grid = grid_for(c.g, n_units);
+    switch (c.g.interp) {
+    case V1C_INTER_NEAREST:
+        hipLaunchKernelGGL((k_remap<CN, V1C_INTER_NEAREST, MODE>), grid, block, 0, stream, c, ua);
+        break;
+    case V1C_INTER_LINEAR:
+        hipLaunchKernelGGL((k_remap<CN, V1C_INTER_LINEAR, MODE>), grid, block, 0, stream, c, ua);
+        break;
+    case V1C_INTER_CUBIC:
+        hipLaunchKernelGGL((k_remap<CN, V1C_INTER_CUBIC, MODE>), grid, block, 0, stream, c, ua);
+        break;
+    case V1C_INTER_LANCZOS4:
+        hipLaunchKernelGGL((k_remap<CN, V1C_INTER_LANCZOS4, MODE>), grid, block, 0, stream, c, ua);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_cn(const KernelCtx& c, const UnitArgs& ua, int n_units, hipStream_t stream)
+{
+    switch (c.g.cn) {
+    case 1: return launch_interp<1, MODE>(c, ua, n_units, stream);
+    case 3: return launch_interp<3, MODE>(c, ua, n_units, stream);
+    case 4: return launch_interp<4, MODE>(c, ua, n_units, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_remap(int mode, const KernelCtx& c, const UnitArgs& ua, int n_units, hipStream_t stream)
+{
+    switch (mode) {
+    case MODE_LITERAL: return launch_cn<MODE_LITERAL>(c, ua, n_units, stream);
+    case MODE_RAY: return launch_cn<MODE_RAY>(c, ua, n_units, stream);
+    case MODE_FIXUP: return launch_cn<MODE_FIXUP>(c, ua, n_units, stream);
+    case MODE_LUT: return launch_cn<MODE_LUT>(c, ua, n_units, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float* xmap, float* ymap, int64_t pitch,
+                          hipStream_t stream)
+{
+    const dim3 block(kBlockX, kBlockY, 1);
+    const dim3 grid = grid_for(c.g, 1);
+    if (mode == MODE_RAY)
+        hipLaunchKernelGGL((k_get_map<MODE_RAY>), grid, block, 0, stream, c, u, xmap, ymap, pitch);
+    else
+        hipLaunchKernelGGL((k_get_map<MODE_LITERAL>), grid, block, 0, stream, c, u, xmap, ymap, pitch);
+    return hipGetLastError();
+}
+
+}  // namespace v1c

@@ -1,0 +1,31 @@
+// kernels.hpp -- declarations shared by kernels.hip (device code) and plan.hip (host C ABI).
+#pragma once
+
+#include "v1c_core.hpp"
+
+namespace v1c {
+
+constexpr int kPX = 4;       // output pixels per lane (12 bytes = 3 dword stores for BGR)
+constexpr int kBlockX = 64;  // lanes per row segment (= one wave)
+constexpr int kBlockY = 4;   // rows (waves) per workgroup
+
+enum { MODE_LITERAL = 0, MODE_RAY = 1, MODE_LUT = 2, MODE_FIXUP = 3 };
+
+// Everything a launch needs besides the units; passed by value as a kernel argument.
+struct KernelCtx {
+    Geom g;
+    const v1c_chain* chain;   // device copy of the lowered chain (literal / fix-up modes)
+    RayParams ray;            // ray mode tables
+    const short* itab;        // cubic / lanczos4 weight table (device), else null
+    uint32_t* tile_flags;     // one word per (unit slot, tile): set by MODE_RAY, consumed by MODE_FIXUP
+    const float* xmap;        // MODE_LUT
+    const float* ymap;
+    int64_t map_pitch;        // bytes
+};
+
+int tiles_per_unit(const Geom& g);
+hipError_t launch_remap(int mode, const KernelCtx& c, const UnitArgs& ua, int n_units, hipStream_t stream);
+hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float* xmap, float* ymap, int64_t pitch,
+                          hipStream_t stream);
+
+}  // namespace v1c

@@ -1,0 +1,577 @@
+// plan.hip -- host side of the C ABI declared in include/vr180_remap.h.
+//
+// A plan owns everything the kernels read besides the images: the device copy of the lowered
+// chain, the separable row / column tables and the radial table of the fused ray path, OpenCV's
+// fixed-point interpolation table for CUBIC / LANCZOS4, and the tile-flag words that connect the
+// ray pass to its fix-up pass.  v1c_plan_run only fills kernel arguments and launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vr180_remap.h"
+#include "kernels.hpp"
+#include "radial_fit.hpp"
+
+using namespace v1c;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(V1C_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// OpenCV's fixed-point interpolation table (initInterTab2D, imgwarp.cpp)
+// ------------------------------------------------------------------------------------------
+static int cv_round_host(float v)
+{
+    return (std::fabs(v) < 2147483648.0f) ? (int)std::nearbyintf(v) : INT_MIN;
+}
+
+static short sat_short_host(int v)
+{
+    return (short)std::min(32767, std::max(-32768, v));
+}
+
+static void coeffs_1d(int interp, float x, float* c)
+{
+    if (interp == V1C_INTER_CUBIC) {
+        const float A = -0.75f;
+        c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+        return;
+    }
+    // Lanczos4
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[][2] = {{1, 0},  {-s45, -s45}, {0, 1},  {s45, -s45},
+                                   {-1, 0}, {s45, s45},   {0, -1}, {-s45, s45}};
+    if (x < 1.1920928955078125e-07f) {
+        for (int i = 0; i < 8; i++)
+            c[i] = 0;
+        c[3] = 1;
+        return;
+    }
+    float sum = 0;
+    const double y0 = -(x + 3) * 3.1415926535897932384626433832795 * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const double y = -(x + 3 - i) * 3.1415926535897932384626433832795 * 0.25;
+        c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += c[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++)
+        c[i] *= sum;
+}
+
+#pragma clang fp contract(off)
+static std::vector<short> build_itab(int interp)
+{
+    const int K = interp == V1C_INTER_CUBIC ? 4 : 8;
+    std::vector<float> t1(32 * K);
+    for (int i = 0; i < 32; i++)
+        coeffs_1d(interp, i * (1.f / 32), &t1[i * K]);
+    std::vector<short> tab((size_t)1024 * K * K);
+    for (int fy = 0; fy < 32; fy++)
+        for (int fx = 0; fx < 32; fx++) {
+            short* e = &tab[(size_t)(fy * 32 + fx) * K * K];
+            int isum = 0;
+            for (int k1 = 0; k1 < K; k1++)
+                for (int k2 = 0; k2 < K; k2++) {
+                    const float v = t1[fy * K + k1] * t1[fx * K + k2];
+                    e[k1 * K + k2] = sat_short_host(cv_round_host(v * 32768));
+                    isum += e[k1 * K + k2];
+                }
+            if (isum != 32768) {
+                // the surplus goes to one of the taps (K/2 .. K/2+1)^2: the largest if the sum is
+                // short, the smallest if it is over; strict comparisons, k1-major scan
+                const int diff = isum - 32768, h = K / 2;
+                int Mk = h * K + h, mk = h * K + h;
+                for (int k1 = h; k1 < h + 2; k1++)
+                    for (int k2 = h; k2 < h + 2; k2++) {
+                        const int q = k1 * K + k2;
+                        if (e[q] < e[mk])
+                            mk = q;
+                        else if (e[q] > e[Mk])
+                            Mk = q;
+                    }
+                if (diff < 0)
+                    e[Mk] = (short)(e[Mk] - diff);
+                else
+                    e[mk] = (short)(e[mk] - diff);
+            }
+        }
+    return tab;
+}
+#pragma clang fp contract(fast)
+
+extern "C" int v1c_build_itab(int interp, int16_t* out)
+{
+    if (!out || (interp != V1C_INTER_CUBIC && interp != V1C_INTER_LANCZOS4))
+        return fail(V1C_E_INVALID, "v1c_build_itab: interp must be CUBIC or LANCZOS4, out non-NULL");
+    const std::vector<short> tab = build_itab(interp);
+    std::memcpy(out, tab.data(), tab.size() * sizeof(short));
+    return V1C_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct v1c_plan {
+    int device = 0;
+    int mode = MODE_LITERAL;
+    v1c_chain chain{};
+    RayAnalysis ana;
+    RadialTable table;
+    bool chain_has_rot = false;   // any V1C_OP_ROTATE stage (per-unit override allowed)
+    int n_rot_stages = 0;
+    bool ray_no_rot_safe = false; // no rotation: reachable m stays below the first flagged interval
+    KernelCtx ctx{};
+    int tiles = 0;
+    std::vector<void*> allocs;
+};
+
+template <typename T>
+static int upload(v1c_plan* p, const std::vector<T>& h, const T** out)
+{
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, std::max<size_t>(h.size() * sizeof(T), 16)));
+    p->allocs.push_back(d);
+    if (!h.empty())
+        HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return V1C_OK;
+}
+
+static int validate_chain(const v1c_chain* ch)
+{
+    if (!ch)
+        return fail(V1C_E_INVALID, "chain is NULL");
+    if (ch->n_ops < 1 || ch->n_ops > V1C_MAX_OPS)
+        return fail(V1C_E_INVALID, "chain.n_ops out of range");
+    for (int i = 0; i < ch->n_ops; i++) {
+        const v1c_op& op = ch->ops[i];
+        if (op.opcode < V1C_OP_NORMALIZE || op.opcode > V1C_OP_ROTATE)
+            return fail(V1C_E_INVALID, "unknown opcode in chain");
+        if (op.nparam < 0 || op.nparam > V1C_MAX_PARAMS)
+            return fail(V1C_E_INVALID, "op.nparam out of range");
+        if (op.opcode == V1C_OP_RADIAL && (op.iparam < V1C_RAD_ENC_RECTILINEAR || op.iparam > V1C_RAD_RECTDEC_INV))
+            return fail(V1C_E_INVALID, "unknown radial kind in chain");
+    }
+    return V1C_OK;
+}
+
+static int validate_geom(int src_h, int src_w, int dst_h, int dst_w, int cn, int interp, int border)
+{
+    if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0)
+        return fail(V1C_E_INVALID, "image sizes must be positive");
+    // cv2.remap works on short coordinates
+    if (src_h >= 32768 || src_w >= 32768 || dst_h >= 32768 || dst_w >= 32768)
+        return fail(V1C_E_INVALID, "image sizes must be < 32768 (cv2.remap limit)");
+    if (cn != 1 && cn != 3 && cn != 4)
+        return fail(V1C_E_INVALID, "cn must be 1, 3 or 4");
+    if (interp < V1C_INTER_NEAREST || interp > V1C_INTER_LANCZOS4)
+        return fail(V1C_E_INVALID, "unknown interpolation");
+    if (border < V1C_BORDER_CONSTANT || border > V1C_BORDER_TRANSPARENT)
+        return fail(V1C_E_INVALID, "unknown border mode");
+    return V1C_OK;
+}
+
+extern "C" int v1c_abi_version(void)
+{
+    return V1C_ABI_VERSION;
+}
+
+extern "C" int v1c_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return fail(V1C_E_NODEVICE, "hipGetDeviceCount failed");
+    return n;
+}
+
+extern "C" const char* v1c_last_error(void)
+{
+    return g_err.c_str();
+}
+
+extern "C" int v1c_plan_destroy(v1c_plan* p)
+{
+    if (!p)
+        return V1C_OK;
+    DeviceGuard dg(p->device);
+    for (void* d : p->allocs)
+        (void)hipFree(d);
+    delete p;
+    return V1C_OK;
+}
+
+static int plan_common(v1c_plan* p, int device, int src_h, int src_w, int dst_h, int dst_w, int cn, int interp,
+                       int border_mode, const uint8_t border_val[4])
+{
+    p->device = device;
+    Geom& g = p->ctx.g;
+    g.src_h = src_h, g.src_w = src_w, g.dst_h = dst_h, g.dst_w = dst_w;
+    g.cn = cn;
+    g.interp = interp == V1C_INTER_AREA ? V1C_INTER_LINEAR : interp;  // cv2.remap: AREA -> LINEAR
+    g.border = border_mode;
+    for (int k = 0; k < 4; k++)
+        g.cval[k] = border_val ? border_val[k] : 0;
+    p->tiles = tiles_per_unit(g);
+    if (g.interp == V1C_INTER_CUBIC || g.interp == V1C_INTER_LANCZOS4) {
+        const std::vector<short> tab = build_itab(g.interp);
+        int rc = upload(p, tab, &p->ctx.itab);
+        if (rc)
+            return rc;
+    }
+    return V1C_OK;
+}
+
+extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chain, int src_h, int src_w, int dst_h,
+                               int dst_w, int cn, int interp, int border_mode, const uint8_t border_val[4])
+{
+    if (!out)
+        return fail(V1C_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = validate_chain(chain);
+    if (rc)
+        return rc;
+    rc = validate_geom(src_h, src_w, dst_h, dst_w, cn, interp, border_mode);
+    if (rc)
+        return rc;
+    DeviceGuard dg(device);
+    if (!dg.ok)
+        return fail(V1C_E_NODEVICE, "hipSetDevice failed");
+
+    v1c_plan* p = new v1c_plan();
+    p->chain = *chain;
+    rc = plan_common(p, device, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, border_val);
+    if (rc) {
+        v1c_plan_destroy(p);
+        return rc;
+    }
+    for (int i = 0; i < chain->n_ops; i++)
+        p->n_rot_stages += chain->ops[i].opcode == V1C_OP_ROTATE;
+    p->chain_has_rot = p->n_rot_stages > 0;
+
+    // device copy of the chain for the interpreter
+    {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, sizeof(v1c_chain));
+        if (e == hipSuccess) {
+            p->allocs.push_back(d);
+            e = hipMemcpy(d, chain, sizeof(v1c_chain), hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) {
+            v1c_plan_destroy(p);
+            return fail(V1C_E_HIP, std::string("chain upload: ") + hipGetErrorString(e));
+        }
+        p->ctx.chain = (const v1c_chain*)d;
+    }
+
+    p->ana = analyze_chain(*chain);
+    if (p->ana.ok) {
+        p->table = build_radial_table(p->ana.radial);
+        if (ray_table_usable(p->table)) {
+            p->mode = MODE_RAY;
+            const RayAnalysis& a = p->ana;
+            const RayHostTables ht = build_ray_host_tables(a, dst_w, dst_h);
+            RayParams& r = p->ctx.ray;
+            if ((rc = upload(p, ht.col_s, &r.col_s)) || (rc = upload(p, ht.col_c, &r.col_c)) ||
+                (rc = upload(p, ht.col_h, &r.col_h)) || (rc = upload(p, ht.row_s, &r.row_s)) ||
+                (rc = upload(p, ht.row_c, &r.row_c)) || (rc = upload(p, ht.row_h, &r.row_h)) ||
+                (rc = upload(p, p->table.coef, &r.radial))) {
+                v1c_plan_destroy(p);
+                return rc;
+            }
+            r.inv_step = p->table.inv_step;
+            r.n_int = p->table.n_int;
+            r.var_is_w = p->table.var_is_w;
+            r.has_rot = a.has_rot;
+            for (int q = 0; q < 9; q++)
+                r.rot[q] = a.rot[q];
+            r.rx = a.rx, r.ry = a.ry, r.cx = a.cx, r.cy = a.cy;
+            p->ray_no_rot_safe = !a.has_rot && ray_reach_is_safe(p->table, ht.m_reach);
+            // tile flags for kMaxUnitsPerLaunch units
+            void* d = nullptr;
+            const size_t nflag = (size_t)p->tiles * kMaxUnitsPerLaunch * sizeof(uint32_t);
+            hipError_t e = hipMalloc(&d, nflag);
+            if (e == hipSuccess) {
+                p->allocs.push_back(d);
+                e = hipMemset(d, 0, nflag);
+            }
+            if (e != hipSuccess) {
+                v1c_plan_destroy(p);
+                return fail(V1C_E_HIP, std::string("tile flags: ") + hipGetErrorString(e));
+            }
+            p->ctx.tile_flags = (uint32_t*)d;
+        }
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        v1c_plan_destroy(p);
+        return fail(V1C_E_HIP, std::string("plan upload: ") + hipGetErrorString(e));
+    }
+    *out = p;
+    return V1C_OK;
+}
+
+extern "C" int v1c_plan_path(const v1c_plan* p)
+{
+    if (!p)
+        return fail(V1C_E_INVALID, "plan is NULL");
+    return p->mode == MODE_RAY ? 1 : 0;
+}
+
+static int fill_unit(const v1c_plan* p, const v1c_unit& in, DevUnit& out)
+{
+    if (!in.src || !in.dst)
+        return fail(V1C_E_INVALID, "unit src/dst is NULL");
+    const Geom& g = p->ctx.g;
+    if (in.src_pitch < (int64_t)g.src_w * g.cn || in.dst_pitch < (int64_t)g.dst_w * g.cn)
+        return fail(V1C_E_INVALID, "unit pitch smaller than a row");
+    if (in.has_rot && !p->chain_has_rot)
+        return fail(V1C_E_INVALID, "unit carries a rotation but the plan's chain has no rotate stage");
+    out.src = in.src, out.dst = in.dst;
+    out.src_pitch = in.src_pitch, out.dst_pitch = in.dst_pitch;
+    out.has_rot = in.has_rot ? 1 : 0;
+    out.pad = 0;
+    for (int q = 0; q < 9; q++)
+        out.rot[q] = in.has_rot ? in.rot[q] : 0.0;
+    return V1C_OK;
+}
+
+extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, int n_units)
+{
+    if (!p || !units || n_units <= 0)
+        return fail(V1C_E_INVALID, "v1c_plan_run: bad arguments");
+    DeviceGuard dg(p->device);
+    if (!dg.ok)
+        return fail(V1C_E_NODEVICE, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n_units; base += kMaxUnitsPerLaunch) {
+        const int n = std::min(kMaxUnitsPerLaunch, n_units - base);
+        UnitArgs ua;
+        std::memset(&ua, 0, sizeof(ua));
+        bool any_rot = false;
+        for (int k = 0; k < n; k++) {
+            int rc = fill_unit(p, units[base + k], ua.u[k]);
+            if (rc)
+                return rc;
+            any_rot |= ua.u[k].has_rot != 0;
+        }
+        if (p->mode == MODE_RAY) {
+            // units overriding one of SEVERAL rotate stages take the interpreter (rare); all other
+            // cases run the ray pass and, unless provably unnecessary, the fix-up pass
+            if (any_rot && p->n_rot_stages > 1) {
+                HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, ua, n, st));
+                continue;
+            }
+            HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
+            if (!p->ray_no_rot_safe || any_rot)
+                HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, ua, n, st));
+        } else {
+            HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, ua, n, st));
+        }
+    }
+    return V1C_OK;
+}
+
+extern "C" int v1c_plan_get_map(v1c_plan* p, void* stream, float* xmap, float* ymap, int64_t map_pitch,
+                                const double* rot_or_null)
+{
+    if (!p || !xmap || !ymap)
+        return fail(V1C_E_INVALID, "v1c_plan_get_map: bad arguments");
+    if (map_pitch < (int64_t)p->ctx.g.dst_w * 4 || (map_pitch & 3))
+        return fail(V1C_E_INVALID, "map_pitch too small or not a multiple of 4");
+    if (rot_or_null && !p->chain_has_rot)
+        return fail(V1C_E_INVALID, "rotation given but the plan's chain has no rotate stage");
+    DeviceGuard dg(p->device);
+    if (!dg.ok)
+        return fail(V1C_E_NODEVICE, "hipSetDevice failed");
+    UnitArgs ua;
+    std::memset(&ua, 0, sizeof(ua));
+    int mode = p->mode;
+    if (rot_or_null) {
+        ua.u[0].has_rot = 1;
+        for (int q = 0; q < 9; q++)
+            ua.u[0].rot[q] = rot_or_null[q];
+        if (p->n_rot_stages > 1)
+            mode = MODE_LITERAL;
+    }
+    HIP_TRY(launch_get_map(mode, p->ctx, ua, xmap, ymap, map_pitch, (hipStream_t)stream));
+    return V1C_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// one-shot entry points
+// ------------------------------------------------------------------------------------------
+struct PlanKey {
+    std::string bytes;
+    bool operator<(const PlanKey& o) const { return bytes < o.bytes; }
+};
+
+static std::mutex g_cache_mu;
+static std::map<PlanKey, v1c_plan*> g_cache;
+
+extern "C" int v1c_remap_fused(int device, void* stream, const uint8_t* src, int src_h, int src_w, int64_t src_pitch,
+                               int cn, uint8_t* dst, int dst_h, int dst_w, int64_t dst_pitch, const v1c_chain* chain,
+                               int interp, int border_mode, const uint8_t border_val[4])
+{
+    int rc = validate_chain(chain);
+    if (rc)
+        return rc;
+    PlanKey key;
+    key.bytes.assign((const char*)chain, sizeof(v1c_chain));
+    const int dims[9] = {device, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, 0};
+    key.bytes.append((const char*)dims, sizeof(dims));
+    key.bytes.append((const char*)(border_val ? border_val : (const uint8_t*)"\0\0\0\0"), 4);
+    v1c_plan* p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end())
+            p = it->second;
+    }
+    if (!p) {
+        rc = v1c_plan_create(&p, device, chain, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, border_val);
+        if (rc)
+            return rc;
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto ins = g_cache.emplace(key, p);
+        if (!ins.second) {  // another thread won the race
+            v1c_plan_destroy(p);
+            p = ins.first->second;
+        }
+    }
+    v1c_unit u;
+    std::memset(&u, 0, sizeof(u));
+    u.src = src, u.dst = dst, u.src_pitch = src_pitch, u.dst_pitch = dst_pitch;
+    return v1c_plan_run(p, stream, &u, 1);
+}
+
+extern "C" int v1c_remap_lut(int device, void* stream, const uint8_t* src, int src_h, int src_w, int64_t src_pitch,
+                             int cn, uint8_t* dst, int dst_h, int dst_w, int64_t dst_pitch, const float* xmap,
+                             const float* ymap, int64_t map_pitch, int interp, int border_mode,
+                             const uint8_t border_val[4])
+{
+    int rc = validate_geom(src_h, src_w, dst_h, dst_w, cn, interp, border_mode);
+    if (rc)
+        return rc;
+    if (!src || !dst || !xmap || !ymap)
+        return fail(V1C_E_INVALID, "v1c_remap_lut: NULL pointer");
+    if (map_pitch < (int64_t)dst_w * 4 || (map_pitch & 3))
+        return fail(V1C_E_INVALID, "map_pitch too small or not a multiple of 4");
+    if (src_pitch < (int64_t)src_w * cn || dst_pitch < (int64_t)dst_w * cn)
+        return fail(V1C_E_INVALID, "pitch smaller than a row");
+    DeviceGuard dg(device);
+    if (!dg.ok)
+        return fail(V1C_E_NODEVICE, "hipSetDevice failed");
+
+    // the only plan state a LUT launch needs is the interpolation table: cache one per
+    // (device, interp)
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, const short*> itabs;
+    KernelCtx c{};
+    Geom& g = c.g;
+    g.src_h = src_h, g.src_w = src_w, g.dst_h = dst_h, g.dst_w = dst_w, g.cn = cn;
+    g.interp = interp == V1C_INTER_AREA ? V1C_INTER_LINEAR : interp;
+    g.border = border_mode;
+    for (int k = 0; k < 4; k++)
+        g.cval[k] = border_val ? border_val[k] : 0;
+    if (g.interp == V1C_INTER_CUBIC || g.interp == V1C_INTER_LANCZOS4) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = itabs.find({device, g.interp});
+        if (it == itabs.end()) {
+            const std::vector<short> tab = build_itab(g.interp);
+            void* d = nullptr;
+            HIP_TRY(hipMalloc(&d, tab.size() * sizeof(short)));
+            HIP_TRY(hipMemcpy(d, tab.data(), tab.size() * sizeof(short), hipMemcpyHostToDevice));
+            it = itabs.emplace(std::make_pair(device, g.interp), (const short*)d).first;
+        }
+        c.itab = it->second;
+    }
+    c.xmap = xmap, c.ymap = ymap, c.map_pitch = map_pitch;
+    UnitArgs ua;
+    std::memset(&ua, 0, sizeof(ua));
+    ua.u[0].src = src, ua.u[0].dst = dst, ua.u[0].src_pitch = src_pitch, ua.u[0].dst_pitch = dst_pitch;
+    HIP_TRY(launch_remap(MODE_LUT, c, ua, 1, (hipStream_t)stream));
+    return V1C_OK;
+}
+
+// get_radius(), transformer.py:108-140.  One row (or column) of the image: copied to the host and
+// scanned there -- O(max(W, H)) bytes, synchronous by nature (the reference returns a float).
+extern "C" int v1c_get_radius(int device, void* stream, const uint8_t* img, int h, int w, int64_t pitch, int cn,
+                              int threshold, double* radius)
+{
+    if (!img || !radius || h <= 0 || w <= 0 || cn <= 0 || pitch < (int64_t)w * cn)
+        return fail(V1C_E_INVALID, "v1c_get_radius: bad arguments");
+    DeviceGuard dg(device);
+    if (!dg.ok)
+        return fail(V1C_E_NODEVICE, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    const bool use_row = w > h;  // transformer.py:126-129
+    const int n = use_row ? w : h;
+    std::vector<uint8_t> line((size_t)n * cn);
+    if (use_row) {
+        HIP_TRY(hipMemcpyAsync(line.data(), img + (int64_t)(h / 2) * pitch, (size_t)w * cn, hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(line.data(), cn, img + (int64_t)(w / 2) * cn, pitch, cn, h, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    int first_rise = -1, last_fall = -1, prev = 0;
+    for (int i = 0; i < n; i++) {
+        double s = 0;
+        for (int k = 0; k < cn; k++)
+            s += line[(size_t)i * cn + k];
+        const int black = (s / cn) < threshold;  // np.mean(axis=-1) < threshold, :133
+        if (i > 0) {
+            const int d = black - prev;  // np.diff, :134
+            if (d == 1 && first_rise < 0)
+                first_rise = i - 1;  // np.where(d == 1)[0][0], :137
+            if (d == -1)
+                last_fall = i - 1;  // np.where(d == -1)[0][-1], :138
+        }
+        prev = black;
+    }
+    if (first_rise < 0 || last_fall < 0)
+        return fail(V1C_E_INVALID, "no black border");  // the reference raises IndexError here
+    *radius = (last_fall - first_rise) / 2.0;  // :139 (sign quirk preserved)
+    return V1C_OK;
+}

@@ -1,0 +1,314 @@
+// radial_fit.hpp -- plan-time analysis of a lowered chain and fit of the radial table (host only).
+//
+// The fused "ray" kernel needs, per output pixel, G = F(theta) / sin(theta), where theta is the
+// angle between the (rotated) viewing ray and the optical axis and F is the composite of every
+// radial stage between the EquirectangularEncoder and the DenormalizeTransformer
+// (PolynomialScaler.transform_polar transformer.py:448-451, FisheyeEncoder.inverse_transform_polar
+// :379-397, ZoomTransformer :468-473 ...).  G is tabulated as a piecewise degree-7 polynomial in
+//     m = 1 - cos(theta)        when that is smooth down to m = 0 (F odd in theta), else in
+//     w = sqrt(m / 2) = sin(theta / 2).
+// The fit is done in long double (x87, 64-bit mantissa) against the reference's stage semantics
+// (including PolarRollTransformer's re-derivation of |theta| and roll, transformer.py:271-272) and
+// every interval is validated; intervals that miss the tolerance are flagged (NaN coefficients)
+// and pixels landing there are evaluated by the literal fp64 interpreter instead.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/vr180_remap.h"
+#include "v1c_core.hpp"
+
+namespace v1c {
+
+struct RayAnalysis {
+    bool ok = false;         // chain has the shape the ray kernel handles
+    bool has_rot = false;
+    double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // composition of consecutive rotate stages
+    double norm_cx = 0, norm_cy = 0, norm_s = 1;  // Normalize
+    double rx = 1, ry = 1, cx = 0, cy = 0;        // Denormalize
+    std::vector<v1c_op> radial;                   // radial / zoom stages, in order
+};
+
+struct RadialTable {
+    int var_is_w = 0;
+    int n_int = 0;
+    double inv_step = 0;
+    double u_max = 0;
+    int first_invalid = 0;  // index of the first flagged interval (== n_int if none)
+    int n_invalid = 0;
+    std::vector<double> coef;  // n_int * kRadialCoefs
+};
+
+constexpr double kTableMMax = 1.9375;  // theta up to ~159.6 deg
+constexpr int kTableIntervals = 1024;
+
+// Does the chain look like Normalize, EquirectEnc(lat_y), Rotate*, (Radial|Zoom)*, Denormalize ?
+inline RayAnalysis analyze_chain(const v1c_chain& ch)
+{
+    RayAnalysis a;
+    const int n = ch.n_ops;
+    if (n < 3 || ch.ops[0].opcode != V1C_OP_NORMALIZE || ch.ops[n - 1].opcode != V1C_OP_DENORMALIZE)
+        return a;
+    if (ch.ops[1].opcode != V1C_OP_EQUIRECT_ENC || ch.ops[1].iparam != 1)
+        return a;
+    a.norm_cx = ch.ops[0].p[0];
+    a.norm_cy = ch.ops[0].p[1];
+    a.norm_s = ch.ops[0].p[2];
+    const v1c_op& dn = ch.ops[n - 1];
+    a.rx = dn.p[0], a.ry = dn.p[1], a.cx = dn.p[2], a.cy = dn.p[3];
+    int k = 2;
+    for (; k < n - 1 && ch.ops[k].opcode == V1C_OP_ROTATE; k++) {
+        // v' = M_k (M_{k-1} ... v): left-multiply
+        const double* m = ch.ops[k].p;
+        double r[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                r[3 * i + j] = m[3 * i] * a.rot[j] + m[3 * i + 1] * a.rot[3 + j] + m[3 * i + 2] * a.rot[6 + j];
+        for (int i = 0; i < 9; i++)
+            a.rot[i] = r[i];
+        a.has_rot = true;
+    }
+    for (; k < n - 1; k++) {
+        const v1c_op& op = ch.ops[k];
+        if (op.opcode == V1C_OP_RADIAL || op.opcode == V1C_OP_ZOOM || op.opcode == V1C_OP_ZOOM_INV)
+            a.radial.push_back(op);
+        else
+            return a;  // rotation after a radial stage, decoders ...: literal path
+    }
+    a.ok = true;
+    return a;
+}
+
+inline long double radial_ld(const v1c_op& op, long double t)
+{
+    const long double half_pi = (long double)1.5707963267948966;  // the reference's float64 np.pi/2
+    const long double sqrt2 = (long double)1.4142135623730951;    // float64 np.sqrt(2)
+    switch (op.iparam) {
+    case V1C_RAD_ENC_RECTILINEAR:   return atanl(t);
+    case V1C_RAD_ENC_STEREOGRAPHIC: return 2 * atanl(t);
+    case V1C_RAD_ENC_EQUIDISTANT:   return t * half_pi;
+    case V1C_RAD_ENC_EQUISOLID:     return 2 * asinl(t / sqrt2);
+    case V1C_RAD_ENC_ORTHOGRAPHIC:  return asinl(t);
+    case V1C_RAD_DEC_RECTILINEAR:   return tanl(t);
+    case V1C_RAD_DEC_STEREOGRAPHIC: return 2 * tanl(t / 2);
+    case V1C_RAD_DEC_EQUIDISTANT:   return t / half_pi;
+    case V1C_RAD_DEC_EQUISOLID:     return sqrt2 * sinl(t / 2);
+    case V1C_RAD_DEC_ORTHOGRAPHIC:  return sinl(t);
+    case V1C_RAD_POLYNOMIAL: {
+        long double y = 0;
+        for (int k = op.nparam - 1; k >= 0; k--)
+            y = y * t + (long double)op.p[k];
+        return y;
+    }
+    case V1C_RAD_RECTDEC_FWD: return tanl(t) * (long double)op.p[0];
+    case V1C_RAD_RECTDEC_INV: return atanl(t / (long double)op.p[0]);
+    default: return NAN;
+    }
+}
+
+// signed radial coordinate after all stages for a point at angle theta > 0 off the axis
+inline bool composite_F(const std::vector<v1c_op>& st, long double theta, long double& out)
+{
+    long double t = theta;
+    for (const v1c_op& op : st) {
+        if (op.opcode == V1C_OP_ZOOM) {
+            t = t / (long double)op.p[0];
+        } else if (op.opcode == V1C_OP_ZOOM_INV) {
+            t = t * (long double)op.p[0];
+        } else {
+            // PolarRollTransformer.transform: theta_in = sqrt(x^2+y^2) = |t|; a negative t flips
+            // the direction (roll + pi), so the stage output carries the sign of its input.
+            const long double s = t < 0 ? -1.0L : 1.0L;
+            t = s * radial_ld(op, fabsl(t));
+        }
+        if (!std::isfinite((double)t))
+            return false;
+    }
+    out = t;
+    return true;
+}
+
+inline bool G_of_u(const std::vector<v1c_op>& st, int var_is_w, long double u, long double& g)
+{
+    long double w = var_is_w ? u : sqrtl(u / 2);
+    if (!(w > 0) || !(w < 1))
+        return false;
+    const long double theta = 2 * asinl(w);
+    const long double rho = 2 * w * sqrtl((1 - w) * (1 + w));  // sin(theta)
+    long double f;
+    if (!composite_F(st, theta, f))
+        return false;
+    g = f / rho;
+    return std::isfinite((double)g);
+}
+
+// solve V c = y, V[i][k] = z_i^k, (n x n), long double, partial pivoting
+inline bool solve_vandermonde(int n, const long double* z, const long double* y, long double* c)
+{
+    long double A[16][17];
+    for (int i = 0; i < n; i++) {
+        long double p = 1;
+        for (int k = 0; k < n; k++, p *= z[i])
+            A[i][k] = p;
+        A[i][n] = y[i];
+    }
+    for (int col = 0; col < n; col++) {
+        int piv = col;
+        for (int r = col + 1; r < n; r++)
+            if (fabsl(A[r][col]) > fabsl(A[piv][col]))
+                piv = r;
+        if (A[piv][col] == 0)
+            return false;
+        if (piv != col)
+            for (int k = 0; k <= n; k++)
+                std::swap(A[piv][k], A[col][k]);
+        for (int r = col + 1; r < n; r++) {
+            const long double f = A[r][col] / A[col][col];
+            for (int k = col; k <= n; k++)
+                A[r][k] -= f * A[col][k];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        long double s = A[i][n];
+        for (int k = i + 1; k < n; k++)
+            s -= A[i][k] * c[k];
+        c[i] = s / A[i][i];
+    }
+    return true;
+}
+
+inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w)
+{
+    RadialTable T;
+    T.var_is_w = var_is_w;
+    T.n_int = kTableIntervals;
+    T.u_max = var_is_w ? std::sqrt(kTableMMax / 2) : kTableMMax;
+    // a step that is exactly representable keeps t = u * inv_step monotone and cheap
+    T.inv_step = std::ldexp(std::floor(std::ldexp(T.n_int / T.u_max, 20)), -20);
+    const long double step = 1.0L / (long double)T.inv_step;
+    T.coef.assign((size_t)T.n_int * kRadialCoefs, NAN);
+    T.first_invalid = T.n_int;
+    const int n = kRadialCoefs;
+    long double zn[16];
+    for (int k = 0; k < n; k++)
+        zn[k] = 0.5L * cosl(M_PIl * (2 * k + 1) / (2.0L * n));  // Chebyshev nodes on [-0.5, 0.5]
+    const double tol = 1.5e-15;
+    for (int i = 0; i < T.n_int; i++) {
+        const long double a = i * step;
+        long double y[16], c[16];
+        bool good = true;
+        for (int k = 0; k < n && good; k++)
+            good = G_of_u(st, var_is_w, a + step * (zn[k] + 0.5L), y[k]);
+        if (good)
+            good = solve_vandermonde(n, zn, y, c);
+        double cd[16];
+        if (good) {
+            for (int k = 0; k < n; k++)
+                cd[k] = (double)c[k];
+            // validate the DOUBLE Horner the kernel runs against the long-double function
+            const int ntest = 4 * n + 1;
+            long double gmax = 0;
+            std::vector<long double> gt(ntest), zt(ntest);
+            for (int q = 0; q < ntest && good; q++) {
+                zt[q] = -0.5L + (q + 0.5L) / ntest;
+                good = G_of_u(st, var_is_w, a + step * (zt[q] + 0.5L), gt[q]);
+                gmax = fmaxl(gmax, fabsl(gt[q]));
+            }
+            for (int q = 0; q < ntest && good; q++) {
+                const double z = (double)zt[q];
+                double g = cd[n - 1];
+                for (int k = n - 2; k >= 0; k--)
+                    g = std::fma(g, z, cd[k]);
+                // the double z differs from zt by <= 1 ulp of 0.5; compare at the long-double z the
+                // function was sampled at (slope * 1e-16 is far below tol)
+                if (!(fabsl((long double)g - gt[q]) <= tol * gmax))
+                    good = false;
+            }
+        }
+        if (good) {
+            for (int k = 0; k < n; k++)
+                T.coef[(size_t)i * n + k] = cd[k];
+        } else {
+            T.n_invalid++;
+            if (T.first_invalid == T.n_int)
+                T.first_invalid = i;
+        }
+    }
+    return T;
+}
+
+// Choose the table variable: m when that fits the front hemisphere (theta <= 90 deg) without a
+// flagged interval, otherwise whichever of m / w flags fewer intervals there.
+inline RadialTable build_radial_table(const std::vector<v1c_op>& st)
+{
+    auto bad_front = [](const RadialTable& T) {
+        const double u_front = T.var_is_w ? std::sqrt(0.5) : 1.0;
+        const int last = std::min(T.n_int, (int)(u_front * T.inv_step) + 1);
+        int bad = 0;
+        for (int i = 0; i < last; i++)
+            bad += std::isnan(T.coef[(size_t)i * kRadialCoefs]);
+        return bad;
+    };
+    RadialTable M = fit_radial_table(st, 0);
+    if (bad_front(M) == 0)
+        return M;
+    RadialTable W = fit_radial_table(st, 1);
+    return bad_front(W) < bad_front(M) ? W : M;
+}
+
+// Separable tables of the ray path (host copies) and the largest table variable any pixel of
+// an UNROTATED chain can reach.
+struct RayHostTables {
+    std::vector<double> col_s, col_c, col_h, row_s, row_c, row_h;
+    double m_reach = 0;
+};
+
+#pragma clang fp contract(off)  // follow the reference's rounding order for lat / lon
+inline RayHostTables build_ray_host_tables(const RayAnalysis& a, int dst_w, int dst_h)
+{
+    RayHostTables t;
+    const double half_pi = 1.5707963267948966;
+    t.col_s.resize(dst_w), t.col_c.resize(dst_w), t.col_h.resize(dst_w);
+    t.row_s.resize(dst_h), t.row_c.resize(dst_h), t.row_h.resize(dst_h);
+    double h_max = 0, h_min = 1e300;
+    for (int i = 0; i < dst_w; i++) {
+        // NormalizeTransformer (transformer.py:162) then lon = x * (pi/2) (:547)
+        const double xn = ((double)i - a.norm_cx) / a.norm_s * 2;
+        const double lon = xn * half_pi;
+        const double sh = std::sin(lon * 0.5);
+        t.col_s[i] = std::sin(lon), t.col_c[i] = std::cos(lon), t.col_h[i] = 2 * sh * sh;
+        h_max = std::max(h_max, t.col_h[i]), h_min = std::min(h_min, t.col_h[i]);
+    }
+    for (int j = 0; j < dst_h; j++) {
+        const double yn = ((double)j - a.norm_cy) / a.norm_s * 2;  // :163
+        const double lat = yn * half_pi;                            // :546
+        const double sh = std::sin(lat * 0.5);
+        t.row_s[j] = std::sin(lat), t.row_c[j] = std::cos(lat), t.row_h[j] = 2 * sh * sh;
+        t.m_reach = std::max(t.m_reach, t.row_h[j] + std::max(t.row_c[j] * h_max, t.row_c[j] * h_min));
+    }
+    return t;
+}
+#pragma clang fp contract(fast)
+
+// true when the ray path should be used at all: at most a quarter of the front hemisphere's
+// intervals are flagged
+inline bool ray_table_usable(const RadialTable& T)
+{
+    const int front = std::min(T.n_int, T.var_is_w ? (int)(std::sqrt(0.5) * T.inv_step) : (int)(1.0 * T.inv_step));
+    int bad = 0;
+    for (int i = 0; i < front; i++)
+        bad += std::isnan(T.coef[(size_t)i * kRadialCoefs]);
+    return bad * 4 < front;
+}
+
+// true when no pixel of an unrotated chain can land in a flagged interval
+inline bool ray_reach_is_safe(const RadialTable& T, double m_reach)
+{
+    const double u = (T.var_is_w ? std::sqrt(m_reach / 2) : m_reach) * (1 + 1e-9);
+    return u * T.inv_step < (double)T.first_invalid;
+}
+
+}  // namespace v1c

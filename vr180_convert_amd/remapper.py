@@ -1,0 +1,438 @@
+"""``get_map`` / ``apply`` / ``apply_lr`` of the reference, running on MI355X.
+
+Drop-in for ``vr180_convert/remapper.py`` (same names, keyword signatures incl. the ``boarder_*``
+spelling, return types and error behaviour).  Instead of evaluating the transformer chain as
+NumPy passes over a meshgrid and handing a float32 map to ``cv2.remap`` (remapper.py:50-58,
+388-398), the chain is lowered once (``chain.lower_for_get_map``) and evaluated per output pixel
+inside the HIP kernel that also does cv2.remap's fixed-point gather; eyes are written straight
+into their half of the side-by-side buffer (remapper.py:517-518).
+
+Inputs may be paths, ``numpy`` arrays (uploaded, results come back as ``numpy``) or CUDA
+``torch`` tensors (device-resident in and out -- what ``bench.py`` times).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from logging import getLogger
+from pathlib import Path
+from typing import Any, Literal, Sequence
+
+import numpy as np
+import torch
+from numpy.typing import NDArray
+
+from . import _abi, _io, _native
+from .chain import NotLowerable, TransformerBase, get_radius, lower_for_get_map
+from .chain import DenormalizeTransformer, NormalizeTransformer
+
+LOG = getLogger(__name__)
+
+INTER_LANCZOS4 = _abi.INTER_LANCZOS4
+BORDER_CONSTANT = _abi.BORDER_CONSTANT
+
+
+# --------------------------------------------------------------------------------------------
+# device plumbing
+# --------------------------------------------------------------------------------------------
+def _device(device: Any = None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise _native.EngineUnavailable(
+            "no HIP device visible: vr180_convert_amd runs the remap on an MI355X and has no CPU fallback"
+        )
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise ValueError("device must be a cuda (HIP) device")
+    return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+
+
+def _stream_ptr(dev: torch.device) -> int:
+    return int(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def border_scalar(value: Any) -> np.ndarray:
+    """Python ``borderValue`` -> saturated uint8[4] the way cv2 fills its Scalar: a bare int sets
+    only component 0, a tuple sets the leading components."""
+    vals = [value] if np.isscalar(value) else list(value)
+    out = np.zeros(4, np.uint8)
+    for i, v in enumerate(vals[:4]):
+        out[i] = int(min(255, max(0, np.rint(float(v)))))
+    return out
+
+
+def _check_image_tensor(t: torch.Tensor, what: str) -> None:
+    if t.dtype != torch.uint8 or t.dim() != 3:
+        raise TypeError(f"{what} must be a uint8 (H, W, C) tensor")
+    if t.stride(2) != 1 or t.stride(1) != t.shape[2] or t.stride(0) < t.shape[1] * t.shape[2]:
+        raise ValueError(f"{what}: pixels must be contiguous within a row (column-sliced views are fine)")
+
+
+class Plan:
+    """Owner of one ``v1c_plan`` (see include/vr180_remap.h: v1c_plan_create)."""
+
+    def __init__(self, chain: _abi.Chain, *, src_hw, dst_wh, cn, interpolation, border_mode, border_value, device):
+        self.device = _device(device)
+        self.src_hw, self.dst_wh, self.cn = tuple(src_hw), tuple(dst_wh), int(cn)
+        self._h = C.c_void_p()
+        bv = border_scalar(border_value)
+        rc = _native.lib().v1c_plan_create(
+            C.byref(self._h), self.device.index, C.byref(chain), src_hw[0], src_hw[1], dst_wh[1], dst_wh[0],
+            cn, int(interpolation), int(border_mode), bv.ctypes.data,
+        )
+        _native.check(rc, "v1c_plan_create")
+
+    @property
+    def path(self) -> str:
+        """'ray' (fused separable tables + radial table) or 'literal' (fp64 interpreter)."""
+        return "ray" if _native.lib().v1c_plan_path(self._h) == 1 else "literal"
+
+    def run(self, srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor], rots: Sequence[Any] | None = None) -> None:
+        n = len(srcs)
+        if n == 0 or len(dsts) != n or (rots is not None and len(rots) != n):
+            raise ValueError("srcs / dsts / rots lengths differ or are empty")
+        units = (_abi.Unit * n)()
+        for k, (s, d) in enumerate(zip(srcs, dsts)):
+            _check_image_tensor(s, "src")
+            _check_image_tensor(d, "dst")
+            if tuple(s.shape) != (*self.src_hw, self.cn) or tuple(d.shape) != (self.dst_wh[1], self.dst_wh[0], self.cn):
+                raise ValueError(f"unit {k}: tensor shapes {tuple(s.shape)} -> {tuple(d.shape)} do not match the plan")
+            if s.device != self.device or d.device != self.device:
+                raise ValueError(f"unit {k}: tensors must live on {self.device}")
+            units[k].src, units[k].dst = s.data_ptr(), d.data_ptr()
+            units[k].src_pitch, units[k].dst_pitch = s.stride(0), d.stride(0)
+            if rots is not None and rots[k] is not None:
+                m = np.asarray(rots[k], dtype=np.float64).reshape(9)
+                units[k].has_rot = 1
+                for q in range(9):
+                    units[k].rot[q] = m[q]
+        rc = _native.lib().v1c_plan_run(self._h, _stream_ptr(self.device), units, n)
+        _native.check(rc, "v1c_plan_run")
+
+    def get_map(self, rot: Any = None) -> tuple[torch.Tensor, torch.Tensor]:
+        w, h = self.dst_wh
+        xm = torch.empty((h, w), dtype=torch.float32, device=self.device)
+        ym = torch.empty((h, w), dtype=torch.float32, device=self.device)
+        r = None if rot is None else np.ascontiguousarray(np.asarray(rot, np.float64).reshape(9))
+        rc = _native.lib().v1c_plan_get_map(
+            self._h, _stream_ptr(self.device), xm.data_ptr(), ym.data_ptr(), xm.stride(0) * 4,
+            None if r is None else r.ctypes.data,
+        )
+        _native.check(rc, "v1c_plan_get_map")
+        return xm, ym
+
+    def __del__(self):
+        try:
+            if self._h:
+                _native.lib().v1c_plan_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
+
+
+_PLANS: "OrderedDict[tuple, Plan]" = OrderedDict()
+_PLAN_CACHE_SIZE = 32
+
+
+def _plan_for(chain: _abi.Chain, *, src_hw, dst_wh, cn, interpolation, border_mode, border_value, device) -> Plan:
+    dev = _device(device)
+    key = (chain.key(), tuple(src_hw), tuple(dst_wh), cn, int(interpolation), int(border_mode),
+           border_scalar(border_value).tobytes(), dev.index)
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = Plan(chain, src_hw=src_hw, dst_wh=dst_wh, cn=cn, interpolation=interpolation,
+                    border_mode=border_mode, border_value=border_value, device=dev)
+        _PLANS[key] = plan
+        while len(_PLANS) > _PLAN_CACHE_SIZE:
+            _PLANS.popitem(last=False)
+    else:
+        _PLANS.move_to_end(key)
+    return plan
+
+
+def _split_single_rotation(chain: _abi.Chain) -> tuple[_abi.Chain, np.ndarray | None]:
+    """Chains that differ only in the matrix of their single rotate stage (BASELINE config 5:
+    per-frame, per-eye calibration, cli.py:308-319) share one plan: returns the chain with that
+    matrix blanked plus the matrix, which then travels per unit (v1c_unit.rot).  Chains with no
+    or several rotate stages are returned unchanged."""
+    idx = [i for i in range(chain.n_ops) if chain.ops[i].opcode == _abi.OP_ROTATE]
+    if len(idx) != 1:
+        return chain, None
+    i = idx[0]
+    rot = np.array(chain.ops[i].p[:9], dtype=np.float64)
+    blank = _abi.Chain.from_buffer_copy(bytes(chain))
+    for q in range(9):
+        blank.ops[i].p[q] = 1.0 if q in (0, 4, 8) else 0.0
+    return blank, rot
+
+
+def _host_map(transformer: TransformerBase, *, radius, size_input, size_output):
+    """The reference's own recipe (remapper.py:50-58) for chains that cannot be lowered: user
+    subclasses only expose NumPy ``transform``, so the map has to be computed by calling it."""
+    xmap, ymap = np.meshgrid(np.arange(size_output[0]), np.arange(size_output[1]))
+    full = (
+        NormalizeTransformer()
+        * transformer
+        * DenormalizeTransformer(scale=(radius, radius), center=(size_input[1] // 2, size_input[0] // 2))
+    )
+    xmap, ymap = full.transform(xmap, ymap)
+    return xmap.astype(np.float32), ymap.astype(np.float32)
+
+
+def remap_tensors(
+    transformer: TransformerBase | Sequence[TransformerBase],
+    srcs: Sequence[torch.Tensor],
+    dsts: Sequence[torch.Tensor],
+    *,
+    radius: float,
+    interpolation: int = INTER_LANCZOS4,
+    boarder_mode: int = BORDER_CONSTANT,
+    boarder_value: Any = 0,
+    size_input: tuple[int, int] | None = None,
+) -> list[str]:
+    """Device-resident core of ``apply``: remap every ``srcs[k]`` into ``dsts[k]`` (same device,
+    same shapes) on the current stream.  ``transformer`` is one chain shared by all units
+    (remapper.py:381-398) or one per unit.  Returns the code path used per launch group
+    ('ray' / 'literal' / 'lut').  Nothing is synchronised."""
+    n = len(srcs)
+    if n == 0:
+        return []
+    per_unit = list(transformer) if isinstance(transformer, (list, tuple)) else [transformer] * n
+    if len(per_unit) != n or len(dsts) != n:
+        raise ValueError("need one transformer and one dst per src")
+    dev = srcs[0].device
+    src_hw = (int(srcs[0].shape[0]), int(srcs[0].shape[1]))
+    cn = int(srcs[0].shape[2])
+    dst_wh = (int(dsts[0].shape[1]), int(dsts[0].shape[0]))
+    size_input = size_input or src_hw
+
+    groups: "OrderedDict[bytes, dict]" = OrderedDict()
+    lowered: dict[int, Any] = {}
+    paths: list[str] = []
+    for k, t in enumerate(per_unit):
+        if id(t) not in lowered:
+            try:
+                lowered[id(t)] = lower_for_get_map(t, radius=radius, size_input=size_input, size_output=dst_wh)
+            except NotLowerable as e:
+                LOG.warning("transformer chain is not lowerable (%s): map evaluated by its own NumPy transform()", e)
+                lowered[id(t)] = None
+        chain = lowered[id(t)]
+        if chain is None:
+            xm, ym = _host_map(t, radius=radius, size_input=size_input, size_output=dst_wh)
+            xm_d, ym_d = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
+            bv = border_scalar(boarder_value)
+            _check_image_tensor(srcs[k], "src")
+            _check_image_tensor(dsts[k], "dst")
+            rc = _native.lib().v1c_remap_lut(
+                dev.index, _stream_ptr(dev), srcs[k].data_ptr(), srcs[k].shape[0], srcs[k].shape[1], srcs[k].stride(0), cn,
+                dsts[k].data_ptr(), dst_wh[1], dst_wh[0], dsts[k].stride(0), xm_d.data_ptr(), ym_d.data_ptr(),
+                xm_d.stride(0) * 4, int(interpolation), int(boarder_mode), bv.ctypes.data,
+            )
+            _native.check(rc, "v1c_remap_lut")
+            paths.append("lut")
+            continue
+        shared, rot = _split_single_rotation(chain)
+        key = bytes(shared) + repr(tuple(srcs[k].shape)).encode()  # different source sizes: different plans
+        g = groups.setdefault(key, {"chain": shared, "src_hw": tuple(srcs[k].shape[:2]), "srcs": [], "dsts": [], "rots": []})
+        g["srcs"].append(srcs[k])
+        g["dsts"].append(dsts[k])
+        g["rots"].append(rot)
+    for g in groups.values():
+        plan = _plan_for(g["chain"], src_hw=g["src_hw"], dst_wh=dst_wh, cn=cn, interpolation=interpolation,
+                         border_mode=boarder_mode, border_value=boarder_value, device=dev)
+        plan.run(g["srcs"], g["dsts"], None if g["rots"][0] is None else g["rots"])
+        paths.append(plan.path)
+    return paths
+
+
+# --------------------------------------------------------------------------------------------
+# reference API
+# --------------------------------------------------------------------------------------------
+def get_map(
+    transformer: TransformerBase,
+    *,
+    radius: float,
+    size_input: tuple[int, int],
+    size_output: tuple[int, int] = (2048, 2048),
+    device: Any = None,
+) -> tuple[NDArray[np.float32], NDArray[np.float32]]:
+    """Generate the remap map (reference remapper.py:23-59): float32 ``xmap, ymap`` of shape
+    ``(size_output[1], size_output[0])``.  Evaluated on the GPU by the same code the fused kernel
+    uses; non-lowerable chains are evaluated through their own ``transform`` like the reference."""
+    try:
+        chain = lower_for_get_map(transformer, radius=radius, size_input=size_input, size_output=size_output)
+    except NotLowerable:
+        return _host_map(transformer, radius=radius, size_input=size_input, size_output=size_output)
+    plan = _plan_for(chain, src_hw=(max(1, size_input[0]), max(1, size_input[1])), dst_wh=size_output, cn=3,
+                     interpolation=_abi.INTER_LINEAR, border_mode=BORDER_CONSTANT, border_value=0, device=device)
+    xm, ym = plan.get_map()
+    return xm.cpu().numpy(), ym.cpu().numpy()
+
+
+def get_radius_smart(radius: float | Literal["auto", "max"], images: Sequence[Any]) -> float:
+    """Reference remapper.py:62-90.  ``images`` may be numpy arrays or device tensors."""
+    if isinstance(radius, str) and radius == "auto":
+        radius_ = max(_get_radius_any(im) for im in images)
+    elif isinstance(radius, str) and radius == "max":
+        radius_ = min(images[0].shape[0] / 2, images[0].shape[1] / 2)
+    else:
+        radius_ = radius
+    LOG.info(f"Radius: {radius_}, strategy: {radius}, image shape: {tuple(images[0].shape)}")
+    return radius_
+
+
+def _get_radius_any(im: Any, threshold: int = 10) -> float:
+    if isinstance(im, torch.Tensor) and im.is_cuda:
+        _check_image_tensor(im, "image")
+        r = C.c_double()
+        rc = _native.lib().v1c_get_radius(im.device.index, _stream_ptr(im.device), im.data_ptr(), im.shape[0], im.shape[1],
+                                          im.stride(0), im.shape[2], threshold, C.byref(r))
+        if rc == _abi.E_INVALID and b"no black border" in _native.lib().v1c_last_error():
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")  # what the reference raises
+        _native.check(rc, "v1c_get_radius")
+        return r.value
+    return float(get_radius(np.asarray(im), threshold=threshold))
+
+
+def _to_device(img: Any, dev: torch.device) -> torch.Tensor:
+    if isinstance(img, torch.Tensor):
+        return img if img.device == dev else img.to(dev)
+    a = np.asarray(img)
+    if a.dtype != np.uint8:
+        raise TypeError("images must be uint8")  # cv2.remap's fixed-point path is the uint8 one
+    if a.ndim == 2:
+        a = a[..., None]
+    # column-sliced views (remapper.py:455-456) are made contiguous on the host before upload
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=False)
+
+
+def apply(
+    transformer: TransformerBase,
+    *,
+    in_paths: Sequence[Path | str | NDArray] | Path | str | NDArray,
+    out_paths: Sequence[Path | str] | None | Path | str = None,
+    size_output: tuple[int, int] = (2048, 2048),
+    interpolation: int = INTER_LANCZOS4,
+    boarder_mode: int = BORDER_CONSTANT,
+    boarder_value: int | tuple[int, int, int] = 0,
+    radius: float | Literal["auto", "max"] = "auto",
+    device: Any = None,
+) -> Sequence[NDArray[np.uint8]]:
+    """Apply transformer to images (reference remapper.py:324-403).
+
+    Returns one ``(size_output[1], size_output[0], C)`` uint8 array per input (CUDA tensors in ->
+    CUDA tensors out).  One map is shared by all images and, like the reference, takes its
+    geometry from ``images[0]``."""
+    in_paths_ = [in_paths] if isinstance(in_paths, (str, Path, np.ndarray, torch.Tensor)) else in_paths
+    out_paths_ = [out_paths] if isinstance(out_paths, (str, Path)) else out_paths
+    del in_paths, out_paths
+
+    images = [_io.imread(p) if isinstance(p, (str, Path)) else p for p in in_paths_]
+    radius_ = get_radius_smart(radius, images)
+    on_device = all(isinstance(im, torch.Tensor) and im.is_cuda for im in images)
+    dev = images[0].device if on_device else _device(device)
+
+    srcs = [_to_device(im, dev) for im in images]
+    cn = srcs[0].shape[2]
+    dsts = [torch.empty((size_output[1], size_output[0], cn), dtype=torch.uint8, device=dev) for _ in srcs]
+    if boarder_mode == _abi.BORDER_TRANSPARENT:
+        for d in dsts:  # cv2 leaves skipped pixels uninitialised; make them deterministic
+            d.zero_()
+    remap_tensors(transformer, srcs, dsts, radius=radius_, interpolation=interpolation, boarder_mode=boarder_mode,
+                  boarder_value=boarder_value, size_input=(int(srcs[0].shape[0]), int(srcs[0].shape[1])))
+    if on_device:
+        results: list[Any] = dsts
+    else:
+        results = [d.cpu().numpy() for d in dsts]
+        results = [r[..., 0] if np.asarray(im).ndim == 2 else r for r, im in zip(results, images)]
+    if out_paths_ is not None:
+        for to_path, image in zip(out_paths_, results):
+            _io.imwrite(to_path, image.cpu().numpy() if isinstance(image, torch.Tensor) else image)
+    return results
+
+
+def apply_lr_tensors(
+    transformer: TransformerBase | tuple[TransformerBase, TransformerBase],
+    left: torch.Tensor,
+    right: torch.Tensor,
+    *,
+    out: torch.Tensor | None = None,
+    size_output: tuple[int, int] = (2048, 2048),
+    interpolation: int = INTER_LANCZOS4,
+    boarder_mode: int = BORDER_CONSTANT,
+    boarder_value: Any = 0,
+    radius: float | Literal["auto", "max"] = "auto",
+) -> torch.Tensor:
+    """Device-resident ``apply_lr`` (merge=False): both eyes are remapped by ONE launch straight
+    into the halves of the ``(H, 2W, C)`` side-by-side tensor (remapper.py:460-484, 517-518)."""
+    w, h = size_output
+    cn = left.shape[2]
+    if out is None:
+        out = torch.empty((h, 2 * w, cn), dtype=torch.uint8, device=left.device)
+        if boarder_mode == _abi.BORDER_TRANSPARENT:
+            out.zero_()
+    halves = [out[:, :w], out[:, w:]]
+    if isinstance(transformer, tuple):
+        # per-eye transformer AND per-eye radius estimate (remapper.py:460-473)
+        r = [get_radius_smart(radius, [im]) for im in (left, right)]
+        if r[0] == r[1]:
+            remap_tensors(list(transformer), [left, right], halves, radius=r[0], interpolation=interpolation,
+                          boarder_mode=boarder_mode, boarder_value=boarder_value)
+        else:
+            for t, im, d, rr in zip(transformer, (left, right), halves, r):
+                remap_tensors(t, [im], [d], radius=rr, interpolation=interpolation, boarder_mode=boarder_mode,
+                              boarder_value=boarder_value)
+    else:
+        r_ = get_radius_smart(radius, [left, right])
+        remap_tensors(transformer, [left, right], halves, radius=r_, interpolation=interpolation,
+                      boarder_mode=boarder_mode, boarder_value=boarder_value,
+                      size_input=(int(left.shape[0]), int(left.shape[1])))
+    return out
+
+
+def apply_lr(
+    transformer: TransformerBase | tuple[TransformerBase, TransformerBase],
+    *,
+    left_path: Path | str | NDArray,
+    right_path: Path | str | NDArray,
+    out_path: Path | str | None,
+    size_output: tuple[int, int] = (2048, 2048),
+    interpolation: int = INTER_LANCZOS4,
+    boarder_mode: int = BORDER_CONSTANT,
+    boarder_value: int | tuple[int, int, int] = 0,
+    radius: float | Literal["auto", "max"] = "auto",
+    merge: bool = False,
+    device: Any = None,
+) -> None:
+    """Apply transformer to a pair of images and save them side by side (reference
+    remapper.py:406-520).  ``left_path == right_path`` means one file holding both eyes."""
+    if isinstance(left_path, (str, Path)) and isinstance(right_path, (str, Path)) and left_path == right_path:
+        image = _io.imread(left_path)
+        left_path = image[:, : image.shape[1] // 2]
+        right_path = image[:, image.shape[1] // 2 :]
+    left, right = (_io.imread(p) if isinstance(p, (str, Path)) else p for p in (left_path, right_path))
+    on_device = isinstance(left, torch.Tensor) and left.is_cuda
+    dev = left.device if on_device else _device(device)
+    lt, rt = _to_device(left, dev), _to_device(right, dev)
+    # "auto" radius: estimated on the host images when they are numpy (one row each)
+    sbs = apply_lr_tensors(transformer, lt, rt, size_output=size_output, interpolation=interpolation,
+                           boarder_mode=boarder_mode, boarder_value=boarder_value,
+                           radius=_radius_for_pair(radius, transformer, left, right))
+    combine = sbs.cpu().numpy()
+    if merge:
+        combine = _io.anaglyph(combine[:, : size_output[0]], combine[:, size_output[0] :])
+    if out_path is not None:
+        _io.imwrite(out_path, combine)
+        LOG.info(f"Saved to {Path(out_path).absolute()}")
+
+
+def _radius_for_pair(radius, transformer, left, right):
+    """``radius`` argument to hand to apply_lr_tensors: estimate 'auto' on the host images when
+    they are numpy (the reference's estimate, remapper.py:82-84), else let the device path do it."""
+    if isinstance(radius, str) and radius == "auto" and not isinstance(left, torch.Tensor):
+        if isinstance(transformer, tuple):
+            r = [get_radius_smart("auto", [im]) for im in (left, right)]
+            return r[0] if r[0] == r[1] else radius
+        return get_radius_smart("auto", [left, right])
+    return radius
