@@ -65,7 +65,10 @@ def border_scalar(value: Any) -> np.ndarray:
 def _check_image_tensor(t: torch.Tensor, what: str) -> None:
     if t.dtype != torch.uint8 or t.dim() != 3:
         raise TypeError(f"{what} must be a uint8 (H, W, C) tensor")
-    if t.stride(2) != 1 or t.stride(1) != t.shape[2] or t.stride(0) < t.shape[1] * t.shape[2]:
+    cn = t.shape[2]
+    if (cn > 1 and t.stride(2) != 1) or (t.shape[1] > 1 and t.stride(1) != cn) or (
+        t.shape[0] > 1 and t.stride(0) < t.shape[1] * cn
+    ):
         raise ValueError(f"{what}: pixels must be contiguous within a row (column-sliced views are fine)")
 
 
