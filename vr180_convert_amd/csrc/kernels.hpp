@@ -21,11 +21,19 @@ struct KernelCtx {
     const float* xmap;        // MODE_LUT
     const float* ymap;
     int64_t map_pitch;        // bytes
+    int abl;                  // experiment switches (V1C_ABL env var; 0 in production)
 };
 
 int tiles_per_unit(const Geom& g);
 hipError_t launch_remap(int mode, const KernelCtx& c, const UnitArgs& ua, int n_units, hipStream_t stream);
 hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float* xmap, float* ymap, int64_t pitch,
                           hipStream_t stream);
+
+// hot configuration (CN = 3, INTER_LINEAR, BORDER_CONSTANT, ray mode): kernels_fast.hip
+// LDS-tiled version of the same (kernels_tile.hip)
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, hipStream_t stream);
+hipError_t launch_ray_lin3_persist(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, int tab_entries,
+                                   int num_cus, hipStream_t stream);
+hipError_t launch_ray_lin3(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, hipStream_t stream);
 
 }  // namespace v1c

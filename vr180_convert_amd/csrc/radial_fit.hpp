@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "../../include/vr180_remap.h"
@@ -39,6 +40,7 @@ struct RadialTable {
     double u_max = 0;
     int first_invalid = 0;  // index of the first flagged interval (== n_int if none)
     int n_invalid = 0;
+    int n_extended = 0;     // intervals whose polynomial is also valid on the 3x wider range
     std::vector<double> coef;  // n_int * kRadialCoefs
 };
 
@@ -205,32 +207,50 @@ inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w)
         if (good)
             good = solve_vandermonde(n, zn, y, c);
         double cd[16];
+        bool ext_ok = false;
         if (good) {
             for (int k = 0; k < n; k++)
                 cd[k] = (double)c[k];
-            // validate the DOUBLE Horner the kernel runs against the long-double function
-            const int ntest = 4 * n + 1;
-            long double gmax = 0;
-            std::vector<long double> gt(ntest), zt(ntest);
-            for (int q = 0; q < ntest && good; q++) {
-                zt[q] = -0.5L + (q + 0.5L) / ntest;
-                good = G_of_u(st, var_is_w, a + step * (zt[q] + 0.5L), gt[q]);
-                gmax = fmaxl(gmax, fabsl(gt[q]));
-            }
-            for (int q = 0; q < ntest && good; q++) {
-                const double z = (double)zt[q];
-                double g = cd[n - 1];
-                for (int k = n - 2; k >= 0; k--)
-                    g = std::fma(g, z, cd[k]);
-                // the double z differs from zt by <= 1 ulp of 0.5; compare at the long-double z the
-                // function was sampled at (slope * 1e-16 is far below tol)
-                if (!(fabsl((long double)g - gt[q]) <= tol * gmax))
-                    good = false;
+            // The LSB of c7 is a flag: 1 = "this polynomial is also within tolerance on the 3x wider
+            // range z in [-1.5, 1.5]" (kernels_tile.hip then uses one entry for a lane's 4 pixels).
+            // Validate the DOUBLE Horner the kernels run, with the flag bit already in place.
+            auto set_flag = [&](bool on) {
+                uint64_t bits;
+                std::memcpy(&bits, &cd[n - 1], 8);
+                bits = on ? (bits | 1ull) : (bits & ~1ull);
+                std::memcpy(&cd[n - 1], &bits, 8);
+            };
+            auto check = [&](long double zlo, long double zhi, int ntest) {
+                std::vector<long double> gt(ntest), zt(ntest);
+                long double gmax = 0;
+                for (int q = 0; q < ntest; q++) {
+                    zt[q] = zlo + (zhi - zlo) * (q + 0.5L) / ntest;
+                    if (!G_of_u(st, var_is_w, a + step * (zt[q] + 0.5L), gt[q]))
+                        return false;
+                    gmax = fmaxl(gmax, fabsl(gt[q]));
+                }
+                for (int q = 0; q < ntest; q++) {
+                    const double z = (double)zt[q];
+                    double g = cd[n - 1];
+                    for (int k = n - 2; k >= 0; k--)
+                        g = std::fma(g, z, cd[k]);
+                    if (!(fabsl((long double)g - gt[q]) <= tol * gmax))
+                        return false;
+                }
+                return true;
+            };
+            set_flag(true);
+            // (interval 0 has nothing on its left: the table variable is never negative)
+            ext_ok = check(i == 0 ? -0.5L : -1.5L, 1.5L, 12 * n + 1);
+            if (!ext_ok) {
+                set_flag(false);
+                good = check(-0.5L, 0.5L, 4 * n + 1);
             }
         }
         if (good) {
             for (int k = 0; k < n; k++)
                 T.coef[(size_t)i * n + k] = cd[k];
+            T.n_extended += ext_ok;
         } else {
             T.n_invalid++;
             if (T.first_invalid == T.n_int)
@@ -271,7 +291,9 @@ inline RayHostTables build_ray_host_tables(const RayAnalysis& a, int dst_w, int 
 {
     RayHostTables t;
     const double half_pi = 1.5707963267948966;
-    t.col_s.resize(dst_w), t.col_c.resize(dst_w), t.col_h.resize(dst_w);
+    // padded to a multiple of 4 columns (last entry replicated): kernels_fast.hip reads 4 at a time
+    const int wpad = (dst_w + 3) & ~3;
+    t.col_s.resize(wpad), t.col_c.resize(wpad), t.col_h.resize(wpad);
     t.row_s.resize(dst_h), t.row_c.resize(dst_h), t.row_h.resize(dst_h);
     double h_max = 0, h_min = 1e300;
     for (int i = 0; i < dst_w; i++) {
@@ -282,6 +304,8 @@ inline RayHostTables build_ray_host_tables(const RayAnalysis& a, int dst_w, int 
         t.col_s[i] = std::sin(lon), t.col_c[i] = std::cos(lon), t.col_h[i] = 2 * sh * sh;
         h_max = std::max(h_max, t.col_h[i]), h_min = std::min(h_min, t.col_h[i]);
     }
+    for (int i = dst_w; i < wpad; i++)
+        t.col_s[i] = t.col_s[dst_w - 1], t.col_c[i] = t.col_c[dst_w - 1], t.col_h[i] = t.col_h[dst_w - 1];
     for (int j = 0; j < dst_h; j++) {
         const double yn = ((double)j - a.norm_cy) / a.norm_s * 2;  // :163
         const double lat = yn * half_pi;                            // :546

@@ -273,23 +273,17 @@ V1C_HD void eval_chain_literal(const v1c_chain* ch, const double* rot, int i, in
 // ------------------------------------------------------------------------------------------
 V1C_HDF double fast_sqrt_half(double m)
 {
-    // sqrt(m/2) to ~1 ulp: f32 rsq seed + two coupled Newton (Goldschmidt) steps in fp64.
+    // sqrt(m/2) to ~1 ulp: v_rsq_f64 seed, one coupled Newton step, one residual correction
     const double a = 0.5 * m;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (!(a > 1e-30))
-        return 0.0;
-    double y = (double)__builtin_amdgcn_rsqf((float)a);  // ~1e-7 relative
-    double g = a * y;        // ~sqrt(a)
-    double h = 0.5 * y;      // ~1/(2 sqrt(a))
-    double r = fma(-g, h, 0.5);
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y;
+    double h = 0.5 * y;
+    const double r = fma(-g, h, 0.5);
     g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-g, h, 0.5);
-    g = fma(g, r, g);
-    // final correction: g += (a - g*g) * h
     h = fma(h, r, h);
     g = fma(fma(-g, g, a), h, g);
-    return g;
+    return a > 1e-280 ? g : 0.0;
 #else
     return sqrt(a);
 #endif
@@ -298,18 +292,18 @@ V1C_HDF double fast_sqrt_half(double m)
 V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], double sl, double cl, double hl,
                       double slon, double clon, double hlon, double& ox, double& oy)
 {
-    double vx = cl * slon;
-    double vy = sl;
-    double m;
+    // NOTE: kernels_fast.hip evaluates these very expressions (same operations, same order); the
+    // fix-up pass relies on both agreeing bit for bit on which pixels are inside the table.
+    double vx, vy, m;
     if (use_rot) {
-        const double vz = cl * clon;
-        const double rxv = fma(rot[0], vx, fma(rot[1], vy, rot[2] * vz));
-        const double ryv = fma(rot[3], vx, fma(rot[4], vy, rot[5] * vz));
-        const double rzv = fma(rot[6], vx, fma(rot[7], vy, rot[8] * vz));
-        vx = rxv;
-        vy = ryv;
-        m = 1.0 - rzv;
+        // R*v with v = (cl*slon, sl, cl*clon), grouped as (R_k0*cl)*slon + (R_k2*cl)*clon + R_k1*sl so
+        // that the row-constant factors can be hoisted out of the pixel loop
+        vx = fma(rot[0] * cl, slon, fma(rot[2] * cl, clon, rot[1] * sl));
+        vy = fma(rot[3] * cl, slon, fma(rot[5] * cl, clon, rot[4] * sl));
+        m = 1.0 - fma(rot[6] * cl, slon, fma(rot[8] * cl, clon, rot[7] * sl));
     } else {
+        vx = cl * slon;
+        vy = sl;
         m = fma(cl, hlon, hl);  // 1 - cl*clon without cancellation
     }
     const double u = P.var_is_w ? fast_sqrt_half(m) : m;
@@ -323,10 +317,14 @@ V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], 
 #pragma unroll
     for (int k = kRadialDegree - 1; k >= 0; k--)
         g = fma(g, z, c[k]);
-    if (!(fabs(g) < 1.0e300))  // interval flagged invalid at plan time (coefficients are NaN)
+    // computed scaled by 32 (exact): float32(32*x) == 32*float32(x) is cv2's fixed-point input
+    const double x32 = fma(g * (32.0 * P.rx), vx, 32.0 * P.cx);
+    const double y32 = fma(g * (32.0 * P.ry), vy, 32.0 * P.cy);
+    // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
+    if (!(fabs(x32) < 1073741824.0 && fabs(y32) < 1073741824.0))
         return false;
-    ox = fma(g * P.rx, vx, P.cx);
-    oy = fma(g * P.ry, vy, P.cy);
+    ox = x32 * 0.03125;
+    oy = y32 * 0.03125;
     return true;
 }
 
