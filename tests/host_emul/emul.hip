@@ -75,6 +75,8 @@ int emul_get_map(const v1c_chain* ch, const double* rot_or_null, int w, int h, i
     for (int q = 0; q < 9; q++)
         P.rot[q] = a.rot[q];
     P.rx = a.rx, P.ry = a.ry, P.cx = a.cx, P.cy = a.cy;
+    P.rx32 = 32.0 * a.rx, P.ry32 = 32.0 * a.ry, P.cx32 = 32.0 * a.cx, P.cy32 = 32.0 * a.cy;
+    P.n_int_f = (double)P.n_int;
     double R[9];
     const bool use_rot = rot_or_null || a.has_rot;
     for (int q = 0; q < 9; q++)

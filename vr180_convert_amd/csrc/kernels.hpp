@@ -21,7 +21,6 @@ struct KernelCtx {
     const float* xmap;        // MODE_LUT
     const float* ymap;
     int64_t map_pitch;        // bytes
-    int abl;                  // experiment switches (V1C_ABL env var; 0 in production)
 };
 
 int tiles_per_unit(const Geom& g);
@@ -29,11 +28,10 @@ hipError_t launch_remap(int mode, const KernelCtx& c, const UnitArgs& ua, int n_
 hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float* xmap, float* ymap, int64_t pitch,
                           hipStream_t stream);
 
-// hot configuration (CN = 3, INTER_LINEAR, BORDER_CONSTANT, ray mode): kernels_fast.hip
-// LDS-tiled version of the same (kernels_tile.hip)
-hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, hipStream_t stream);
-hipError_t launch_ray_lin3_persist(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, int tab_entries,
-                                   int num_cus, hipStream_t stream);
-hipError_t launch_ray_lin3(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, hipStream_t stream);
+// hot configuration (CN = 3, INTER_LINEAR, BORDER_CONSTANT, ray mode): kernels_tile.hip
+size_t tile_box_bytes(const Geom& g);
+hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream);
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes,
+                                hipStream_t stream);
 
 }  // namespace v1c

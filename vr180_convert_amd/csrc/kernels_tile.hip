@@ -1,40 +1,50 @@
 // kernels_tile.hip -- LDS-tiled kernel for the hot configuration (BGR, INTER_LINEAR,
-// BORDER_CONSTANT, fused ray path).  Same arithmetic as kernels.hip / kernels_fast.hip.
+// BORDER_CONSTANT, fused ray path).  Same arithmetic as kernels.hip: the tests compare both with
+// the oracle bit for bit.
 //
-// Why: rocprof counters on the gather-from-global version show the vector L1 (TCP) as the limit:
-// it retires about one 64-byte access per clock, and a wave's 64 unaligned 8-byte gathers cost
-// ~100 accesses per load instruction (no coalescing), a dwordx4 table read 16.  Here
+// Why tiles: rocprof counters on a gather-from-global version show the vector L1 (TCP) as the
+// limit -- it retires about one 64-byte access per clock, a wave's 64 unaligned 8-byte gathers
+// cost ~100 accesses per load instruction (no coalescing) and a dwordx4 table read 16.  Here
 //   * a workgroup owns a 64 x 16 output tile (lane = 4 px of one row, wave = 64 px x 4 rows);
-//   * the bounding box of the tile's source taps is reduced across the workgroup (packed int16
-//     min/max), then copied from HBM to LDS with 16-byte, row-contiguous, dword-aligned loads
-//     (a 1 KiB wave load = 16 L1 accesses for ~340 source pixels);
-//   * the 2x2 cells are read back from LDS with unaligned ds_read_b64 (12-byte lane stride is
-//     coprime with the 64 banks);
+//   * the bounding box of the tile's source taps is copied from HBM to LDS with 12-byte,
+//     row-contiguous, dword-aligned loads (one wave load = 768 contiguous bytes = 256 pixels for
+//     ~13 L1 accesses) and kept 4 bytes per pixel in LDS (BGRx: three v_perm_b32 expand 4 pixels
+//     into one ds_write_b128), so a 2x2 cell is two ALIGNED ds_read2_b32 (unaligned 8-byte LDS
+//     reads of packed BGR measured ~60 stall cycles each);
+//   * the box of every tile is computed ONCE per plan by k_tile_boxes (the map does not depend on
+//     the pixels), so the hot kernel starts its staging loads before any coordinate math and has
+//     no reduction; units that override the rotation (per-frame calibration) use the BOXES = 0
+//     variant, which reduces the box in-kernel with DPP mins;
 //   * each lane reads ONE 64-byte radial-table entry for its 4 pixels: intervals whose polynomial
 //     was validated at plan time on the 3x wider range carry a flag in the LSB of c7.
 // Tiles whose box does not fit the LDS budget (strong rotation / minification) gather from global
-// memory like kernels_fast.hip; pixels with taps outside the source go through the generic
-// border-aware sampler; pixels outside the radial table's domain are left to the fix-up launch.
+// memory; pixels with taps outside the source go through the generic border-aware sampler;
+// pixels outside the radial table's domain are left to the fix-up launch (kernels.hip MODE_FIXUP).
 #include "kernels.hpp"
 
 namespace v1c {
 
 constexpr int kTW = 64, kTH = 16;          // output tile (px)
-constexpr int kBoxBytes = 16 * 1024;       // LDS budget for the source box
-constexpr int kMaxCpr = 64;                // 16-byte chunks per box row (magic division bound)
+constexpr int kBoxBytes = 24 * 1024;       // LDS budget for the source box (4 B per source pixel)
+constexpr int kMaxCpr = 64;                // 4-pixel chunks per box row (magic division bound)
+constexpr int kMaxChunks = 1024;           // staged by 256 threads x 4
 
-typedef short __attribute__((ext_vector_type(2))) s16x2;
-
-__device__ __forceinline__ int pk_min(int a, int b)
+// wave-wide signed min via DPP (no LDS traffic): after the six steps lane 63 holds the result
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_step(int v)
 {
-    return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+    // lanes / rows without a source get the identity of min
+    return min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROW_MASK, 0xf, false));
 }
 
-__device__ __forceinline__ int wave_pk_min(int v)
+__device__ __forceinline__ int wave_min_to_lane63(int v)
 {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1)
-        v = pk_min(v, __shfl_xor(v, m));
+    v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row = row minimum
+    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -50,28 +60,27 @@ struct u128 {
     uint32_t x, y, z, w;
 };
 
-template <int VAR_W, int ROT>
-__global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua)
-{
-    __shared__ int red[8];
-    __shared__ __attribute__((aligned(16))) uint8_t box[kBoxBytes + 16];
+// source box of one output tile: pixels [x0, x0 + 4*cpr) x rows [y0, y0 + nrows); cpr == 0: no
+// pixel of the tile has its 2x2 cell inside the source
+struct TileBox {
+    int x0, y0, cpr, nrows;
+};
 
+struct LaneCoords {
+    int sx[kPX], sy[kPX];      // cv2's fixed point: cvRound(32 x)
+    float fx[kPX], fy[kPX];    // 32 * float32(x)
+    unsigned ok;               // coordinate valid (inside the radial table's domain), bit per pixel
+    unsigned inside;           // ... and the whole 2x2 cell (plus 8 readable bytes) inside the source
+};
+
+// ---- coordinates of a lane's 4 pixels: identical operations to ray_eval() (v1c_core.hpp) ----
+template <int VAR_W, int ROT>
+__device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, int xc, int jc, int npx, LaneCoords& L)
+{
     const RayParams& P = c.ray;
     const Geom& g = c.g;
-    const int z = blockIdx.z;
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-    const int x0 = (blockIdx.x * 16 + lx) * kPX;
-    const int j = blockIdx.y * kTH + ly;
-    const bool active = x0 < g.dst_w && j < g.dst_h;
-    const int xc = min(x0, ((g.dst_w + 3) & ~3) - 4), jc = min(j, g.dst_h - 1);  // clamped for table reads
-    // flag words are indexed like kernels.hip's 256x4 tiles so that MODE_FIXUP finds them
-    const int tiles_x = (g.dst_w + kBlockX * kPX - 1) / (kBlockX * kPX), tiles_y = (g.dst_h + kBlockY - 1) / kBlockY;
-    const int tile = (z * tiles_y + jc / kBlockY) * tiles_x + xc / (kBlockX * kPX);
-
-    const uint8_t* __restrict__ src = ua.u[z].src;
-    const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
     const double sl = P.row_s[jc], cl = P.row_c[jc], hl = P.row_h[jc];
-    const double rx32 = 32.0 * P.rx, ry32 = 32.0 * P.ry, cx32 = 32.0 * P.cx, cy32 = 32.0 * P.cy;
+    const double rx32 = P.rx32, ry32 = P.ry32, cx32 = P.cx32, cy32 = P.cy32;
 
     double A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, C0 = 0, C1 = 0, C2 = 0;
     if (ROT) {
@@ -84,7 +93,6 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua)
         A2 = R[6] * cl, B2 = R[8] * cl, C2 = R[7] * sl;
     }
 
-    // ---- column tables -> table variable of the 4 pixels ----
     double slon[kPX], qlon[kPX];
     {
         const double* __restrict__ ps = P.col_s + xc;
@@ -109,20 +117,20 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua)
             m = fma(cl, qlon[k], hl);
         }
         const double u = VAR_W ? fast_sqrt_half(m) : m;
-        tt[k] = u * P.inv_step;
-        const bool in = tt[k] >= 0.0 && tt[k] < (double)P.n_int;
+        tt[k] = fmax(u * P.inv_step, 0.0);
+        const bool in = tt[k] < P.n_int_f;  // false for NaN
         in_table |= in ? 1u << k : 0u;
-        idx[k] = in ? (int)tt[k] : 0;
+        idx[k] = (int)fmin(tt[k], P.n_int_f - 1.0);  // clamped: always a readable entry
     }
 
-    // ---- radial table: one entry (that of pixel 1) serves all 4 pixels where it may ----
+    // radial table: one entry (that of pixel 1) serves all 4 pixels where it may
     double G[kPX];
     {
         const int ic = idx[1];
         double e[kRadialCoefs];
         {
             typedef double __attribute__((ext_vector_type(2))) d2;
-            const d2* p2 = (const d2*)(P.radial + (size_t)ic * kRadialCoefs);
+            const d2* p2 = (const d2*)((const char*)P.radial + (uint32_t)ic * (uint32_t)(kRadialCoefs * 8));
 #pragma unroll
             for (int q = 0; q < kRadialCoefs / 2; q++) {
                 const d2 v = p2[q];
@@ -130,12 +138,13 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua)
             }
         }
         const bool ext = (__double2loint(e[kRadialDegree]) & 1) != 0;  // validated on |z| <= 1.5
+        const double zc = (double)ic + 0.5;
         unsigned own = 0;  // pixels that must use their own entry
 #pragma unroll
         for (int k = 0; k < kPX; k++) {
-            const double zk = tt[k] - ((double)ic + 0.5);
-            const bool usec = idx[k] == ic || (ext && fabs(zk) <= 1.5);
-            own |= (!usec && ((in_table >> k) & 1)) ? 1u << k : 0u;
+            const double zk = tt[k] - zc;
+            const bool usec = (idx[k] == ic) | (ext & (fabs(zk) <= 1.5));
+            own |= (!usec & (bool)((in_table >> k) & 1)) ? 1u << k : 0u;
             double gk = e[kRadialDegree];
 #pragma unroll
             for (int q = kRadialDegree - 1; q >= 0; q--)
@@ -158,133 +167,142 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua)
         }
     }
 
-    const int npx = active ? min(kPX, g.dst_w - x0) : 0;
-    int sx[kPX], sy[kPX];
-    float fxs[kPX], fys[kPX];
-    unsigned ok = 0;
+    L.ok = 0, L.inside = 0;
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
         const double x32 = fma(G[k] * rx32, vx[k], cx32), y32 = fma(G[k] * ry32, vy[k], cy32);
-        fxs[k] = (float)x32, fys[k] = (float)y32;  // = 32 * float32(x)
-        const bool good = ((in_table >> k) & 1) && fabs(x32) < 1073741824.0 && fabs(y32) < 1073741824.0;
-        ok |= (good && k < npx) ? 1u << k : 0u;
-        sx[k] = good ? __float2int_rn(fxs[k]) : 0;
-        sy[k] = good ? __float2int_rn(fys[k]) : 0;
+        L.fx[k] = (float)x32, L.fy[k] = (float)y32;  // = 32 * float32(x)
+        // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
+        const bool good = (bool)((in_table >> k) & 1) & (fabsf(L.fx[k]) < 1073741824.0f) & (fabsf(L.fy[k]) < 1073741824.0f);
+        const bool okk = good & (k < npx);
+        L.ok |= okk ? 1u << k : 0u;
+        // branch-free: the conversion always sees a finite, in-range float
+        L.sx[k] = __float2int_rn(good ? L.fx[k] : 0.0f);
+        L.sy[k] = __float2int_rn(good ? L.fy[k] : 0.0f);
+        const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+        const bool in = okk & ((unsigned)ix < (unsigned)(g.src_w - 2)) & ((unsigned)iy < (unsigned)(g.src_h - 1));
+        L.inside |= in ? 1u << k : 0u;
     }
-    if (ok != (1u << npx) - 1)
-        c.tile_flags[tile] = 1;
+}
 
-    // ---- bounding box of the fully-inside 2x2 cells ----
-    unsigned inside = 0;
+// ---- workgroup-wide bounding box of the inside pixels (DPP mins + one LDS exchange) ----
+__device__ __forceinline__ TileBox reduce_box(const LaneCoords& L, int* red, int tid)
+{
     int xmn = 32767, ymn = 32767, nxmx = 32767, nymx = 32767;  // running mins of x, y, -x, -y
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
-        const int ix = sx[k] >> 5, iy = sy[k] >> 5;
-        const bool in = ((ok >> k) & 1) && (unsigned)ix < (unsigned)(g.src_w - 2) && (unsigned)iy < (unsigned)(g.src_h - 1);
-        inside |= in ? 1u << k : 0u;
-        xmn = in ? min(xmn, ix) : xmn, ymn = in ? min(ymn, iy) : ymn;
-        nxmx = in ? min(nxmx, -ix) : nxmx, nymx = in ? min(nymx, -iy) : nymx;
+        const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+        const bool in = (L.inside >> k) & 1;
+        xmn = min(xmn, in ? ix : 32767), ymn = min(ymn, in ? iy : 32767);
+        nxmx = min(nxmx, in ? -ix : 32767), nymx = min(nymx, in ? -iy : 32767);
     }
-    int pa = (xmn & 0xffff) | (ymn << 16), pb = (nxmx & 0xffff) | (nymx << 16);
-    pa = wave_pk_min(pa), pb = wave_pk_min(pb);
-    if ((tid & 63) == 0)
-        red[(tid >> 6) * 2] = pa, red[(tid >> 6) * 2 + 1] = pb;
+    xmn = wave_min_to_lane63(xmn), ymn = wave_min_to_lane63(ymn);
+    nxmx = wave_min_to_lane63(nxmx), nymx = wave_min_to_lane63(nymx);
+    if ((tid & 63) == 63) {
+        int* r = red + (tid >> 6) * 4;
+        r[0] = xmn, r[1] = ymn, r[2] = nxmx, r[3] = nymx;
+    }
     __syncthreads();
-    pa = pk_min(pk_min(red[0], red[2]), pk_min(red[4], red[6]));
-    pb = pk_min(pk_min(red[1], red[3]), pk_min(red[5], red[7]));
-    pa = __builtin_amdgcn_readfirstlane(pa), pb = __builtin_amdgcn_readfirstlane(pb);
-    const int bx0 = (short)(pa & 0xffff), by0 = pa >> 16;
-    const int bx1 = -(int)(short)(pb & 0xffff), by1 = -(pb >> 16);
+    const int bx0r = __builtin_amdgcn_readfirstlane(min(min(red[0], red[4]), min(red[8], red[12])));
+    const int by0 = __builtin_amdgcn_readfirstlane(min(min(red[1], red[5]), min(red[9], red[13])));
+    const int bx1 = -__builtin_amdgcn_readfirstlane(min(min(red[2], red[6]), min(red[10], red[14])));
+    const int by1 = -__builtin_amdgcn_readfirstlane(min(min(red[3], red[7]), min(red[11], red[15])));
+    TileBox b;
+    b.x0 = bx0r & ~3;  // the box starts on a 4-pixel (12-byte) boundary
+    b.y0 = by0;
+    b.cpr = bx0r <= bx1 ? (bx1 + 2 - b.x0 + 3) >> 2 : 0;
+    b.nrows = by1 - by0 + 2;
+    return b;
+}
 
-    // box rows hold source bytes [a0, a0 + cpr*16) of rows by0 .. by1+1
-    const int a0 = (bx0 * 3) & ~3;
-    const int cpr = (bx1 * 3 + 8 - a0 + 15) >> 4;
-    const int nrows = by1 - by0 + 2;
-    const int lp = cpr * 16;
-    const bool any_inside = bx0 <= bx1;
-    const bool use_lds = any_inside && cpr <= kMaxCpr && nrows * lp <= kBoxBytes && ((((uintptr_t)src) | spitch) & 3) == 0;
+__device__ __forceinline__ bool box_fits(const TileBox& b, const uint8_t* src, uint32_t spitch)
+{
+    const int lpw = b.cpr * 4 + 4;
+    return (b.cpr > 0) & (b.cpr <= kMaxCpr) & (b.nrows * b.cpr <= kMaxChunks) & (b.nrows * lpw * 4 <= kBoxBytes) &
+           (((((uintptr_t)src) | spitch) & 3) == 0);
+}
 
-    uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
-    if (use_lds) {
-        const int nchunks = nrows * cpr;  // <= 1024
-        const uint32_t magic = (65536u + cpr - 1) / cpr;
-        const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
-        u128 v[4];
-        uint32_t lds_off[4];
+struct Staged {
+    uint32_t w0[4], w1[4], w2[4];
+};
+
+// ---- issue the box loads: thread t owns chunks t, t+256, t+512, t+768 (4 source pixels each) ----
+__device__ __forceinline__ void stage_load(const TileBox& b, const uint8_t* __restrict__ src, uint32_t spitch, uint32_t src_bytes,
+                                           int tid, Staged& S)
+{
+    const int nchunks = b.nrows * b.cpr;
+    const uint32_t magic = (65536u + b.cpr - 1) / b.cpr;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int ch = tid + q * 256;
-            const uint32_t r = ((uint32_t)ch * magic) >> 16, col = ch - r * cpr;
-            const uint32_t goff = (uint32_t)(by0 + r) * spitch + (uint32_t)a0 + col * 16u;
-            lds_off[q] = r * lp + col * 16;
-            if (ch < nchunks) {
-                if (goff + 16u <= src_bytes) {
-                    typedef u128 __attribute__((aligned(4), may_alias)) u128a4;
-                    v[q] = *(const u128a4*)(src + goff);
-                } else {  // last bytes of the image: never read past the allocation
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    for (int b = 0; b < 16; b++)
-                        if (goff + b < src_bytes)
-                            w[b >> 2] |= (uint32_t)src[goff + b] << (8 * (b & 3));
-                    v[q] = u128{w[0], w[1], w[2], w[3]};
-                }
+    for (int q = 0; q < 4; q++) {
+        const uint32_t ch = tid + q * 256;
+        const uint32_t r = (ch * magic) >> 16, col = ch - r * b.cpr;
+        const uint32_t goff = __umul24(b.y0 + r, spitch) + (uint32_t)(b.x0 + 4 * col) * 3u;
+        S.w0[q] = S.w1[q] = S.w2[q] = 0;
+        if (ch < (uint32_t)nchunks) {
+            if (goff + 12u <= src_bytes) {
+                struct u96 {
+                    uint32_t a, b, c;
+                };
+                typedef u96 __attribute__((aligned(4), may_alias)) u96a4;
+                const u96 v = *(const u96a4*)(src + goff);
+                S.w0[q] = v.a, S.w1[q] = v.b, S.w2[q] = v.c;
+            } else {  // last bytes of the image: never read past the allocation
+                uint32_t w[3] = {0, 0, 0};
+#pragma unroll 1
+                for (int bb = 0; bb < 12; bb++)
+                    if (goff + bb < src_bytes)
+                        w[bb >> 2] |= (uint32_t)src[goff + bb] << (8 * (bb & 3));
+                S.w0[q] = w[0], S.w1[q] = w[1], S.w2[q] = w[2];
             }
         }
+    }
+}
+
+// ---- expand to BGRx and write the box into LDS ----
+__device__ __forceinline__ void stage_store(const TileBox& b, int tid, const Staged& S, uint32_t* boxw)
+{
+    const int nchunks = b.nrows * b.cpr;
+    const int lpw = b.cpr * 4 + 4;  // LDS row pitch in dwords (+4: rotate the banks from row to row)
+    const uint32_t magic = (65536u + b.cpr - 1) / b.cpr;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (tid + q * 256 < nchunks)
-                *(u128*)(box + lds_off[q]) = v[q];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kPX; k++) {
-            const int ix = sx[k] >> 5, iy = sy[k] >> 5;
-            const bool in = (inside >> k) & 1;
-            const uint32_t lo = in ? (uint32_t)((iy - by0) * lp + ix * 3 - a0) : 0u;
-            const u64pair a = load_u64_unaligned(box + lo);
-            const u64pair b = load_u64_unaligned(box + lo + lp);
-            alo[k] = a.lo, ahi[k] = a.hi, blo[k] = b.lo, bhi[k] = b.hi;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kPX; k++) {
-            const int ix = sx[k] >> 5, iy = sy[k] >> 5;
-            const bool in = (inside >> k) & 1;
-            const uint32_t off = in ? __umul24(iy, spitch) + (uint32_t)(ix * 3) : 0u;
-            const u64pair a = load_u64_unaligned(src + off);
-            const u64pair b = load_u64_unaligned(src + off + spitch);
-            alo[k] = a.lo, ahi[k] = a.hi, blo[k] = b.lo, bhi[k] = b.hi;
+    for (int q = 0; q < 4; q++) {
+        const uint32_t ch = tid + q * 256;
+        if (ch < (uint32_t)nchunks) {
+            const uint32_t r = (ch * magic) >> 16, col = ch - r * b.cpr;
+            // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  BGRx x 4
+            u128 o;
+            o.x = S.w0[q] & 0x00ffffffu;
+            o.y = __builtin_amdgcn_perm(S.w1[q], S.w0[q], 0x0c050403u);
+            o.z = __builtin_amdgcn_perm(S.w2[q], S.w1[q], 0x0c040302u);
+            o.w = S.w2[q] >> 8;
+            *(u128*)(boxw + r * lpw + col * 4) = o;
         }
     }
+}
 
-    uint32_t pix[kPX];
+// ---- bilinear blend of one pixel from its two tap pairs; SEL_HI = byte index of px1 ----
+template <int SEL_HI>
+__device__ __forceinline__ uint32_t blend3(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, int sx, int sy)
+{
+    const uint32_t fq = sx & 31, fr = sy & 31;
+    const uint32_t wxp = (32u - fq) | (fq << 8);  // bytes (wx0, wx1, 0, 0)
+    const uint32_t wy0 = 32u - fr, wy1 = fr;
+    uint32_t o = 0;
 #pragma unroll
-    for (int k = 0; k < kPX; k++) {
-        const uint32_t fq = sx[k] & 31, fr = sy[k] & 31;
-        const uint32_t wxp = (32u - fq) | (fq << 8);
-        const uint32_t wy0 = 32u - fr, wy1 = fr;
-        uint32_t o = 0;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const uint32_t sel = 0x0c0c0000u | ((uint32_t)(ch + 3) << 8) | (uint32_t)ch;
-            const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(ahi[k], alo[k], sel), wxp, 0u, false);
-            const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(bhi[k], blo[k], sel), wxp, 0u, false);
-            const uint32_t v = __umul24(h0, wy0) + __umul24(h1, wy1) + 512u;
-            o |= (v >> 10) << (8 * ch);
-        }
-        pix[k] = o;
+    for (int ch = 0; ch < 3; ch++) {
+        // bytes (p0c, p1c, 0, 0) of the pixel pair
+        constexpr uint32_t base = 0x0c0c0000u | ((uint32_t)SEL_HI << 8);
+        const uint32_t sel = base + (uint32_t)ch * 0x0101u;
+        const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(ahi, alo, sel), wxp, 0u, false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(bhi, blo, sel), wxp, 0u, false);
+        const uint32_t v = __umul24(h1, wy1) + (__umul24(h0, wy0) + 512u);
+        o |= (v >> 10) << (8 * ch);
     }
+    return o;
+}
 
-    const unsigned slow = ok & ~inside;
-    if (slow) {
-#pragma unroll
-        for (int k = 0; k < kPX; k++)
-            if (slow & (1u << k))
-                pix[k] = slow_pixel_linear3_t(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, fxs[k] * 0.03125f, fys[k] * 0.03125f);
-    }
-
-    if (!active)
-        return;
-    uint8_t* drow = ua.u[z].dst + (int64_t)j * ua.u[z].dst_pitch + (int64_t)x0 * 3;
+__device__ __forceinline__ void store4(uint8_t* drow, const uint32_t (&pix)[kPX], unsigned ok)
+{
     if (ok == 0xFu && (((uintptr_t)drow) & 3) == 0) {
         uint32_t* d32 = (uint32_t*)drow;
         d32[0] = pix[0] | (pix[1] << 24);
@@ -301,21 +319,182 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua)
     }
 }
 
-hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, hipStream_t stream)
+struct TileIds {
+    int x0, j, xc, jc, npx, flag_tile, box_tile;
+    bool active;
+};
+
+__device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid)
 {
-    const dim3 block(256, 1, 1);
-    const dim3 grid((c.g.dst_w + kTW - 1) / kTW, (c.g.dst_h + kTH - 1) / kTH, n_units);
+    TileIds t;
+    const int lx = tid & 15, ly = tid >> 4;
+    t.x0 = (blockIdx.x * 16 + lx) * kPX;
+    t.j = blockIdx.y * kTH + ly;
+    t.active = (t.x0 < g.dst_w) & (t.j < g.dst_h);
+    t.xc = min(t.x0, ((g.dst_w + 3) & ~3) - 4), t.jc = min(t.j, g.dst_h - 1);  // clamped for table reads
+    t.npx = t.active ? min(kPX, g.dst_w - t.x0) : 0;
+    // flag words are indexed like kernels.hip's 256x4 tiles so that MODE_FIXUP finds them
+    const int ftx = (g.dst_w + kBlockX * kPX - 1) / (kBlockX * kPX), fty = (g.dst_h + kBlockY - 1) / kBlockY;
+    t.flag_tile = (z * fty + t.jc / kBlockY) * ftx + t.xc / (kBlockX * kPX);
+    t.box_tile = blockIdx.y * gridDim.x + blockIdx.x;
+    return t;
+}
+
+// Plan-time pass: the source box of every 64x16 tile (chain rotation as stored in the plan).
+template <int VAR_W, int ROT>
+__global__ __launch_bounds__(256) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes)
+{
+    __shared__ __attribute__((aligned(16))) int red[16];
+    const int tid = threadIdx.x;
+    const TileIds t = tile_ids(c.g, 0, tid);
+    LaneCoords L;
+    lane_coords<VAR_W, ROT>(c, ua, 0, t.xc, t.jc, t.npx, L);
+    const TileBox b = reduce_box(L, red, tid);
+    if (tid == 0)
+        boxes[t.box_tile] = b;
+}
+
+// BOXES = 1: boxes precomputed by k_tile_boxes; 0: reduced in-kernel (per-unit rotations)
+template <int VAR_W, int ROT, int BOXES>
+__global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes)
+{
+    __shared__ __attribute__((aligned(16))) int red[16];
+    __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
+
+    const Geom& g = c.g;
+    const int z = blockIdx.z;
+    const int tid = threadIdx.x;
+    const TileIds t = tile_ids(g, z, tid);
+    const uint8_t* __restrict__ src = ua.u[z].src;
+    const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+    const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
+
+    TileBox b;
+    bool use_lds = false;
+    Staged S;
+    if (BOXES) {
+        // scalar load of the precomputed box, then the staging loads go out before any math
+        const int4 bb = *(const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
+        b.x0 = bb.x, b.y0 = bb.y, b.cpr = bb.z, b.nrows = bb.w;
+        use_lds = box_fits(b, src, spitch);
+        if (use_lds)
+            stage_load(b, src, spitch, src_bytes, tid, S);
+    }
+
+    LaneCoords L;
+    lane_coords<VAR_W, ROT>(c, ua, z, t.xc, t.jc, t.npx, L);
+    if (L.ok != (1u << t.npx) - 1)
+        c.tile_flags[t.flag_tile] = 1;
+
+    if (!BOXES) {
+        b = reduce_box(L, red, tid);
+        use_lds = box_fits(b, src, spitch);
+        if (use_lds)
+            stage_load(b, src, spitch, src_bytes, tid, S);
+    }
+
+    uint32_t pix[kPX];
+    if (use_lds) {
+        stage_store(b, tid, S, boxw);
+        __syncthreads();
+        const int lpw = b.cpr * 4 + 4;
+        uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+            const bool in = (L.inside >> k) & 1;
+            const uint32_t lo = in ? __umul24(iy - b.y0, lpw) + (uint32_t)(ix - b.x0) : 0u;
+            alo[k] = boxw[lo], ahi[k] = boxw[lo + 1];
+            blo[k] = boxw[lo + lpw], bhi[k] = boxw[lo + lpw + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            pix[k] = blend3<4>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
+    } else {
+        uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+            const bool in = (L.inside >> k) & 1;
+            const uint32_t off = in ? __umul24(iy, spitch) + (uint32_t)(ix * 3) : 0u;
+            const u64pair a = load_u64_unaligned(src + off);
+            const u64pair bq = load_u64_unaligned(src + off + spitch);
+            alo[k] = a.lo, ahi[k] = a.hi, blo[k] = bq.lo, bhi[k] = bq.hi;
+        }
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            pix[k] = blend3<3>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
+    }
+
+    // pixels that are valid but whose 2x2 cell is not fully inside: border-aware generic sampler
+    const unsigned slow = L.ok & ~L.inside;
+    if (slow) {
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            if (slow & (1u << k))
+                pix[k] = slow_pixel_linear3_t(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, L.fx[k] * 0.03125f, L.fy[k] * 0.03125f);
+    }
+    if (!t.active)
+        return;
+    store4(ua.u[z].dst + (int64_t)t.j * ua.u[z].dst_pitch + (int64_t)t.x0 * 3, pix, L.ok);
+}
+
+static dim3 tile_grid(const Geom& g, int n_units)
+{
+    return dim3((g.dst_w + kTW - 1) / kTW, (g.dst_h + kTH - 1) / kTH, n_units);
+}
+
+size_t tile_box_bytes(const Geom& g)
+{
+    const dim3 d = tile_grid(g, 1);
+    return (size_t)d.x * d.y * sizeof(TileBox);
+}
+
+// plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
+hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream)
+{
+    UnitArgs ua{};
+    const dim3 block(256, 1, 1), grid = tile_grid(c.g, 1);
+    const bool rot = c.ray.has_rot != 0;
+    if (c.ray.var_is_w) {
+        if (rot)
+            hipLaunchKernelGGL((k_tile_boxes<1, 1>), grid, block, 0, stream, c, ua, (TileBox*)boxes);
+        else
+            hipLaunchKernelGGL((k_tile_boxes<1, 0>), grid, block, 0, stream, c, ua, (TileBox*)boxes);
+    } else {
+        if (rot)
+            hipLaunchKernelGGL((k_tile_boxes<0, 1>), grid, block, 0, stream, c, ua, (TileBox*)boxes);
+        else
+            hipLaunchKernelGGL((k_tile_boxes<0, 0>), grid, block, 0, stream, c, ua, (TileBox*)boxes);
+    }
+    return hipGetLastError();
+}
+
+// `boxes` may be null (or the units may override the rotation): then boxes are reduced in-kernel
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes,
+                                hipStream_t stream)
+{
+    const dim3 block(256, 1, 1), grid = tile_grid(c.g, n_units);
+    const TileBox* bx = (const TileBox*)boxes;
+#define V1C_TILE(VW, RT)                                                                           \
+    do {                                                                                           \
+        if (bx)                                                                                    \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1>), grid, block, 0, stream, c, ua, bx);   \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 0>), grid, block, 0, stream, c, ua, bx);   \
+    } while (0)
     if (c.ray.var_is_w) {
         if (use_rot)
-            hipLaunchKernelGGL((k_ray_lin3_tile<1, 1>), grid, block, 0, stream, c, ua);
+            V1C_TILE(1, 1);
         else
-            hipLaunchKernelGGL((k_ray_lin3_tile<1, 0>), grid, block, 0, stream, c, ua);
+            V1C_TILE(1, 0);
     } else {
         if (use_rot)
-            hipLaunchKernelGGL((k_ray_lin3_tile<0, 1>), grid, block, 0, stream, c, ua);
+            V1C_TILE(0, 1);
         else
-            hipLaunchKernelGGL((k_ray_lin3_tile<0, 0>), grid, block, 0, stream, c, ua);
+            V1C_TILE(0, 0);
     }
+#undef V1C_TILE
     return hipGetLastError();
 }
 

@@ -165,8 +165,7 @@ struct v1c_plan {
     bool ray_no_rot_safe = false; // no rotation: reachable m stays below the first flagged interval
     KernelCtx ctx{};
     int tiles = 0;
-    int num_cus = 256;
-    int tab_reach_entries = 0;    // radial-table entries an unrotated chain can touch (+ margin)
+    void* tile_boxes = nullptr;   // per-tile source boxes of the tiled kernel (plan rotation)
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     std::vector<void*> allocs;
 };
@@ -288,8 +287,6 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
     {
         const char* e = std::getenv("V1C_DISABLE_FAST");
         p->disable_fast = e && e[0] == '1';
-        const char* a = std::getenv("V1C_ABL");
-        p->ctx.abl = a ? std::atoi(a) : 0;
     }
     rc = plan_common(p, device, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, border_val);
     if (rc) {
@@ -337,14 +334,9 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             for (int q = 0; q < 9; q++)
                 r.rot[q] = a.rot[q];
             r.rx = a.rx, r.ry = a.ry, r.cx = a.cx, r.cy = a.cy;
+            r.rx32 = 32.0 * a.rx, r.ry32 = 32.0 * a.ry, r.cx32 = 32.0 * a.cx, r.cy32 = 32.0 * a.cy;
+            r.n_int_f = (double)r.n_int;
             p->ray_no_rot_safe = !a.has_rot && ray_reach_is_safe(p->table, ht.m_reach);
-            {
-                const double u = (p->table.var_is_w ? std::sqrt(ht.m_reach / 2) : ht.m_reach) * (1 + 1e-9);
-                p->tab_reach_entries = std::min(p->table.n_int, (int)(u * p->table.inv_step) + 2);
-                hipDeviceProp_t prop;
-                if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-                    p->num_cus = prop.multiProcessorCount;
-            }
             // tile flags for kMaxUnitsPerLaunch units
             void* d = nullptr;
             const size_t nflag = (size_t)p->tiles * kMaxUnitsPerLaunch * sizeof(uint32_t);
@@ -358,6 +350,21 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 return fail(V1C_E_HIP, std::string("tile flags: ") + hipGetErrorString(e));
             }
             p->ctx.tile_flags = (uint32_t*)d;
+            // source boxes of the tiled kernel, computed once (BGR + bilinear + constant border)
+            const Geom& g = p->ctx.g;
+            if (g.cn == 3 && g.interp == V1C_INTER_LINEAR && g.border == V1C_BORDER_CONSTANT && g.src_w >= 3 && g.src_h >= 2) {
+                void* bx = nullptr;
+                e = hipMalloc(&bx, tile_box_bytes(g));
+                if (e == hipSuccess) {
+                    p->allocs.push_back(bx);
+                    e = launch_tile_boxes(p->ctx, bx, nullptr);
+                }
+                if (e != hipSuccess) {
+                    v1c_plan_destroy(p);
+                    return fail(V1C_E_HIP, std::string("tile boxes: ") + hipGetErrorString(e));
+                }
+                p->tile_boxes = bx;
+            }
         }
     }
     hipError_t e = hipDeviceSynchronize();
@@ -422,21 +429,15 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             }
             // hand-tuned kernel for BGR + bilinear + constant border; 32-bit source offsets
             const Geom& g = p->ctx.g;
-            bool fast = g.cn == 3 && g.interp == V1C_INTER_LINEAR && g.border == V1C_BORDER_CONSTANT && g.src_w >= 3 &&
-                        g.src_h >= 2 && !p->disable_fast;
+            bool fast = p->tile_boxes != nullptr && !p->disable_fast;
             for (int k = 0; k < n && fast; k++)
                 fast = (uint64_t)g.src_h * (uint64_t)ua.u[k].src_pitch < 0xFFFFFF00ull && ua.u[k].src_pitch < (1 << 24);
-            if (fast && !(p->ctx.abl & 128)) {
-                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, st));
-            } else if (fast && !(p->ctx.abl & 64)) {
-                // LDS-resident part of the radial table: what an unrotated chain can reach, else all
-                const bool rot = any_rot || p->ana.has_rot;
-                const int entries = rot ? p->table.n_int : std::min(p->table.n_int, p->tab_reach_entries);
-                HIP_TRY(launch_ray_lin3_persist(p->ctx, ua, n, rot, entries, p->num_cus, st));
-            } else if (fast)
-                HIP_TRY(launch_ray_lin3(p->ctx, ua, n, any_rot || p->ana.has_rot, st));
-            else
+            if (fast) {
+                // precomputed tile boxes describe the plan's own rotation only
+                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, st));
+            } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
+            }
             if (!p->ray_no_rot_safe || any_rot)
                 HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, ua, n, st));
         } else {

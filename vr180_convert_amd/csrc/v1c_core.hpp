@@ -65,6 +65,8 @@ struct RayParams {
     int pad;
     double rot[9];         // composed rotation of the chain (overridden per unit when DevUnit.has_rot)
     double rx, ry, cx, cy;  // Denormalize: x = X*rx + cx, y = Y*ry + cy   (transformer.py:202-203)
+    double rx32, ry32, cx32, cy32;  // the same times 32 (exact): kernels produce cv2's 32*x directly
+    double n_int_f;                 // (double)n_int
 };
 
 // ------------------------------------------------------------------------------------------
@@ -274,7 +276,9 @@ V1C_HD void eval_chain_literal(const v1c_chain* ch, const double* rot, int i, in
 V1C_HDF double fast_sqrt_half(double m)
 {
     // sqrt(m/2) to ~1 ulp: v_rsq_f64 seed, one coupled Newton step, one residual correction
-    const double a = 0.5 * m;
+    // (inputs below 1e-280 -- the exact image centre -- are lifted to it: w ~ 1e-140 instead of
+    // 0 changes G(w) by nothing representable, and keeps v_rsq_f64 away from 0 and denormals)
+    const double a = fmax(0.5 * m, 1e-280);
 #if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(a);
     double g = a * y;
@@ -283,7 +287,7 @@ V1C_HDF double fast_sqrt_half(double m)
     g = fma(g, r, g);
     h = fma(h, r, h);
     g = fma(fma(-g, g, a), h, g);
-    return a > 1e-280 ? g : 0.0;
+    return g;
 #else
     return sqrt(a);
 #endif
@@ -307,8 +311,9 @@ V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], 
         m = fma(cl, hlon, hl);  // 1 - cl*clon without cancellation
     }
     const double u = P.var_is_w ? fast_sqrt_half(m) : m;
-    const double t = u * P.inv_step;
-    if (!(t >= 0.0 && t < (double)P.n_int))  // also rejects NaN
+    // (a rotated ray can give m = -1e-17: clamp; NaN fails the range test)
+    const double t = fmax(u * P.inv_step, 0.0);
+    if (!(t < P.n_int_f))
         return false;
     const int idx = (int)t;
     const double z = t - ((double)idx + 0.5);
@@ -318,10 +323,10 @@ V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], 
     for (int k = kRadialDegree - 1; k >= 0; k--)
         g = fma(g, z, c[k]);
     // computed scaled by 32 (exact): float32(32*x) == 32*float32(x) is cv2's fixed-point input
-    const double x32 = fma(g * (32.0 * P.rx), vx, 32.0 * P.cx);
-    const double y32 = fma(g * (32.0 * P.ry), vy, 32.0 * P.cy);
-    // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
-    if (!(fabs(x32) < 1073741824.0 && fabs(y32) < 1073741824.0))
+    const double x32 = fma(g * P.rx32, vx, P.cx32);
+    const double y32 = fma(g * P.ry32, vy, P.cy32);
+    // flagged intervals carry NaN coefficients; |float32(32 x)| < 2^30 keeps the int conversion exact
+    if (!(fabsf((float)x32) < 1073741824.0f && fabsf((float)y32) < 1073741824.0f))
         return false;
     ox = x32 * 0.03125;
     oy = y32 * 0.03125;
