@@ -189,11 +189,15 @@ def main() -> None:
         from vr180_convert_amd.remapper import _PLANS
 
         paths = sorted({p.path for p in _PLANS.values()})
+        # HBM bytes per launch from the PMC counters: collected by tools_profile.sh in separate
+        # rocprofv3 --pmc passes of this very command (a profiler cannot run inside the timed run)
         traffic = None
         tfile = ROOT / "profiles" / "pmc_traffic_latest.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(args.workload)
+                t = json.loads(tfile.read_text())
+                if t.get("workload") == args.workload:
+                    traffic = t.get("hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {

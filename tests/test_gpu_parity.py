@@ -341,3 +341,53 @@ def test_known_answer_reference_docs_pair_gpu(V, golden_dir):
     sbs = np.concatenate(out, axis=1)
     d = sbs.astype(np.float64) - ref
     assert 10 * np.log10(255.0**2 / np.mean(d * d)) >= 30.0
+
+
+# ---------------------------------------------------------------------------- tile-kernel edge paths
+TILE_EDGE = {
+    # name: (src (H, W), out (W, H), spec, radius)
+    "ragged_sizes": ((275, 301), (333, 217), [("equirect_enc", True), CS.EQUI], 130.0),
+    "tiny": ((9, 7), (5, 3), [("equirect_enc", True), CS.EQUI], 3.0),
+    "one_tile_minus_one": ((64, 64), (63, 15), [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI], 32.0),
+    "minification_box_too_big": ((1500, 1500), (96, 96), [("equirect_enc", True), CS.EQUI], 750.0),
+    "magnification": ((40, 40), (640, 480), [("equirect_enc", True), ("zoom", 3.0), CS.EQUI], 20.0),
+    "rotated_45_boxes": ((700, 700), (512, 512), [("equirect_enc", True), ("rot", CS.ry(0.0)), ("rot_quat", CS.rotvec_quat([0, 0, 0.8])), CS.EQUI], 350.0),
+    "circle_edge_outside": ((300, 300), (256, 256), [("equirect_enc", True), ("zoom", 0.7), CS.EQUI], 150.0),
+}
+
+
+@pytest.mark.parametrize("name", list(TILE_EDGE))
+def test_tile_kernel_edge_paths(V, oracle_mod, dev, name):
+    from vr180_convert_amd.synth import noise_disc
+
+    (sh, sw), out, spec, radius = TILE_EDGE[name]
+    img = noise_disc(sh, sw, 11)
+    img[::7, ::5] = 255  # make the black outside non-uniform so border handling shows
+    want = oracle_mod.apply(spec, [img], size_output=out, interpolation=1, radius=radius, border_value=(3, 250, 77))[0]
+    src = torch.from_numpy(img).to(dev)
+    dst = torch.full((out[1], out[0], 3), 9, dtype=torch.uint8, device=dev)
+    paths = V.remap_tensors(CS.to_product(spec), [src], [dst], radius=radius, interpolation=1, boarder_value=(3, 250, 77))
+    torch.cuda.synchronize()
+    assert paths == ["ray"]
+    assert np.array_equal(dst.cpu().numpy(), want), name
+
+
+def test_tile_kernel_unaligned_source_and_pitched_views(V, oracle_mod, dev):
+    """Source pointers / pitches that are not dword aligned (tile kernel gathers from global
+    memory instead of staging) and destinations that are column views of a wider buffer."""
+    from vr180_convert_amd.synth import noise_disc
+
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    t = CS.to_product(spec)
+    img = noise_disc(200, 203, 5)  # row bytes 609: odd pitch
+    want = oracle_mod.apply(spec, [img], size_output=(180, 170), interpolation=1, radius="max")[0]
+    flat = torch.zeros(200 * 609 + 64, dtype=torch.uint8, device=dev)
+    for shift in (0, 1, 3):
+        src = flat[shift:shift + 200 * 609].view(200, 203, 3)
+        src.copy_(torch.from_numpy(img))
+        wide = torch.zeros((170, 400, 3), dtype=torch.uint8, device=dev)
+        dst = wide[:, 101:281]  # byte offset 303: unaligned destination rows
+        V.remap_tensors(t, [src], [dst], radius=100.0, interpolation=1)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), want), shift
+        assert int(wide[:, :101].max()) == 0 and int(wide[:, 281:].max()) == 0
