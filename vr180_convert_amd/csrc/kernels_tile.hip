@@ -1,5 +1,5 @@
-// kernels_tile.hip -- LDS-tiled kernel for the hot configuration (BGR, INTER_LINEAR,
-// BORDER_CONSTANT, fused ray path).  Same arithmetic as kernels.hip: the tests compare both with
+// kernels_tile.hip -- LDS-tiled kernel for the hot configurations (BGR, BORDER_CONSTANT, fused ray
+// path; INTER_LINEAR, and with K x K table taps INTER_CUBIC / INTER_LANCZOS4).  Same arithmetic as kernels.hip: the tests compare both with
 // the oracle bit for bit.
 //
 // Why tiles: rocprof counters on a gather-from-global version show the vector L1 (TCP) as the
@@ -74,7 +74,8 @@ struct LaneCoords {
 };
 
 // ---- coordinates of a lane's 4 pixels: identical operations to ray_eval() (v1c_core.hpp) ----
-template <int VAR_W, int ROT>
+// K = taps per axis: 2 (bilinear), 4 (bicubic), 8 (Lanczos4); top-left tap at ix - (K/2 - 1)
+template <int VAR_W, int ROT, int K>
 __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, int xc, int jc, int npx, LaneCoords& L)
 {
     const RayParams& P = c.ray;
@@ -180,12 +181,19 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
         L.sx[k] = __float2int_rn(good ? L.fx[k] : 0.0f);
         L.sy[k] = __float2int_rn(good ? L.fy[k] : 0.0f);
         const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-        const bool in = okk & ((unsigned)ix < (unsigned)(g.src_w - 2)) & ((unsigned)iy < (unsigned)(g.src_h - 1));
+        // whole footprint inside the source (remapBilinear / remapBicubic / remapLanczos4 inlier
+        // test); the bilinear path additionally wants 8 readable bytes per row for its global-memory
+        // fallback, hence w - 2 there
+        constexpr int off = K / 2 - 1;
+        const bool in = K == 2 ? okk & ((unsigned)ix < (unsigned)(g.src_w - 2)) & ((unsigned)iy < (unsigned)(g.src_h - 1))
+                               : okk & ((unsigned)(ix - off) < (unsigned)max(g.src_w - (K - 1), 0)) &
+                                     ((unsigned)(iy - off) < (unsigned)max(g.src_h - (K - 1), 0));
         L.inside |= in ? 1u << k : 0u;
     }
 }
 
 // ---- workgroup-wide bounding box of the inside pixels (DPP mins + one LDS exchange) ----
+template <int K>
 __device__ __forceinline__ TileBox reduce_box(const LaneCoords& L, int* red, int tid)
 {
     int xmn = 32767, ymn = 32767, nxmx = 32767, nymx = 32767;  // running mins of x, y, -x, -y
@@ -207,11 +215,13 @@ __device__ __forceinline__ TileBox reduce_box(const LaneCoords& L, int* red, int
     const int by0 = __builtin_amdgcn_readfirstlane(min(min(red[1], red[5]), min(red[9], red[13])));
     const int bx1 = -__builtin_amdgcn_readfirstlane(min(min(red[2], red[6]), min(red[10], red[14])));
     const int by1 = -__builtin_amdgcn_readfirstlane(min(min(red[3], red[7]), min(red[11], red[15])));
+    // footprint of pixel (ix, iy): columns ix-off .. ix-off+K-1, rows iy-off .. iy-off+K-1
+    constexpr int off = K / 2 - 1;
     TileBox b;
-    b.x0 = bx0r & ~3;  // the box starts on a 4-pixel (12-byte) boundary
-    b.y0 = by0;
-    b.cpr = bx0r <= bx1 ? (bx1 + 2 - b.x0 + 3) >> 2 : 0;
-    b.nrows = by1 - by0 + 2;
+    b.x0 = (bx0r - off) & ~3;  // the box starts on a 4-pixel (12-byte) boundary
+    b.y0 = by0 - off;
+    b.cpr = bx0r <= bx1 ? (bx1 - off + K - b.x0 + 3) >> 2 : 0;
+    b.nrows = by1 - by0 + K;
     return b;
 }
 
@@ -301,6 +311,79 @@ __device__ __forceinline__ uint32_t blend3(uint32_t alo, uint32_t ahi, uint32_t 
     return o;
 }
 
+// ---- K x K taps (bicubic / Lanczos4) from the BGRx box with OpenCV's int16 table ----
+// remapBicubic / remapLanczos4 inlier branch: sum over the K x K footprint of S * w, then
+// FixedPtCast: saturate((sum + 2^14) >> 15).  `lo` = dword index of the top-left tap.
+typedef short __attribute__((ext_vector_type(2))) short2v;
+
+// (not inlined: four inlined copies make the scheduler hoist all 4 x K*K tap loads -> 256 VGPRs)
+template <int K>
+__device__ __noinline__ uint32_t blend_table(const uint32_t* boxw, uint32_t lo, int lpw, const short* __restrict__ w)
+{
+    int acc0 = 1 << 14, acc1 = 1 << 14, acc2 = 1 << 14;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        uint32_t d[K];
+#pragma unroll
+        for (int q = 0; q < K; q++)
+            d[q] = boxw[lo + r * lpw + q];
+        uint32_t wr[K / 2];
+        {
+            const uint32_t* wp = (const uint32_t*)(w + r * K);
+#pragma unroll
+            for (int q = 0; q < K / 2; q++)
+                wr[q] = wp[q];
+        }
+#pragma unroll
+        for (int q = 0; q < K / 2; q++) {
+            const short2v ww = __builtin_bit_cast(short2v, wr[q]);
+            // (channel c of pixel 2q, 0, channel c of pixel 2q+1, 0) = two zero-extended int16
+            const uint32_t p0 = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x0c040c00u);
+            const uint32_t p1 = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x0c050c01u);
+            const uint32_t p2 = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x0c060c02u);
+            acc0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, p0), ww, acc0, false);
+            acc1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, p1), ww, acc1, false);
+            acc2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, p2), ww, acc2, false);
+        }
+    }
+    const int o0 = min(max(acc0 >> 15, 0), 255), o1 = min(max(acc1 >> 15, 0), 255), o2 = min(max(acc2 >> 15, 0), 255);
+    return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
+}
+
+// Border-aware K x K sampler for the rare pixel whose footprint leaves the source (same
+// arithmetic as sample_table<3, K> in v1c_core.hpp, loops kept rolled: a small register
+// footprint matters more than speed here because the callee's VGPRs count against the kernel).
+template <int K>
+__device__ __noinline__ uint32_t slow_pixel_table3_t(const uint8_t* src, int64_t pitch, int h, int w, Geom g, const short* itab,
+                                                     float x, float y)
+{
+    const Taps t = quantize(x, y);
+    const short* __restrict__ wt = itab + (size_t)(t.fy * 32 + t.fx) * (K * K);
+    constexpr int off = K / 2 - 1;
+    const int sx = t.ix - off, sy = t.iy - off;
+    if (sx >= w || sx + K <= 0 || sy >= h || sy + K <= 0)  // BORDER_CONSTANT: footprint entirely outside
+        return (uint32_t)g.cval[0] | ((uint32_t)g.cval[1] << 8) | ((uint32_t)g.cval[2] << 16);
+    int a0 = 1 << 14, a1 = 1 << 14, a2 = 1 << 14;
+#pragma unroll 1
+    for (int i = 0; i < K; i++) {
+        const int yi = sy + i;
+        const bool yin = (unsigned)yi < (unsigned)h;
+        const uint8_t* S = src + (int64_t)(yin ? yi : 0) * pitch;
+#pragma unroll 1
+        for (int j = 0; j < K; j++) {
+            const int xj = sx + j;
+            const bool in = yin & ((unsigned)xj < (unsigned)w);
+            const int wv = wt[i * K + j];
+            const uint8_t* p = S + (in ? xj : 0) * 3;
+            a0 += (in ? (int)p[0] : (int)g.cval[0]) * wv;
+            a1 += (in ? (int)p[1] : (int)g.cval[1]) * wv;
+            a2 += (in ? (int)p[2] : (int)g.cval[2]) * wv;
+        }
+    }
+    const int o0 = min(max(a0 >> 15, 0), 255), o1 = min(max(a1 >> 15, 0), 255), o2 = min(max(a2 >> 15, 0), 255);
+    return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
+}
+
 __device__ __forceinline__ void store4(uint8_t* drow, const uint32_t (&pix)[kPX], unsigned ok)
 {
     if (ok == 0xFu && (((uintptr_t)drow) & 3) == 0) {
@@ -341,21 +424,21 @@ __device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid)
 }
 
 // Plan-time pass: the source box of every 64x16 tile (chain rotation as stored in the plan).
-template <int VAR_W, int ROT>
+template <int VAR_W, int ROT, int K>
 __global__ __launch_bounds__(256) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes)
 {
     __shared__ __attribute__((aligned(16))) int red[16];
     const int tid = threadIdx.x;
     const TileIds t = tile_ids(c.g, 0, tid);
     LaneCoords L;
-    lane_coords<VAR_W, ROT>(c, ua, 0, t.xc, t.jc, t.npx, L);
-    const TileBox b = reduce_box(L, red, tid);
+    lane_coords<VAR_W, ROT, K>(c, ua, 0, t.xc, t.jc, t.npx, L);
+    const TileBox b = reduce_box<K>(L, red, tid);
     if (tid == 0)
         boxes[t.box_tile] = b;
 }
 
 // BOXES = 1: boxes precomputed by k_tile_boxes; 0: reduced in-kernel (per-unit rotations)
-template <int VAR_W, int ROT, int BOXES>
+template <int VAR_W, int ROT, int BOXES, int K>
 __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes)
 {
     __shared__ __attribute__((aligned(16))) int red[16];
@@ -382,35 +465,49 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
     }
 
     LaneCoords L;
-    lane_coords<VAR_W, ROT>(c, ua, z, t.xc, t.jc, t.npx, L);
+    lane_coords<VAR_W, ROT, K>(c, ua, z, t.xc, t.jc, t.npx, L);
     if (L.ok != (1u << t.npx) - 1)
         c.tile_flags[t.flag_tile] = 1;
 
     if (!BOXES) {
-        b = reduce_box(L, red, tid);
+        b = reduce_box<K>(L, red, tid);
         use_lds = box_fits(b, src, spitch);
         if (use_lds)
             stage_load(b, src, spitch, src_bytes, tid, S);
     }
 
     uint32_t pix[kPX];
+    unsigned done = 0;  // pixels produced by the tiled path
     if (use_lds) {
         stage_store(b, tid, S, boxw);
         __syncthreads();
         const int lpw = b.cpr * 4 + 4;
-        uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
+        if (K == 2) {
+            uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
 #pragma unroll
-        for (int k = 0; k < kPX; k++) {
-            const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-            const bool in = (L.inside >> k) & 1;
-            const uint32_t lo = in ? __umul24(iy - b.y0, lpw) + (uint32_t)(ix - b.x0) : 0u;
-            alo[k] = boxw[lo], ahi[k] = boxw[lo + 1];
-            blo[k] = boxw[lo + lpw], bhi[k] = boxw[lo + lpw + 1];
+            for (int k = 0; k < kPX; k++) {
+                const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+                const bool in = (L.inside >> k) & 1;
+                const uint32_t lo = in ? __umul24(iy - b.y0, lpw) + (uint32_t)(ix - b.x0) : 0u;
+                alo[k] = boxw[lo], ahi[k] = boxw[lo + 1];
+                blo[k] = boxw[lo + lpw], bhi[k] = boxw[lo + lpw + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < kPX; k++)
+                pix[k] = blend3<4>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
+        } else {
+            constexpr int off = K / 2 - 1;
+#pragma unroll
+            for (int k = 0; k < kPX; k++) {
+                const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+                const bool in = (L.inside >> k) & 1;
+                const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
+                const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
+                pix[k] = blend_table<K>(boxw, lo, lpw, c.itab + a * (K * K));
+            }
         }
-#pragma unroll
-        for (int k = 0; k < kPX; k++)
-            pix[k] = blend3<4>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
-    } else {
+        done = L.inside;
+    } else if (K == 2) {
         uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
 #pragma unroll
         for (int k = 0; k < kPX; k++) {
@@ -424,15 +521,21 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
 #pragma unroll
         for (int k = 0; k < kPX; k++)
             pix[k] = blend3<3>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
+        done = L.inside;
     }
 
-    // pixels that are valid but whose 2x2 cell is not fully inside: border-aware generic sampler
-    const unsigned slow = L.ok & ~L.inside;
+    // everything else that has valid coordinates: border-aware generic sampler
+    const unsigned slow = L.ok & ~done;
     if (slow) {
 #pragma unroll
         for (int k = 0; k < kPX; k++)
-            if (slow & (1u << k))
-                pix[k] = slow_pixel_linear3_t(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, L.fx[k] * 0.03125f, L.fy[k] * 0.03125f);
+            if (slow & (1u << k)) {
+                if (K == 2)
+                    pix[k] = slow_pixel_linear3_t(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, L.fx[k] * 0.03125f, L.fy[k] * 0.03125f);
+                else
+                    pix[k] = slow_pixel_table3_t<K>(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, c.itab, L.fx[k] * 0.03125f,
+                                                    L.fy[k] * 0.03125f);
+            }
     }
     if (!t.active)
         return;
@@ -451,37 +554,56 @@ size_t tile_box_bytes(const Geom& g)
 }
 
 // plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
-hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream)
+template <int K>
+static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, hipStream_t stream)
 {
-    UnitArgs ua{};
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 1);
     const bool rot = c.ray.has_rot != 0;
     if (c.ray.var_is_w) {
         if (rot)
-            hipLaunchKernelGGL((k_tile_boxes<1, 1>), grid, block, 0, stream, c, ua, (TileBox*)boxes);
+            hipLaunchKernelGGL((k_tile_boxes<1, 1, K>), grid, block, 0, stream, c, ua, boxes);
         else
-            hipLaunchKernelGGL((k_tile_boxes<1, 0>), grid, block, 0, stream, c, ua, (TileBox*)boxes);
+            hipLaunchKernelGGL((k_tile_boxes<1, 0, K>), grid, block, 0, stream, c, ua, boxes);
     } else {
         if (rot)
-            hipLaunchKernelGGL((k_tile_boxes<0, 1>), grid, block, 0, stream, c, ua, (TileBox*)boxes);
+            hipLaunchKernelGGL((k_tile_boxes<0, 1, K>), grid, block, 0, stream, c, ua, boxes);
         else
-            hipLaunchKernelGGL((k_tile_boxes<0, 0>), grid, block, 0, stream, c, ua, (TileBox*)boxes);
+            hipLaunchKernelGGL((k_tile_boxes<0, 0, K>), grid, block, 0, stream, c, ua, boxes);
+    }
+}
+
+static int taps_of(int interp)
+{
+    return interp == V1C_INTER_LINEAR ? 2 : interp == V1C_INTER_CUBIC ? 4 : interp == V1C_INTER_LANCZOS4 ? 8 : 0;
+}
+
+bool tile_kernel_supports(const Geom& g)
+{
+    return g.cn == 3 && g.border == V1C_BORDER_CONSTANT && taps_of(g.interp) != 0 && g.src_w >= 3 && g.src_h >= 2;
+}
+
+hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream)
+{
+    UnitArgs ua{};
+    switch (taps_of(c.g.interp)) {
+    case 2: launch_boxes_k<2>(c, ua, (TileBox*)boxes, stream); break;
+    case 4: launch_boxes_k<4>(c, ua, (TileBox*)boxes, stream); break;
+    case 8: launch_boxes_k<8>(c, ua, (TileBox*)boxes, stream); break;
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-// `boxes` may be null (or the units may override the rotation): then boxes are reduced in-kernel
-hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes,
-                                hipStream_t stream)
+template <int K>
+static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, hipStream_t stream)
 {
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, n_units);
-    const TileBox* bx = (const TileBox*)boxes;
-#define V1C_TILE(VW, RT)                                                                           \
-    do {                                                                                           \
-        if (bx)                                                                                    \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1>), grid, block, 0, stream, c, ua, bx);   \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 0>), grid, block, 0, stream, c, ua, bx);   \
+#define V1C_TILE(VW, RT)                                                                              \
+    do {                                                                                              \
+        if (bx)                                                                                       \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K>), grid, block, 0, stream, c, ua, bx);   \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 0, K>), grid, block, 0, stream, c, ua, bx);   \
     } while (0)
     if (c.ray.var_is_w) {
         if (use_rot)
@@ -495,6 +617,19 @@ hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_un
             V1C_TILE(0, 0);
     }
 #undef V1C_TILE
+}
+
+// `boxes` may be null (or the units may override the rotation): then boxes are reduced in-kernel
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes,
+                                hipStream_t stream)
+{
+    const TileBox* bx = (const TileBox*)boxes;
+    switch (taps_of(c.g.interp)) {
+    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, stream); break;
+    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, stream); break;
+    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, stream); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -350,9 +350,9 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 return fail(V1C_E_HIP, std::string("tile flags: ") + hipGetErrorString(e));
             }
             p->ctx.tile_flags = (uint32_t*)d;
-            // source boxes of the tiled kernel, computed once (BGR + bilinear + constant border)
+            // source boxes of the tiled kernel, computed once (BGR, constant border, linear/cubic/lanczos4)
             const Geom& g = p->ctx.g;
-            if (g.cn == 3 && g.interp == V1C_INTER_LINEAR && g.border == V1C_BORDER_CONSTANT && g.src_w >= 3 && g.src_h >= 2) {
+            if (tile_kernel_supports(g)) {
                 void* bx = nullptr;
                 e = hipMalloc(&bx, tile_box_bytes(g));
                 if (e == hipSuccess) {
