@@ -62,11 +62,16 @@ struct u128 {
 
 // source box of one output tile: pixels [x0, x0 + 4*cpr) x rows [y0, y0 + nrows); cpr == 0: no
 // pixel of the tile has its 2x2 cell inside the source
+// idx0 / nidx: range of radial-table entries the tile's in-table pixels use (nidx == 0: unknown)
 struct TileBox {
     int x0, y0, cpr, nrows;
+    int idx0, nidx, pad0, pad1;
 };
 
+constexpr int kTabSlice = 64;  // radial-table entries a workgroup may keep in LDS (4 KB)
+
 struct LaneCoords {
+    int idx_lo, idx_hi;        // range of table entries of the lane's in-table pixels (k_tile_boxes)
     int sx[kPX], sy[kPX];      // cv2's fixed point: cvRound(32 x)
     float fx[kPX], fy[kPX];    // 32 * float32(x)
     unsigned ok;               // coordinate valid (inside the radial table's domain), bit per pixel
@@ -74,13 +79,31 @@ struct LaneCoords {
 };
 
 // ---- coordinates of a lane's 4 pixels: identical operations to ray_eval() (v1c_core.hpp) ----
-// K = taps per axis: 2 (bilinear), 4 (bicubic), 8 (Lanczos4); top-left tap at ix - (K/2 - 1)
-template <int VAR_W, int ROT, int K>
-__device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, int xc, int jc, int npx, LaneCoords& L)
+struct RowCol {
+    double sl, cl, hl;            // row: sin / cos / 1-cos of the latitude
+    double slon[kPX], qlon[kPX];  // columns: sin(lon) and 1-cos(lon) (no rotation) or cos(lon) (rotation)
+};
+
+template <int ROT>
+__device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, RowCol& rc)
+{
+    rc.sl = P.row_s[jc], rc.cl = P.row_c[jc], rc.hl = P.row_h[jc];
+    const double* __restrict__ ps = P.col_s + xc;
+    const double* __restrict__ pq = (ROT ? P.col_c : P.col_h) + xc;
+#pragma unroll
+    for (int k = 0; k < kPX; k++)
+        rc.slon[k] = ps[k], rc.qlon[k] = pq[k];
+}
+
+// K = taps per axis: 2 (bilinear), 4 (bicubic), 8 (Lanczos4); top-left tap at ix - (K/2 - 1).
+// `tab` = radial table (global memory, or the tile's slice in LDS starting at entry `tab0`).
+template <int VAR_W, int ROT, int K, typename TabPtr>
+__device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, const RowCol& rc, int npx, TabPtr tab,
+                                            int tab0, int tabn, LaneCoords& L)
 {
     const RayParams& P = c.ray;
     const Geom& g = c.g;
-    const double sl = P.row_s[jc], cl = P.row_c[jc], hl = P.row_h[jc];
+    const double sl = rc.sl, cl = rc.cl, hl = rc.hl;
     const double rx32 = P.rx32, ry32 = P.ry32, cx32 = P.cx32, cy32 = P.cy32;
 
     double A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, C0 = 0, C1 = 0, C2 = 0;
@@ -93,35 +116,31 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
         A1 = R[3] * cl, B1 = R[5] * cl, C1 = R[4] * sl;
         A2 = R[6] * cl, B2 = R[8] * cl, C2 = R[7] * sl;
     }
-
-    double slon[kPX], qlon[kPX];
-    {
-        const double* __restrict__ ps = P.col_s + xc;
-        const double* __restrict__ pq = (ROT ? P.col_c : P.col_h) + xc;
-#pragma unroll
-        for (int k = 0; k < kPX; k++)
-            slon[k] = ps[k], qlon[k] = pq[k];
-    }
-    double vx[kPX], vy[kPX], tt[kPX];
+    const double* slon = rc.slon;
+    const double* qlon = rc.qlon;
+    // factors of G (see ray_eval): x32 = (G*kx)*fx_[k] + cx32 ; y32 = (G*ky)*fy_[k] + cy32 (rotation)
+    //                                                          y32 = G*ky + cy32          (none)
+    const double kx = ROT ? rx32 : rx32 * cl, ky = ROT ? ry32 : ry32 * sl;
+    double fx_[kPX], fy_[kPX], tt[kPX];
     int idx[kPX];
     unsigned in_table = 0;
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
         double m;
         if (ROT) {
-            vx[k] = fma(A0, slon[k], fma(B0, qlon[k], C0));
-            vy[k] = fma(A1, slon[k], fma(B1, qlon[k], C1));
+            fx_[k] = fma(A0, slon[k], fma(B0, qlon[k], C0));
+            fy_[k] = fma(A1, slon[k], fma(B1, qlon[k], C1));
             m = 1.0 - fma(A2, slon[k], fma(B2, qlon[k], C2));
         } else {
-            vx[k] = cl * slon[k];
-            vy[k] = sl;
+            fx_[k] = slon[k];
+            fy_[k] = 1.0;
             m = fma(cl, qlon[k], hl);
         }
         const double u = VAR_W ? fast_sqrt_half(m) : m;
-        tt[k] = fmax(u * P.inv_step, 0.0);
-        const bool in = tt[k] < P.n_int_f;  // false for NaN
-        in_table |= in ? 1u << k : 0u;
-        idx[k] = (int)fmin(tt[k], P.n_int_f - 1.0);  // clamped: always a readable entry
+        tt[k] = u * P.inv_step;
+        const int ir = table_index(tt[k]);
+        in_table |= (unsigned)ir < (unsigned)P.n_int ? 1u << k : 0u;
+        idx[k] = min(ir, P.n_int - 1);  // clamped: always a readable entry
     }
 
     // radial table: one entry (that of pixel 1) serves all 4 pixels where it may
@@ -131,7 +150,9 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
         double e[kRadialCoefs];
         {
             typedef double __attribute__((ext_vector_type(2))) d2;
-            const d2* p2 = (const d2*)((const char*)P.radial + (uint32_t)ic * (uint32_t)(kRadialCoefs * 8));
+            // (slice-relative and clamped: out-of-table pixels read some entry and are discarded)
+            const uint32_t rel = (uint32_t)min(max(ic - tab0, 0), tabn - 1);
+            const d2* p2 = (const d2*)(tab + rel * (uint32_t)kRadialCoefs);
 #pragma unroll
             for (int q = 0; q < kRadialCoefs / 2; q++) {
                 const d2 v = p2[q];
@@ -156,7 +177,7 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
 #pragma unroll
             for (int k = 0; k < kPX; k++) {
                 if (own & (1u << k)) {
-                    const double* __restrict__ pc = P.radial + (size_t)idx[k] * kRadialCoefs;
+                    const double* __restrict__ pc = P.radial + (size_t)idx[k] * kRadialCoefs;  // always from global
                     const double zk = tt[k] - ((double)idx[k] + 0.5);
                     double gk = pc[kRadialDegree];
 #pragma unroll
@@ -169,17 +190,25 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
     }
 
     L.ok = 0, L.inside = 0;
+    L.idx_lo = 0x7fffffff, L.idx_hi = -0x7fffffff;
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
-        const double x32 = fma(G[k] * rx32, vx[k], cx32), y32 = fma(G[k] * ry32, vy[k], cy32);
+        const bool it = (in_table >> k) & 1;
+        L.idx_lo = min(L.idx_lo, it ? idx[k] : 0x7fffffff), L.idx_hi = max(L.idx_hi, it ? idx[k] : -0x7fffffff);
+    }
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        const double x32 = fma(G[k] * kx, fx_[k], cx32);
+        const double y32 = ROT ? fma(G[k] * ky, fy_[k], cy32) : fma(G[k], ky, cy32);
         L.fx[k] = (float)x32, L.fy[k] = (float)y32;  // = 32 * float32(x)
         // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
         const bool good = (bool)((in_table >> k) & 1) & (fabsf(L.fx[k]) < 1073741824.0f) & (fabsf(L.fy[k]) < 1073741824.0f);
         const bool okk = good & (k < npx);
         L.ok |= okk ? 1u << k : 0u;
-        // branch-free: the conversion always sees a finite, in-range float
-        L.sx[k] = __float2int_rn(good ? L.fx[k] : 0.0f);
-        L.sy[k] = __float2int_rn(good ? L.fy[k] : 0.0f);
+        // branch-free: the conversion always sees an in-range float (NaN -> clamped by med3);
+        // pixels that are not `good` are never used
+        L.sx[k] = __float2int_rn(__builtin_amdgcn_fmed3f(L.fx[k], -1073741824.0f, 1073741824.0f));
+        L.sy[k] = __float2int_rn(__builtin_amdgcn_fmed3f(L.fy[k], -1073741824.0f, 1073741824.0f));
         const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
         // whole footprint inside the source (remapBilinear / remapBicubic / remapLanczos4 inlier
         // test); the bilinear path additionally wants 8 readable bytes per row for its global-memory
@@ -237,6 +266,8 @@ struct Staged {
 };
 
 // ---- issue the box loads: thread t owns chunks t, t+256, t+512, t+768 (4 source pixels each) ----
+// TAIL: the box may reach past the last byte of the image (decided per tile, wave-uniform)
+template <bool TAIL>
 __device__ __forceinline__ void stage_load(const TileBox& b, const uint8_t* __restrict__ src, uint32_t spitch, uint32_t src_bytes,
                                            int tid, Staged& S)
 {
@@ -249,7 +280,7 @@ __device__ __forceinline__ void stage_load(const TileBox& b, const uint8_t* __re
         const uint32_t goff = __umul24(b.y0 + r, spitch) + (uint32_t)(b.x0 + 4 * col) * 3u;
         S.w0[q] = S.w1[q] = S.w2[q] = 0;
         if (ch < (uint32_t)nchunks) {
-            if (goff + 12u <= src_bytes) {
+            if (!TAIL || goff + 12u <= src_bytes) {
                 struct u96 {
                     uint32_t a, b, c;
                 };
@@ -423,64 +454,50 @@ __device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid)
     return t;
 }
 
-// Plan-time pass: the source box of every 64x16 tile (chain rotation as stored in the plan).
+__device__ __forceinline__ bool box_touches_image_end(const TileBox& b, const Geom& g)
+{
+    // only the last chunk(s) of the image's last row can reach past the allocation
+    return (b.y0 + b.nrows >= g.src_h) & ((b.x0 + 4 * b.cpr) > g.src_w);
+}
+
+// Plan-time pass: the source box and the radial-table slice of every 64x16 tile (chain rotation
+// as stored in the plan).
 template <int VAR_W, int ROT, int K>
 __global__ __launch_bounds__(256) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes)
 {
     __shared__ __attribute__((aligned(16))) int red[16];
+    __shared__ int red2[8];
     const int tid = threadIdx.x;
     const TileIds t = tile_ids(c.g, 0, tid);
+    RowCol rc;
+    load_rowcol<ROT>(c.ray, t.xc, t.jc, rc);
     LaneCoords L;
-    lane_coords<VAR_W, ROT, K>(c, ua, 0, t.xc, t.jc, t.npx, L);
-    const TileBox b = reduce_box<K>(L, red, tid);
-    if (tid == 0)
+    lane_coords<VAR_W, ROT, K>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
+    TileBox b = reduce_box<K>(L, red, tid);
+    const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
+    if ((tid & 63) == 63)
+        red2[(tid >> 6) * 2] = lo, red2[(tid >> 6) * 2 + 1] = nhi;
+    __syncthreads();
+    if (tid == 0) {
+        const int i0 = min(min(red2[0], red2[2]), min(red2[4], red2[6]));
+        const int i1 = -min(min(red2[1], red2[3]), min(red2[5], red2[7]));
+        b.idx0 = i0 <= i1 ? i0 : 0;
+        b.nidx = i0 <= i1 ? i1 - i0 + 1 : 0;
+        b.pad0 = b.pad1 = 0;
         boxes[t.box_tile] = b;
+    }
 }
 
-// BOXES = 1: boxes precomputed by k_tile_boxes; 0: reduced in-kernel (per-unit rotations)
-template <int VAR_W, int ROT, int BOXES, int K>
-__global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes)
+// ---- taps, blend, slow-path patch and store: shared tail of the kernel ----
+template <int K>
+__device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
+                                                 const TileBox& b, bool use_lds, const uint32_t* boxw, const uint8_t* __restrict__ src,
+                                                 uint32_t spitch)
 {
-    __shared__ __attribute__((aligned(16))) int red[16];
-    __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
-
     const Geom& g = c.g;
-    const int z = blockIdx.z;
-    const int tid = threadIdx.x;
-    const TileIds t = tile_ids(g, z, tid);
-    const uint8_t* __restrict__ src = ua.u[z].src;
-    const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
-    const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
-
-    TileBox b;
-    bool use_lds = false;
-    Staged S;
-    if (BOXES) {
-        // scalar load of the precomputed box, then the staging loads go out before any math
-        const int4 bb = *(const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
-        b.x0 = bb.x, b.y0 = bb.y, b.cpr = bb.z, b.nrows = bb.w;
-        use_lds = box_fits(b, src, spitch);
-        if (use_lds)
-            stage_load(b, src, spitch, src_bytes, tid, S);
-    }
-
-    LaneCoords L;
-    lane_coords<VAR_W, ROT, K>(c, ua, z, t.xc, t.jc, t.npx, L);
-    if (L.ok != (1u << t.npx) - 1)
-        c.tile_flags[t.flag_tile] = 1;
-
-    if (!BOXES) {
-        b = reduce_box<K>(L, red, tid);
-        use_lds = box_fits(b, src, spitch);
-        if (use_lds)
-            stage_load(b, src, spitch, src_bytes, tid, S);
-    }
-
     uint32_t pix[kPX];
     unsigned done = 0;  // pixels produced by the tiled path
     if (use_lds) {
-        stage_store(b, tid, S, boxw);
-        __syncthreads();
         const int lpw = b.cpr * 4 + 4;
         if (K == 2) {
             uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
@@ -540,6 +557,74 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
     if (!t.active)
         return;
     store4(ua.u[z].dst + (int64_t)t.j * ua.u[z].dst_pitch + (int64_t)t.x0 * 3, pix, L.ok);
+}
+
+// BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes; 0: box reduced in-kernel, table
+// read from global memory (units that override the rotation)
+template <int VAR_W, int ROT, int BOXES, int K>
+__global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes)
+{
+    __shared__ __attribute__((aligned(16))) int red[16];
+    __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
+    __shared__ __attribute__((aligned(16))) double tabw[BOXES ? kTabSlice * kRadialCoefs : 2];
+
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    const int z = blockIdx.z;
+    const int tid = threadIdx.x;
+    const TileIds t = tile_ids(g, z, tid);
+    const uint8_t* __restrict__ src = ua.u[z].src;
+    const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+    const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
+
+    RowCol rc;
+    LaneCoords L;
+    TileBox b;
+    Staged S;
+    bool use_lds;
+    if (BOXES) {
+        // everything the tile needs from global memory is requested up front: the box, the
+        // radial-table slice and the row / column table entries (one exposed latency per tile)
+        const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
+        const int4 b0 = bp[0], b1 = bp[1];
+        b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y;
+        use_lds = box_fits(b, src, spitch);
+        const bool tail = box_touches_image_end(b, g);
+        if (use_lds) {
+            if (tail)
+                stage_load<true>(b, src, spitch, src_bytes, tid, S);
+            else
+                stage_load<false>(b, src, spitch, src_bytes, tid, S);
+        }
+        const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
+        typedef double __attribute__((ext_vector_type(2))) d2;
+        d2 tv = {0.0, 0.0};
+        if (tab_lds && tid < b.nidx * 4)
+            tv = ((const d2*)(P.radial + (size_t)b.idx0 * kRadialCoefs))[tid];
+        load_rowcol<ROT>(P, t.xc, t.jc, rc);
+        if (use_lds)
+            stage_store(b, tid, S, boxw);
+        if (tab_lds && tid < b.nidx * 4)
+            ((d2*)tabw)[tid] = tv;
+        __syncthreads();
+        if (tab_lds)
+            lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        else
+            lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+    } else {
+        load_rowcol<ROT>(P, t.xc, t.jc, rc);
+        lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+        b = reduce_box<K>(L, red, tid);
+        use_lds = box_fits(b, src, spitch);
+        if (use_lds) {
+            stage_load<true>(b, src, spitch, src_bytes, tid, S);
+            stage_store(b, tid, S, boxw);
+        }
+        __syncthreads();
+    }
+    if (L.ok != (1u << t.npx) - 1)
+        c.tile_flags[t.flag_tile] = 1;
+    sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, src, spitch);
 }
 
 static dim3 tile_grid(const Geom& g, int n_units)

@@ -273,6 +273,17 @@ V1C_HD void eval_chain_literal(const v1c_chain* ch, const double* rot, int i, in
 // Returns false when the pixel falls outside the table's validated domain: the caller then uses
 // eval_chain_literal for that pixel.
 // ------------------------------------------------------------------------------------------
+// (int)t with saturation: negative / tiny-negative -> 0.., huge -> INT_MAX, so that one unsigned
+// compare against n_int decides "inside the table".  t is never NaN (finite tables in, finite out).
+V1C_HDF int table_index(double t)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return max((int)t, 0);  // v_cvt_i32_f64 saturates
+#else
+    return t < 0.0 ? 0 : (t >= 2147483647.0 ? 2147483647 : (int)t);
+#endif
+}
+
 V1C_HDF double fast_sqrt_half(double m)
 {
     // sqrt(m/2) to ~1 ulp: v_rsq_f64 seed, one coupled Newton step, one residual correction
@@ -296,26 +307,30 @@ V1C_HDF double fast_sqrt_half(double m)
 V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], double sl, double cl, double hl,
                       double slon, double clon, double hlon, double& ox, double& oy)
 {
-    // NOTE: kernels_fast.hip evaluates these very expressions (same operations, same order); the
+    // NOTE: kernels_tile.hip evaluates these very expressions (same operations, same order); the
     // fix-up pass relies on both agreeing bit for bit on which pixels are inside the table.
-    double vx, vy, m;
+    double m, x32, y32;
+    double sx_, sy_;  // the factors G multiplies: x32 = (G*kx)*sx_ + cx32, y32 = (G*ky)*sy_ + cy32
+    double kx, ky;
     if (use_rot) {
         // R*v with v = (cl*slon, sl, cl*clon), grouped as (R_k0*cl)*slon + (R_k2*cl)*clon + R_k1*sl so
         // that the row-constant factors can be hoisted out of the pixel loop
-        vx = fma(rot[0] * cl, slon, fma(rot[2] * cl, clon, rot[1] * sl));
-        vy = fma(rot[3] * cl, slon, fma(rot[5] * cl, clon, rot[4] * sl));
+        sx_ = fma(rot[0] * cl, slon, fma(rot[2] * cl, clon, rot[1] * sl));
+        sy_ = fma(rot[3] * cl, slon, fma(rot[5] * cl, clon, rot[4] * sl));
         m = 1.0 - fma(rot[6] * cl, slon, fma(rot[8] * cl, clon, rot[7] * sl));
+        kx = P.rx32, ky = P.ry32;
     } else {
-        vx = cl * slon;
-        vy = sl;
+        // v = (cl*slon, sl, .): the row factors cl / sl are folded into the scale
+        sx_ = slon, sy_ = 1.0;
+        kx = P.rx32 * cl, ky = P.ry32 * sl;
         m = fma(cl, hlon, hl);  // 1 - cl*clon without cancellation
     }
     const double u = P.var_is_w ? fast_sqrt_half(m) : m;
-    // (a rotated ray can give m = -1e-17: clamp; NaN fails the range test)
-    const double t = fmax(u * P.inv_step, 0.0);
-    if (!(t < P.n_int_f))
+    const double t = u * P.inv_step;
+    // a rotated ray can give m = -1e-17 (t = -0.0...): the saturating conversion clamps it to entry 0
+    const int idx = table_index(t);
+    if ((unsigned)idx >= (unsigned)P.n_int)
         return false;
-    const int idx = (int)t;
     const double z = t - ((double)idx + 0.5);
     const double* c = P.radial + (size_t)idx * kRadialCoefs;
     double g = c[kRadialDegree];
@@ -323,8 +338,8 @@ V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], 
     for (int k = kRadialDegree - 1; k >= 0; k--)
         g = fma(g, z, c[k]);
     // computed scaled by 32 (exact): float32(32*x) == 32*float32(x) is cv2's fixed-point input
-    const double x32 = fma(g * P.rx32, vx, P.cx32);
-    const double y32 = fma(g * P.ry32, vy, P.cy32);
+    x32 = fma(g * kx, sx_, P.cx32);
+    y32 = use_rot ? fma(g * ky, sy_, P.cy32) : fma(g, ky, P.cy32);
     // flagged intervals carry NaN coefficients; |float32(32 x)| < 2^30 keeps the int conversion exact
     if (!(fabsf((float)x32) < 1073741824.0f && fabsf((float)y32) < 1073741824.0f))
         return false;
