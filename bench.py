@@ -42,6 +42,11 @@ WORKLOADS = {
                desc="L+R 2048x2048 fisheye -> 4096x2048 SBS equirect, equidistant, bilinear"),
     "C4": dict(size=8192, poly=[0, 1, -0.1], rot="ry45", interp=4,
                desc="L+R 8192x8192 -> 16384x8192 SBS, Euler rotation + PolynomialScaler, Lanczos4"),
+    # batch shapes: `frames` SBS frames per GPU per step (BASELINE configs 3 and 5 shard 8 resp. 32 per GPU)
+    "C3": dict(size=2880, poly=None, rot=None, interp=1, frames=8,
+               desc="8 SBS frames 5760x2880 per GPU (of 64 over 8 GPUs), equidistant, bilinear"),
+    "C5": dict(size=3840, poly=None, rot="calib", interp=1, frames=32,
+               desc="32 SBS frames 7680x3840 per GPU (of 256 over 8 GPUs), per-frame per-eye calibration rotation, bilinear"),
 }
 
 
@@ -66,9 +71,25 @@ def build_transformer(cfg):
     t = EquirectangularEncoder()
     if cfg["rot"] == "ry45":
         t = t * Euclidean3DRotator(from_euler_angles(0.0, math.pi / 4, 0.0))
+    if cfg["rot"] == "calib":
+        t = t * Euclidean3DRotator((1.0, 0.0, 0.0, 0.0))  # replaced per unit, see calib_rotations()
     if cfg["poly"] is not None:
         t = t * PolynomialScaler(cfg["poly"])
     return t * FisheyeDecoder("equidistant")
+
+
+def calib_rotations(frame: int):
+    """BASELINE config 5: q = from_rotation_vector(N(0, 0.02)^3) per frame; the left
+    eye gets conj(half_q), the right eye half_q with half_q = sin(phi/2)/sin(phi)*q + 0.5 (cli.py:308-319)."""
+    import math
+
+    from vr180_convert_amd.quat import as_rotation_matrix, from_rotation_vector
+
+    rng = np.random.default_rng(20240619 + frame)
+    q = from_rotation_vector(rng.normal(0, 0.02, 3))
+    phi = math.acos(q.w)
+    half = math.sin(phi / 2) / math.sin(phi) * q + 0.5
+    return as_rotation_matrix(half.conj()), as_rotation_matrix(half)
 
 
 def oracle_spec(cfg):
@@ -149,14 +170,33 @@ def main() -> None:
     cfg = WORKLOADS[args.workload]
     size = cfg["size"]
     transformer = build_transformer(cfg)
-    # seeded noise-disc frames; frame index = rank so ranks hold different pixels
-    left_h, right_h = noise_disc(size, size, 2 * rank), noise_disc(size, size, 2 * rank + 1)
-    left, right = torch.from_numpy(left_h).to(dev), torch.from_numpy(right_h).to(dev)
-    sbs = torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)
+    frames = cfg.get("frames", 0)
+    left_h = right_h = None
+    if frames:
+        # batch of SBS frames resident in HBM; units are the column halves (pitched views), each
+        # eye is written straight into its half of the output SBS frame
+        from vr180_convert_amd.synth import noise_disc_torch
 
-    def step():
-        V.apply_lr_tensors(transformer, left, right, out=sbs, size_output=(size, size), interpolation=cfg["interp"],
-                           radius="max")
+        ins = [noise_disc_torch(size, 2 * size, rank * frames + f, dev) for f in range(frames)]
+        outs = [torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev) for _ in range(frames)]
+        srcs = [v for fr in ins for v in (fr[:, :size], fr[:, size:])]
+        dsts = [v for fr in outs for v in (fr[:, :size], fr[:, size:])]
+        rots = None
+        if cfg["rot"] == "calib":
+            rots = [m for f in range(frames) for m in calib_rotations(rank * frames + f)]
+        sbs = outs[0]
+
+        def step():
+            V.remap_tensors(transformer, srcs, dsts, radius=size / 2, interpolation=cfg["interp"], rotations=rots)
+    else:
+        # seeded noise-disc frames; frame index = rank so ranks hold different pixels
+        left_h, right_h = noise_disc(size, size, 2 * rank), noise_disc(size, size, 2 * rank + 1)
+        left, right = torch.from_numpy(left_h).to(dev), torch.from_numpy(right_h).to(dev)
+        sbs = torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)
+
+        def step():
+            V.apply_lr_tensors(transformer, left, right, out=sbs, size_output=(size, size), interpolation=cfg["interp"],
+                               radius="max")
 
     def barrier():
         if world > 1:
@@ -180,9 +220,12 @@ def main() -> None:
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
     kernel_ms_max = allreduce_max(kernel_ms, dev)
 
-    px_per_step = 2 * size * size * world
+    units = 2 * max(frames, 1)
+    px_per_step = units * size * size * world
     value = px_per_step * args.steps / elapsed / 1e6
-    alg_bytes = 2 * 3 * (size * size + size * size)  # both eyes: source read once + destination written once
+    # all eyes of a step: source read once + destination written once (a batch is ceil(units/16) launches:
+    # the figure is per step, i.e. per group of launches, for batch workloads)
+    alg_bytes = units * 3 * (size * size + size * size)
     achieved = alg_bytes / (kernel_ms_max * 1e-3) / 1e9
 
     if rank == 0:
@@ -206,13 +249,13 @@ def main() -> None:
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 coordinates (fused chain), u8 pixels with int32 fixed-point blend",
             "data": "synthetic (seeded uint8 noise inside the fisheye circle, black outside), resident in HBM",
-            "config": {"workload": f"{args.workload}: {cfg['desc']}", "units_per_step_per_gpu": 2,
+            "config": {"workload": f"{args.workload}: {cfg['desc']}", "units_per_step_per_gpu": units,
                        "sharding": "frames over ranks, no collective", "kernel_path": paths},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not frames:
             torch.cuda.synchronize(dev)
             cb, parity = cpu_baseline(cfg, left_h, right_h, sbs.cpu().numpy())
             line["cpu_baseline"] = cb

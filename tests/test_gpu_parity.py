@@ -391,3 +391,24 @@ def test_tile_kernel_unaligned_source_and_pitched_views(V, oracle_mod, dev):
         torch.cuda.synchronize()
         assert np.array_equal(dst.cpu().numpy(), want), shift
         assert int(wide[:, :101].max()) == 0 and int(wide[:, 281:].max()) == 0
+
+
+def test_rotations_argument_equals_per_unit_transformers(V, oracle_mod, dev):
+    """remap_tensors(..., rotations=[...]) == one Euclidean3DRotator chain per unit."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    size = 192
+    imgs = [noise_disc(size, size, f) for f in range(6)]
+    quats = [CS.c5_spec(f // 2, f % 2)[1][1] for f in range(6)]
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    for interp in (1, 4):
+        dsts = [torch.empty_like(s) for s in srcs]
+        assert V.remap_tensors(base, srcs, dsts, radius=size / 2, interpolation=interp, rotations=quats) == ["ray"]
+        torch.cuda.synchronize()
+        for f in range(6):
+            want = oracle_mod.apply(CS.c5_spec(f // 2, f % 2), [imgs[f]], size_output=(size, size), interpolation=interp, radius=size / 2)[0]
+            assert np.array_equal(dsts[f].cpu().numpy(), want), (interp, f)
+    with pytest.raises(ValueError):
+        V.remap_tensors(T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant"), srcs, dsts, radius=96.0, rotations=quats)

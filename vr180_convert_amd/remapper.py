@@ -193,14 +193,21 @@ def remap_tensors(
     boarder_mode: int = BORDER_CONSTANT,
     boarder_value: Any = 0,
     size_input: tuple[int, int] | None = None,
+    rotations: Sequence[Any] | None = None,
 ) -> list[str]:
     """Device-resident core of ``apply``: remap every ``srcs[k]`` into ``dsts[k]`` (same device,
     same shapes) on the current stream.  ``transformer`` is one chain shared by all units
-    (remapper.py:381-398) or one per unit.  Returns the code path used per launch group
-    ('ray' / 'literal' / 'lut').  Nothing is synchronised."""
+    (remapper.py:381-398) or one per unit.  ``rotations`` (optional, one 3x3 matrix or quaternion
+    per unit) replaces the rotation of the chain's single ``Euclidean3DRotator`` per unit -- the
+    per-frame, per-eye calibration of the CLI (cli.py:308-319) without lowering a chain per unit.
+    Returns the code path used per launch group ('ray' / 'literal' / 'lut').  Nothing is
+    synchronised."""
     n = len(srcs)
     if n == 0:
         return []
+    if rotations is not None:
+        return _remap_with_rotations(transformer, srcs, dsts, rotations, radius=radius, interpolation=interpolation,
+                                     boarder_mode=boarder_mode, boarder_value=boarder_value, size_input=size_input)
     per_unit = list(transformer) if isinstance(transformer, (list, tuple)) else [transformer] * n
     if len(per_unit) != n or len(dsts) != n:
         raise ValueError("need one transformer and one dst per src")
@@ -247,6 +254,24 @@ def remap_tensors(
         plan.run(g["srcs"], g["dsts"], None if g["rots"][0] is None else g["rots"])
         paths.append(plan.path)
     return paths
+
+
+def _remap_with_rotations(transformer, srcs, dsts, rotations, *, radius, interpolation, boarder_mode, boarder_value, size_input):
+    from .quat import as_rotation_matrix
+
+    if isinstance(transformer, (list, tuple)) or len(rotations) != len(srcs) or len(dsts) != len(srcs):
+        raise ValueError("rotations= needs ONE transformer chain and one rotation / dst per src")
+    dev = srcs[0].device
+    src_hw = (int(srcs[0].shape[0]), int(srcs[0].shape[1]))
+    dst_wh = (int(dsts[0].shape[1]), int(dsts[0].shape[0]))
+    chain = lower_for_get_map(transformer, radius=radius, size_input=size_input or src_hw, size_output=dst_wh)
+    shared, rot = _split_single_rotation(chain)
+    if rot is None:
+        raise ValueError("rotations= needs a chain with exactly one Euclidean3DRotator")
+    plan = _plan_for(shared, src_hw=src_hw, dst_wh=dst_wh, cn=int(srcs[0].shape[2]), interpolation=interpolation,
+                     border_mode=boarder_mode, border_value=boarder_value, device=dev)
+    plan.run(srcs, dsts, [as_rotation_matrix(r) for r in rotations])
+    return [plan.path]
 
 
 # --------------------------------------------------------------------------------------------
