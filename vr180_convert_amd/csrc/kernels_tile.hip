@@ -20,6 +20,8 @@
 // Tiles whose box does not fit the LDS budget (strong rotation / minification) gather from global
 // memory; pixels with taps outside the source go through the generic border-aware sampler;
 // pixels outside the radial table's domain are left to the fix-up launch (kernels.hip MODE_FIXUP).
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace v1c {
@@ -69,6 +71,7 @@ struct TileBox {
 };
 
 constexpr int kTabSlice = 64;  // radial-table entries a workgroup may keep in LDS (4 KB)
+constexpr int kUnitsPerBlock = 4;  // units sharing the map that one workgroup serves (BOXES = 1)
 
 struct LaneCoords {
     int idx_lo, idx_hi;        // range of table entries of the lane's in-table pixels (k_tile_boxes)
@@ -348,8 +351,13 @@ __device__ __forceinline__ uint32_t blend3(uint32_t alo, uint32_t ahi, uint32_t 
 typedef short __attribute__((ext_vector_type(2))) short2v;
 
 // (not inlined: four inlined copies make the scheduler hoist all 4 x K*K tap loads -> 256 VGPRs)
+// explicit address spaces: a generic pointer into a noinline function costs a flat-address null
+// check (3 VALU) per tap and defeats ds_read2 / global_load selection
+typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+typedef const __attribute__((address_space(1))) uint32_t* glb_u32_ptr;
+
 template <int K>
-__device__ __noinline__ uint32_t blend_table(const uint32_t* boxw, uint32_t lo, int lpw, const short* __restrict__ w)
+__device__ __noinline__ uint32_t blend_table(lds_u32_ptr boxw, uint32_t lo, int lpw, glb_u32_ptr w)
 {
     int acc0 = 1 << 14, acc1 = 1 << 14, acc2 = 1 << 14;
 #pragma unroll
@@ -359,12 +367,9 @@ __device__ __noinline__ uint32_t blend_table(const uint32_t* boxw, uint32_t lo, 
         for (int q = 0; q < K; q++)
             d[q] = boxw[lo + r * lpw + q];
         uint32_t wr[K / 2];
-        {
-            const uint32_t* wp = (const uint32_t*)(w + r * K);
 #pragma unroll
-            for (int q = 0; q < K / 2; q++)
-                wr[q] = wp[q];
-        }
+        for (int q = 0; q < K / 2; q++)
+            wr[q] = w[r * (K / 2) + q];
 #pragma unroll
         for (int q = 0; q < K / 2; q++) {
             const short2v ww = __builtin_bit_cast(short2v, wr[q]);
@@ -434,7 +439,7 @@ __device__ __forceinline__ void store4(uint8_t* drow, const uint32_t (&pix)[kPX]
 }
 
 struct TileIds {
-    int x0, j, xc, jc, npx, flag_tile, box_tile;
+    int x0, j, xc, jc, npx, flag_tile, flag_stride, box_tile;
     bool active;
 };
 
@@ -450,6 +455,7 @@ __device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid)
     // flag words are indexed like kernels.hip's 256x4 tiles so that MODE_FIXUP finds them
     const int ftx = (g.dst_w + kBlockX * kPX - 1) / (kBlockX * kPX), fty = (g.dst_h + kBlockY - 1) / kBlockY;
     t.flag_tile = (z * fty + t.jc / kBlockY) * ftx + t.xc / (kBlockX * kPX);
+    t.flag_stride = fty * ftx;  // flag words per unit
     t.box_tile = blockIdx.y * gridDim.x + blockIdx.x;
     return t;
 }
@@ -520,7 +526,7 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
                 const bool in = (L.inside >> k) & 1;
                 const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
                 const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
-                pix[k] = blend_table<K>(boxw, lo, lpw, c.itab + a * (K * K));
+                pix[k] = blend_table<K>((lds_u32_ptr)boxw, lo, lpw, (glb_u32_ptr)(c.itab + a * (K * K)));
             }
         }
         done = L.inside;
@@ -559,10 +565,16 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
     store4(ua.u[z].dst + (int64_t)t.j * ua.u[z].dst_pitch + (int64_t)t.x0 * 3, pix, L.ok);
 }
 
-// BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes; 0: box reduced in-kernel, table
-// read from global memory (units that override the rotation)
+// BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes.  The units of one launch share the
+//   map (the reference computes ONE map per apply() call, remapper.py:381-398: both eyes of a pair,
+//   all frames of a batch), so a workgroup evaluates its tile's coordinates once and then serves
+//   `upb` consecutive units: stage box -> taps -> blend -> store per unit, the next unit's box
+//   loads in flight during the current unit's blend.
+// BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
+//   reduced in-kernel, table read from global memory.
 template <int VAR_W, int ROT, int BOXES, int K>
-__global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes)
+__global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
+                                                       int upb)
 {
     __shared__ __attribute__((aligned(16))) int red[16];
     __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
@@ -570,26 +582,26 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
 
     const Geom& g = c.g;
     const RayParams& P = c.ray;
-    const int z = blockIdx.z;
     const int tid = threadIdx.x;
-    const TileIds t = tile_ids(g, z, tid);
-    const uint8_t* __restrict__ src = ua.u[z].src;
-    const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
-    const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
+    const int z0 = BOXES ? blockIdx.z * upb : blockIdx.z;
+    const TileIds t = tile_ids(g, z0, tid);
 
     RowCol rc;
     LaneCoords L;
     TileBox b;
     Staged S;
-    bool use_lds;
     if (BOXES) {
+        const int nu = min(upb, n_units - z0);
+        const uint8_t* __restrict__ src = ua.u[z0].src;
+        uint32_t spitch = (uint32_t)ua.u[z0].src_pitch;
+        uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
         // everything the tile needs from global memory is requested up front: the box, the
         // radial-table slice and the row / column table entries (one exposed latency per tile)
         const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
         const int4 b0 = bp[0], b1 = bp[1];
         b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y;
-        use_lds = box_fits(b, src, spitch);
         const bool tail = box_touches_image_end(b, g);
+        bool use_lds = box_fits(b, src, spitch);
         if (use_lds) {
             if (tail)
                 stage_load<true>(b, src, spitch, src_bytes, tid, S);
@@ -608,23 +620,59 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
             ((d2*)tabw)[tid] = tv;
         __syncthreads();
         if (tab_lds)
-            lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+            lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
         else
-            lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+            lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
+        const bool incomplete = L.ok != (1u << t.npx) - 1;
+
+        for (int u = 0; u < nu; u++) {
+            const int z = z0 + u;
+            if (incomplete)
+                c.tile_flags[t.flag_tile + u * t.flag_stride] = 1;
+            // prefetch the next unit's box into registers while this unit is sampled
+            bool use_next = false;
+            const uint8_t* __restrict__ nsrc = src;
+            uint32_t npitch = spitch;
+            if (u + 1 < nu) {
+                nsrc = ua.u[z + 1].src;
+                npitch = (uint32_t)ua.u[z + 1].src_pitch;
+                src_bytes = (uint32_t)(g.src_h - 1) * npitch + (uint32_t)g.src_w * 3u;
+                use_next = box_fits(b, nsrc, npitch);
+                if (use_next) {
+                    if (tail)
+                        stage_load<true>(b, nsrc, npitch, src_bytes, tid, S);
+                    else
+                        stage_load<false>(b, nsrc, npitch, src_bytes, tid, S);
+                }
+            }
+            sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, ua.u[z].src, spitch);
+            if (u + 1 < nu) {
+                __syncthreads();  // everyone is done reading this unit's box
+                if (use_next)
+                    stage_store(b, tid, S, boxw);
+                __syncthreads();
+                use_lds = use_next;
+                spitch = npitch;
+            }
+        }
     } else {
+        const int z = z0;
+        const uint8_t* __restrict__ src = ua.u[z].src;
+        const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+        const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
         load_rowcol<ROT>(P, t.xc, t.jc, rc);
         lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
         b = reduce_box<K>(L, red, tid);
-        use_lds = box_fits(b, src, spitch);
+        const bool use_lds = box_fits(b, src, spitch);
         if (use_lds) {
             stage_load<true>(b, src, spitch, src_bytes, tid, S);
             stage_store(b, tid, S, boxw);
         }
         __syncthreads();
+        if (L.ok != (1u << t.npx) - 1)
+            c.tile_flags[t.flag_tile] = 1;
+        sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, src, spitch);
     }
-    if (L.ok != (1u << t.npx) - 1)
-        c.tile_flags[t.flag_tile] = 1;
-    sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, src, spitch);
 }
 
 static dim3 tile_grid(const Geom& g, int n_units)
@@ -682,13 +730,15 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream
 template <int K>
 static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, hipStream_t stream)
 {
-    const dim3 block(256, 1, 1), grid = tile_grid(c.g, n_units);
-#define V1C_TILE(VW, RT)                                                                              \
-    do {                                                                                              \
-        if (bx)                                                                                       \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K>), grid, block, 0, stream, c, ua, bx);   \
-        else                                                                                          \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 0, K>), grid, block, 0, stream, c, ua, bx);   \
+    // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
+    const int upb = bx ? std::min(n_units, kUnitsPerBlock) : 1;
+    const dim3 block(256, 1, 1), grid = tile_grid(c.g, (n_units + upb - 1) / upb);
+#define V1C_TILE(VW, RT)                                                                                            \
+    do {                                                                                                            \
+        if (bx)                                                                                                     \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K>), grid, block, 0, stream, c, ua, bx, n_units, upb);   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 0, K>), grid, block, 0, stream, c, ua, bx, n_units, upb);   \
     } while (0)
     if (c.ray.var_is_w) {
         if (use_rot)
