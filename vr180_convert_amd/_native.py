@@ -11,7 +11,10 @@ from pathlib import Path
 
 from . import _abi
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libvr180remap.so"
+import os
+
+# V1C_LIB: alternative build of the same ABI (kernel-tuning experiments); default = the in-tree build
+LIB_PATH = Path(os.environ.get("V1C_LIB") or (Path(__file__).resolve().parent / "csrc" / "libvr180remap.so"))
 
 SYMBOLS = [
     "v1c_abi_version", "v1c_device_count", "v1c_last_error", "v1c_plan_create", "v1c_plan_destroy",

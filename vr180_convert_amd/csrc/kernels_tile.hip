@@ -27,7 +27,13 @@
 namespace v1c {
 
 constexpr int kTW = 64, kTH = 16;          // output tile (px)
-constexpr int kBoxBytes = 24 * 1024;       // LDS budget for the source box (4 B per source pixel)
+#ifndef V1C_BOX_KB
+#define V1C_BOX_KB 24
+#endif
+#ifndef V1C_UPB
+#define V1C_UPB 8
+#endif
+constexpr int kBoxBytes = V1C_BOX_KB * 1024;  // LDS budget for the source box (4 B per source pixel)
 constexpr int kMaxCpr = 64;                // 4-pixel chunks per box row (magic division bound)
 constexpr int kMaxChunks = 1024;           // staged by 256 threads x 4
 
@@ -71,7 +77,7 @@ struct TileBox {
 };
 
 constexpr int kTabSlice = 64;  // radial-table entries a workgroup may keep in LDS (4 KB)
-constexpr int kUnitsPerBlock = 4;  // units sharing the map that one workgroup serves (BOXES = 1)
+constexpr int kUnitsPerBlock = V1C_UPB;  // units sharing the map that one workgroup serves (BOXES = 1)
 
 struct LaneCoords {
     int idx_lo, idx_hi;        // range of table entries of the lane's in-table pixels (k_tile_boxes)
@@ -268,21 +274,44 @@ struct Staged {
     uint32_t w0[4], w1[4], w2[4];
 };
 
-// ---- issue the box loads: thread t owns chunks t, t+256, t+512, t+768 (4 source pixels each) ----
-// TAIL: the box may reach past the last byte of the image (decided per tile, wave-uniform)
-template <bool TAIL>
-__device__ __forceinline__ void stage_load(const TileBox& b, const uint8_t* __restrict__ src, uint32_t spitch, uint32_t src_bytes,
-                                           int tid, Staged& S)
+// Where a thread's (up to) four 4-pixel chunks of the box live: computed once per tile -- the
+// decomposition chunk -> (row, column) costs half-rate integer multiplies -- and reused by every
+// unit the workgroup serves.
+struct ChunkMap {
+    uint32_t row[4];     // box row of chunk q
+    uint32_t xbyte[4];   // byte offset of the chunk inside a source row
+    uint32_t lds_dw[4];  // dword index in the LDS box
+    unsigned valid;      // bit q: chunk q exists
+};
+
+__device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkMap& M)
 {
     const int nchunks = b.nrows * b.cpr;
+    const int lpw = b.cpr * 4 + 4;  // LDS row pitch in dwords (+4: rotate the banks from row to row)
     const uint32_t magic = (65536u + b.cpr - 1) / b.cpr;
+    M.valid = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t ch = tid + q * 256;
         const uint32_t r = (ch * magic) >> 16, col = ch - r * b.cpr;
-        const uint32_t goff = __umul24(b.y0 + r, spitch) + (uint32_t)(b.x0 + 4 * col) * 3u;
+        M.row[q] = b.y0 + r;
+        M.xbyte[q] = (uint32_t)(b.x0 + 4 * col) * 3u;
+        M.lds_dw[q] = r * lpw + col * 4;
+        M.valid |= ch < (uint32_t)nchunks ? 1u << q : 0u;
+    }
+}
+
+// ---- issue the box loads (4 source pixels = 12 bytes per chunk) ----
+// TAIL: the box may reach past the last byte of the image (decided per tile, wave-uniform)
+template <bool TAIL>
+__device__ __forceinline__ void stage_load(const ChunkMap& M, const uint8_t* __restrict__ src, uint32_t spitch, uint32_t src_bytes,
+                                           Staged& S)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
         S.w0[q] = S.w1[q] = S.w2[q] = 0;
-        if (ch < (uint32_t)nchunks) {
+        if (M.valid & (1u << q)) {
+            const uint32_t goff = __umul24(M.row[q], spitch) + M.xbyte[q];
             if (!TAIL || goff + 12u <= src_bytes) {
                 struct u96 {
                     uint32_t a, b, c;
@@ -303,23 +332,18 @@ __device__ __forceinline__ void stage_load(const TileBox& b, const uint8_t* __re
 }
 
 // ---- expand to BGRx and write the box into LDS ----
-__device__ __forceinline__ void stage_store(const TileBox& b, int tid, const Staged& S, uint32_t* boxw)
+__device__ __forceinline__ void stage_store(const ChunkMap& M, const Staged& S, uint32_t* boxw)
 {
-    const int nchunks = b.nrows * b.cpr;
-    const int lpw = b.cpr * 4 + 4;  // LDS row pitch in dwords (+4: rotate the banks from row to row)
-    const uint32_t magic = (65536u + b.cpr - 1) / b.cpr;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t ch = tid + q * 256;
-        if (ch < (uint32_t)nchunks) {
-            const uint32_t r = (ch * magic) >> 16, col = ch - r * b.cpr;
+        if (M.valid & (1u << q)) {
             // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  BGRx x 4
             u128 o;
             o.x = S.w0[q] & 0x00ffffffu;
             o.y = __builtin_amdgcn_perm(S.w1[q], S.w0[q], 0x0c050403u);
             o.z = __builtin_amdgcn_perm(S.w2[q], S.w1[q], 0x0c040302u);
             o.w = S.w2[q] >> 8;
-            *(u128*)(boxw + r * lpw + col * 4) = o;
+            *(u128*)(boxw + M.lds_dw[q]) = o;
         }
     }
 }
@@ -602,11 +626,13 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y;
         const bool tail = box_touches_image_end(b, g);
         bool use_lds = box_fits(b, src, spitch);
+        ChunkMap M;
+        make_chunk_map(b, tid, M);
         if (use_lds) {
             if (tail)
-                stage_load<true>(b, src, spitch, src_bytes, tid, S);
+                stage_load<true>(M, src, spitch, src_bytes, S);
             else
-                stage_load<false>(b, src, spitch, src_bytes, tid, S);
+                stage_load<false>(M, src, spitch, src_bytes, S);
         }
         const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
         typedef double __attribute__((ext_vector_type(2))) d2;
@@ -615,7 +641,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
             tv = ((const d2*)(P.radial + (size_t)b.idx0 * kRadialCoefs))[tid];
         load_rowcol<ROT>(P, t.xc, t.jc, rc);
         if (use_lds)
-            stage_store(b, tid, S, boxw);
+            stage_store(M, S, boxw);
         if (tab_lds && tid < b.nidx * 4)
             ((d2*)tabw)[tid] = tv;
         __syncthreads();
@@ -640,16 +666,16 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
                 use_next = box_fits(b, nsrc, npitch);
                 if (use_next) {
                     if (tail)
-                        stage_load<true>(b, nsrc, npitch, src_bytes, tid, S);
+                        stage_load<true>(M, nsrc, npitch, src_bytes, S);
                     else
-                        stage_load<false>(b, nsrc, npitch, src_bytes, tid, S);
+                        stage_load<false>(M, nsrc, npitch, src_bytes, S);
                 }
             }
             sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, ua.u[z].src, spitch);
             if (u + 1 < nu) {
                 __syncthreads();  // everyone is done reading this unit's box
                 if (use_next)
-                    stage_store(b, tid, S, boxw);
+                    stage_store(M, S, boxw);
                 __syncthreads();
                 use_lds = use_next;
                 spitch = npitch;
@@ -665,8 +691,10 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         b = reduce_box<K>(L, red, tid);
         const bool use_lds = box_fits(b, src, spitch);
         if (use_lds) {
-            stage_load<true>(b, src, spitch, src_bytes, tid, S);
-            stage_store(b, tid, S, boxw);
+            ChunkMap M;
+            make_chunk_map(b, tid, M);
+            stage_load<true>(M, src, spitch, src_bytes, S);
+            stage_store(M, S, boxw);
         }
         __syncthreads();
         if (L.ok != (1u << t.npx) - 1)
