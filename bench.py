@@ -232,7 +232,7 @@ def main() -> None:
         from vr180_convert_amd.remapper import _PLANS
 
         paths = sorted({p.path for p in _PLANS.values()})
-        # HBM bytes per launch from the PMC counters: collected by tools_profile.sh in separate
+        # HBM bytes per launch from the PMC counters: collected by tools/profile.sh in separate
         # rocprofv3 --pmc passes of this very command (a profiler cannot run inside the timed run)
         traffic = None
         tfile = ROOT / "profiles" / "pmc_traffic_latest.json"

@@ -412,3 +412,30 @@ def test_rotations_argument_equals_per_unit_transformers(V, oracle_mod, dev):
             assert np.array_equal(dsts[f].cpu().numpy(), want), (interp, f)
     with pytest.raises(ValueError):
         V.remap_tensors(T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant"), srcs, dsts, radius=96.0, rotations=quats)
+
+
+@pytest.mark.parametrize("interp", [1, 4])
+def test_shared_map_unit_loop_mixed_alignment(V, oracle_mod, dev, interp):
+    """One launch group, 11 units sharing the map (a workgroup serves up to 8 units, reusing its
+    coordinates): units alternate between dword-aligned sources (LDS-staged) and byte-shifted ones
+    (gathered from global memory), with different row pitches."""
+    from vr180_convert_amd.synth import noise_disc
+
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    size = 160
+    imgs = [noise_disc(size, size, f) for f in range(11)]
+    srcs, keep = [], []
+    for f, im in enumerate(imgs):
+        shift = (0, 1, 0, 2, 0, 0, 3, 0, 0, 1, 0)[f]
+        pitch = size * 3 + (0, 4, 8)[f % 3]
+        flat = torch.zeros(size * pitch + 16, dtype=torch.uint8, device=dev)
+        v = flat[shift:shift + size * pitch].view(size, pitch)[:, : size * 3].view(size, size, 3)
+        v.copy_(torch.from_numpy(im))
+        srcs.append(v)
+        keep.append(flat)
+    dsts = [torch.empty((size, size, 3), dtype=torch.uint8, device=dev) for _ in imgs]
+    assert V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=size / 2, interpolation=interp) == ["ray"]
+    torch.cuda.synchronize()
+    want = oracle_mod.apply(spec, imgs, size_output=(size, size), interpolation=interp, radius=size / 2)
+    for f in range(11):
+        assert np.array_equal(dsts[f].cpu().numpy(), want[f]), (interp, f)

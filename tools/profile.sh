@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats of the bench command, then separate PMC
 # passes for FETCH_SIZE and WRITE_SIZE (rocprofv3 cannot hold both in one pass on gfx950).
-# Usage: bash tools_profile.sh <tag> [bench args...]     -> gpurun_out/prof_<tag>/
+# Usage: bash tools/profile.sh <tag> [bench args...]     -> gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r01}; shift || true
 OUT=gpurun_out/prof_$TAG
@@ -18,5 +18,5 @@ for k in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_$k
 done
 rm -rf $OUT/trace
-python3 tools_traffic.py $OUT "$@" > $OUT/traffic.json
+python3 tools/traffic.py $OUT "$@" > $OUT/traffic.json
 cat $OUT/traffic.json
