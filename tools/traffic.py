@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the FETCH_SIZE / WRITE_SIZE rows collected by tools_profile.sh into HBM bytes per launch.
+"""Turn the FETCH_SIZE / WRITE_SIZE rows collected by tools/profile.sh into HBM bytes per launch.
 
 Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section):
 both counters are in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request, i.e. reports half
