@@ -115,13 +115,26 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
     O.set_threads(cores)
     size = cfg["size"]
     spec = oracle_spec(cfg)
-    kw = dict(size_output=(size, size), interpolation=cfg["interp"], radius="max")
-    out = O.apply_lr(spec, left, right, **kw)  # warm (page faults, table build)
+    # output buffers are allocated (and touched) once: the timed passes measure arithmetic, not
+    # first-touch page faults of 100 MB of fresh memory per call
+    xm, ym = np.zeros((size, size), np.float32), np.zeros((size, size), np.float32)
+    out = np.zeros((size, 2 * size, 3), np.uint8)
+    halves = [np.zeros((size, size, 3), np.uint8), np.zeros((size, size, 3), np.uint8)]
+
+    def one_pass():
+        # apply_lr with a shared transformer: ONE map (remapper.py:381-386), remap per eye (:388-398),
+        # concatenate (:518)
+        O.get_map(spec, radius=size / 2, size_input=(size, size), size_output=(size, size), out=(xm, ym))
+        O.remap(left, xm, ym, cfg["interp"], dst=halves[0])
+        O.remap(right, xm, ym, cfg["interp"], dst=halves[1])
+        out[:, :size], out[:, size:] = halves[0], halves[1]
+
+    one_pass()  # warm (table build, thread pool)
     times = []
     t_end = time.perf_counter() + 12.0
     while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 10):
         t0 = time.perf_counter()
-        out = O.apply_lr(spec, left, right, **kw)
+        one_pass()
         times.append(time.perf_counter() - t0)
     best = min(times)
     mpx = 2 * size * size / 1e6
@@ -130,6 +143,32 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
         "sample": f"{len(times)} full passes of the bench workload ({mpx:.1f} Mpx each: fp64 chain per pixel + "
                   f"fixed-point remap, both eyes, one shared map), best of them, OpenMP {cores} threads",
     }
+    # (A) reference-equivalent path: NumPy chain (single-threaded float64 ufunc passes, like the
+    # reference's get_map) on a 1024-row band of the same map + the C remap of that band; and
+    # (B) remap only with a precomputed map (SURVEY.md 8d "CPU baseline")
+    try:
+        from oracle import chain_numpy
+
+        band = 1024 if size >= 1024 else size
+        t0 = time.perf_counter()
+        with np.errstate(all="ignore"):
+            xm, ym = chain_numpy.get_map(spec, radius=size / 2, size_input=(size, size), size_output=(size, band))
+        t_np = time.perf_counter() - t0
+        bd = [np.zeros((band, size, 3), np.uint8), np.zeros((band, size, 3), np.uint8)]
+        O.remap(left, xm, ym, cfg["interp"], dst=bd[0])  # warm
+        t0 = time.perf_counter()
+        O.remap(left, xm, ym, cfg["interp"], dst=bd[0])
+        O.remap(right, xm, ym, cfg["interp"], dst=bd[1])
+        t_rm = time.perf_counter() - t0
+        res["numpy_chain_plus_remap"] = {
+            "value": round(2 * size * band / 1e6 / (t_np + t_rm), 3), "unit": "Mpixels/s",
+            "sample": f"top {band} rows of the workload's map: NumPy float64 chain (1 thread) {t_np:.2f} s + C remap of both eyes "
+                      f"({cores} threads) {t_rm:.3f} s",
+        }
+        res["remap_only"] = {"value": round(2 * size * band / 1e6 / t_rm, 1), "unit": "Mpixels/s",
+                             "sample": "same band, map precomputed"}
+    except Exception as e:  # noqa: BLE001 - the extra baselines must never break the bench line
+        res["numpy_chain_plus_remap"] = {"error": repr(e)}
     parity = None
     if gpu_out is not None:
         diff = np.abs(gpu_out.astype(np.int16) - out.astype(np.int16))

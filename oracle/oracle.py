@@ -178,12 +178,17 @@ def chain_from_spec(spec: Sequence[tuple], *, radius: float, size_input: tuple[i
 
 
 # ----------------------------------------------------------------------------- entry points
-def get_map(spec, *, radius: float, size_input: tuple[int, int], size_output: tuple[int, int] = (2048, 2048), f64: bool = False):
+def get_map(spec, *, radius: float, size_input: tuple[int, int], size_output: tuple[int, int] = (2048, 2048), f64: bool = False,
+            out: tuple[np.ndarray, np.ndarray] | None = None):
     ch = spec if isinstance(spec, Chain) else chain_from_spec(spec, radius=radius, size_input=size_input, size_output=size_output)
     W, H = size_output
     dt = np.float64 if f64 else np.float32
-    xm = np.empty((H, W), dt)
-    ym = np.empty((H, W), dt)
+    if out is not None:  # reuse the caller's (already touched) buffers
+        xm, ym = out
+        assert xm.shape == ym.shape == (H, W) and xm.dtype == ym.dtype == dt and xm.flags.c_contiguous and ym.flags.c_contiguous
+    else:
+        xm = np.empty((H, W), dt)
+        ym = np.empty((H, W), dt)
     fn = lib().orc_get_map_f64 if f64 else lib().orc_get_map
     rc = fn(C.byref(ch), W, H, xm.ctypes.data, ym.ctypes.data)
     if rc != 0:

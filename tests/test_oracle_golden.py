@@ -83,3 +83,16 @@ def test_oracle_get_radius(oracle_mod, golden_dir):
     assert oracle_mod.get_radius_smart("auto", [g["landscape_img"], g["noisy_img"]]) == float(g["smart_auto"])
     assert oracle_mod.get_radius_smart("max", [g["landscape_img"]]) == float(g["smart_max"])
     assert oracle_mod.get_radius_smart(33.5, [g["landscape_img"]]) == float(g["smart_num"])
+
+
+@pytest.mark.parametrize("name", list(CS.SMALL_CASES))
+def test_numpy_chain_vs_goldens(golden_dir, name):
+    """oracle/chain_numpy.py (the reference-equivalent NumPy CPU path timed by bench.py) against the
+    reference's own maps."""
+    from oracle import chain_numpy
+
+    g = np.load(golden_dir / "maps_small.npz")
+    spec, out, inp, radius = CS.SMALL_CASES[name]
+    with np.errstate(all="ignore"):
+        xm, ym = chain_numpy.get_map(spec, radius=radius, size_input=inp, size_output=out)
+    assert_maps_match(xm, ym, g[f"{name}__x"], g[f"{name}__y"], name)

@@ -163,6 +163,8 @@ struct v1c_plan {
     bool chain_has_rot = false;   // any V1C_OP_ROTATE stage (per-unit override allowed)
     int n_rot_stages = 0;
     bool ray_no_rot_safe = false; // no rotation: reachable m stays below the first flagged interval
+    bool ray_plan_rot_safe = false;  // the chain's own rotation keeps every ray inside the validated table
+    bool front_hemisphere = false;   // unrotated rays all have v_z >= 0
     KernelCtx ctx{};
     int tiles = 0;
     void* tile_boxes = nullptr;   // per-tile source boxes of the tiled kernel (plan rotation)
@@ -337,6 +339,8 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             r.rx32 = 32.0 * a.rx, r.ry32 = 32.0 * a.ry, r.cx32 = 32.0 * a.cx, r.cy32 = 32.0 * a.cy;
             r.n_int_f = (double)r.n_int;
             p->ray_no_rot_safe = !a.has_rot && ray_reach_is_safe(p->table, ht.m_reach);
+            p->front_hemisphere = ht.front_hemisphere;
+            p->ray_plan_rot_safe = a.has_rot && ht.front_hemisphere && ray_reach_is_safe(p->table, rotated_reach(a.rot));
             // tile flags for kMaxUnitsPerLaunch units
             void* d = nullptr;
             const size_t nflag = (size_t)p->tiles * kMaxUnitsPerLaunch * sizeof(uint32_t);
@@ -438,7 +442,19 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }
-            if (!p->ray_no_rot_safe || any_rot)
+            // the fix-up pass is skipped when no pixel can land in a flagged table interval: proven at
+            // plan time for the chain's own rotation, per unit for overriding rotations
+            bool need_fixup = !(p->ray_no_rot_safe || p->ray_plan_rot_safe);
+            if (any_rot) {
+                need_fixup = !p->front_hemisphere;
+                for (int k = 0; k < n && !need_fixup; k++) {
+                    const double* r = ua.u[k].has_rot ? ua.u[k].rot : p->ana.rot;
+                    const bool covered = ua.u[k].has_rot || p->ana.has_rot ? ray_reach_is_safe(p->table, rotated_reach(r))
+                                                                           : p->ray_no_rot_safe;
+                    need_fixup = !covered;
+                }
+            }
+            if (need_fixup)
                 HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, ua, n, st));
         } else {
             HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, ua, n, st));

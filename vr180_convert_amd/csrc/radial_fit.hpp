@@ -284,6 +284,7 @@ inline RadialTable build_radial_table(const std::vector<v1c_op>& st)
 struct RayHostTables {
     std::vector<double> col_s, col_c, col_h, row_s, row_c, row_h;
     double m_reach = 0;
+    bool front_hemisphere = false;  // every unrotated ray has v_z >= 0 (|lon|, |lat| <= 90 deg)
 };
 
 #pragma clang fp contract(off)  // follow the reference's rounding order for lat / lon
@@ -313,6 +314,11 @@ inline RayHostTables build_ray_host_tables(const RayAnalysis& a, int dst_w, int 
         t.row_s[j] = std::sin(lat), t.row_c[j] = std::cos(lat), t.row_h[j] = 2 * sh * sh;
         t.m_reach = std::max(t.m_reach, t.row_h[j] + std::max(t.row_c[j] * h_max, t.row_c[j] * h_min));
     }
+    t.front_hemisphere = true;
+    for (int i = 0; i < dst_w; i++)
+        t.front_hemisphere &= t.col_c[i] >= -1e-12;
+    for (int j = 0; j < dst_h; j++)
+        t.front_hemisphere &= t.row_c[j] >= -1e-12;
     return t;
 }
 #pragma clang fp contract(fast)
@@ -326,6 +332,13 @@ inline bool ray_table_usable(const RadialTable& T)
     for (int i = 0; i < front; i++)
         bad += std::isnan(T.coef[(size_t)i * kRadialCoefs]);
     return bad * 4 < front;
+}
+
+// Largest m = 1 - (R v)_z over unit vectors v of the front hemisphere (v_z >= 0): the minimum of
+// r2 . v there is -sqrt(r20^2 + r21^2) when r22 >= 0 (attained on the rim), -1 otherwise.
+inline double rotated_reach(const double* rot)
+{
+    return rot[8] >= 0 ? 1.0 + std::sqrt(rot[6] * rot[6] + rot[7] * rot[7]) : 2.0;
 }
 
 // true when no pixel of an unrotated chain can land in a flagged interval
