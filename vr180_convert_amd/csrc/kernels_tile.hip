@@ -35,7 +35,7 @@ constexpr int kTW = 64, kTH = 16;          // output tile (px)
 #endif
 constexpr int kBoxBytes = V1C_BOX_KB * 1024;  // LDS budget for the source box (4 B per source pixel)
 constexpr int kMaxCpr = 64;                // 4-pixel chunks per box row (magic division bound)
-constexpr int kMaxChunks = 1024;           // staged by 256 threads x 4
+// a thread stages up to 4 chunks: 1024 chunks per 256-thread workgroup, 2048 per 512-thread one
 
 // wave-wide signed min via DPP (no LDS traffic): after the six steps lane 63 holds the result
 template <int CTRL, int ROW_MASK>
@@ -231,7 +231,7 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
 }
 
 // ---- workgroup-wide bounding box of the inside pixels (DPP mins + one LDS exchange) ----
-template <int K>
+template <int K, int NW>
 __device__ __forceinline__ TileBox reduce_box(const LaneCoords& L, int* red, int tid)
 {
     int xmn = 32767, ymn = 32767, nxmx = 32767, nymx = 32767;  // running mins of x, y, -x, -y
@@ -249,10 +249,14 @@ __device__ __forceinline__ TileBox reduce_box(const LaneCoords& L, int* red, int
         r[0] = xmn, r[1] = ymn, r[2] = nxmx, r[3] = nymx;
     }
     __syncthreads();
-    const int bx0r = __builtin_amdgcn_readfirstlane(min(min(red[0], red[4]), min(red[8], red[12])));
-    const int by0 = __builtin_amdgcn_readfirstlane(min(min(red[1], red[5]), min(red[9], red[13])));
-    const int bx1 = -__builtin_amdgcn_readfirstlane(min(min(red[2], red[6]), min(red[10], red[14])));
-    const int by1 = -__builtin_amdgcn_readfirstlane(min(min(red[3], red[7]), min(red[11], red[15])));
+    int m0 = red[0], m1 = red[1], m2 = red[2], m3 = red[3];
+#pragma unroll
+    for (int w = 1; w < NW; w++)
+        m0 = min(m0, red[4 * w]), m1 = min(m1, red[4 * w + 1]), m2 = min(m2, red[4 * w + 2]), m3 = min(m3, red[4 * w + 3]);
+    const int bx0r = __builtin_amdgcn_readfirstlane(m0);
+    const int by0 = __builtin_amdgcn_readfirstlane(m1);
+    const int bx1 = -__builtin_amdgcn_readfirstlane(m2);
+    const int by1 = -__builtin_amdgcn_readfirstlane(m3);
     // footprint of pixel (ix, iy): columns ix-off .. ix-off+K-1, rows iy-off .. iy-off+K-1
     constexpr int off = K / 2 - 1;
     TileBox b;
@@ -263,10 +267,10 @@ __device__ __forceinline__ TileBox reduce_box(const LaneCoords& L, int* red, int
     return b;
 }
 
-__device__ __forceinline__ bool box_fits(const TileBox& b, const uint8_t* src, uint32_t spitch)
+__device__ __forceinline__ bool box_fits(const TileBox& b, const uint8_t* src, uint32_t spitch, int max_chunks)
 {
     const int lpw = b.cpr * 4 + 4;
-    return (b.cpr > 0) & (b.cpr <= kMaxCpr) & (b.nrows * b.cpr <= kMaxChunks) & (b.nrows * lpw * 4 <= kBoxBytes) &
+    return (b.cpr > 0) & (b.cpr <= kMaxCpr) & (b.nrows * b.cpr <= max_chunks) & (b.nrows * lpw * 4 <= kBoxBytes) &
            (((((uintptr_t)src) | spitch) & 3) == 0);
 }
 
@@ -284,16 +288,17 @@ struct ChunkMap {
     unsigned valid;      // bit q: chunk q exists
 };
 
+template <int NT>
 __device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkMap& M)
 {
     const int nchunks = b.nrows * b.cpr;
     const int lpw = b.cpr * 4 + 4;  // LDS row pitch in dwords (+4: rotate the banks from row to row)
-    const uint32_t magic = (65536u + b.cpr - 1) / b.cpr;
+    const uint32_t magic = ((1u << 20) + b.cpr - 1) / b.cpr;  // exact floor(ch / cpr) for ch < 16k, cpr <= 64
     M.valid = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t ch = tid + q * 256;
-        const uint32_t r = (ch * magic) >> 16, col = ch - r * b.cpr;
+        const uint32_t ch = tid + q * NT;
+        const uint32_t r = (ch * magic) >> 20, col = ch - r * b.cpr;
         M.row[q] = b.y0 + r;
         M.xbyte[q] = (uint32_t)(b.x0 + 4 * col) * 3u;
         M.lds_dw[q] = r * lpw + col * 4;
@@ -380,8 +385,8 @@ typedef short __attribute__((ext_vector_type(2))) short2v;
 typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
 typedef const __attribute__((address_space(1))) uint32_t* glb_u32_ptr;
 
-template <int K>
-__device__ __noinline__ uint32_t blend_table(lds_u32_ptr boxw, uint32_t lo, int lpw, glb_u32_ptr w)
+template <int K, typename WPtr>
+__device__ __noinline__ uint32_t blend_table(lds_u32_ptr boxw, uint32_t lo, int lpw, WPtr w)
 {
     int acc0 = 1 << 14, acc1 = 1 << 14, acc2 = 1 << 14;
 #pragma unroll
@@ -467,12 +472,13 @@ struct TileIds {
     bool active;
 };
 
-__device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid)
+// tile (tx, ty) of a grid of tiles_x columns; the tile is 64 px wide and `th` = threads/16 rows high
+__device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid, int tx, int ty, int tiles_x, int th)
 {
     TileIds t;
     const int lx = tid & 15, ly = tid >> 4;
-    t.x0 = (blockIdx.x * 16 + lx) * kPX;
-    t.j = blockIdx.y * kTH + ly;
+    t.x0 = (tx * 16 + lx) * kPX;
+    t.j = ty * th + ly;
     t.active = (t.x0 < g.dst_w) & (t.j < g.dst_h);
     t.xc = min(t.x0, ((g.dst_w + 3) & ~3) - 4), t.jc = min(t.j, g.dst_h - 1);  // clamped for table reads
     t.npx = t.active ? min(kPX, g.dst_w - t.x0) : 0;
@@ -480,7 +486,7 @@ __device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid)
     const int ftx = (g.dst_w + kBlockX * kPX - 1) / (kBlockX * kPX), fty = (g.dst_h + kBlockY - 1) / kBlockY;
     t.flag_tile = (z * fty + t.jc / kBlockY) * ftx + t.xc / (kBlockX * kPX);
     t.flag_stride = fty * ftx;  // flag words per unit
-    t.box_tile = blockIdx.y * gridDim.x + blockIdx.x;
+    t.box_tile = ty * tiles_x + tx;
     return t;
 }
 
@@ -490,27 +496,30 @@ __device__ __forceinline__ bool box_touches_image_end(const TileBox& b, const Ge
     return (b.y0 + b.nrows >= g.src_h) & ((b.x0 + 4 * b.cpr) > g.src_w);
 }
 
-// Plan-time pass: the source box and the radial-table slice of every 64x16 tile (chain rotation
-// as stored in the plan).
-template <int VAR_W, int ROT, int K>
-__global__ __launch_bounds__(256) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes)
+// Plan-time pass: the source box and the radial-table slice of every 64 x (NT/16) tile (chain
+// rotation as stored in the plan).
+template <int VAR_W, int ROT, int K, int NT>
+__global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes)
 {
-    __shared__ __attribute__((aligned(16))) int red[16];
-    __shared__ int red2[8];
+    constexpr int NW = NT / 64;
+    __shared__ __attribute__((aligned(16))) int red[4 * NW];
+    __shared__ int red2[2 * NW];
     const int tid = threadIdx.x;
-    const TileIds t = tile_ids(c.g, 0, tid);
+    const TileIds t = tile_ids(c.g, 0, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / 16);
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, t.jc, rc);
     LaneCoords L;
     lane_coords<VAR_W, ROT, K>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
-    TileBox b = reduce_box<K>(L, red, tid);
+    TileBox b = reduce_box<K, NW>(L, red, tid);
     const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
     if ((tid & 63) == 63)
         red2[(tid >> 6) * 2] = lo, red2[(tid >> 6) * 2 + 1] = nhi;
     __syncthreads();
     if (tid == 0) {
-        const int i0 = min(min(red2[0], red2[2]), min(red2[4], red2[6]));
-        const int i1 = -min(min(red2[1], red2[3]), min(red2[5], red2[7]));
+        int i0 = red2[0], n1 = red2[1];
+        for (int w = 1; w < NW; w++)
+            i0 = min(i0, red2[2 * w]), n1 = min(n1, red2[2 * w + 1]);
+        const int i1 = -n1;
         b.idx0 = i0 <= i1 ? i0 : 0;
         b.nidx = i0 <= i1 ? i1 - i0 + 1 : 0;
         b.pad0 = b.pad1 = 0;
@@ -518,11 +527,12 @@ __global__ __launch_bounds__(256) void k_tile_boxes(KernelCtx c, UnitArgs ua, Ti
     }
 }
 
-// ---- taps, blend, slow-path patch and store: shared tail of the kernel ----
-template <int K>
+// ---- taps, blend, slow-path patch and store: shared tail of the kernels ----
+// `wtab` = OpenCV's int16 weight table for K = 4 / 8 (global memory, or LDS in the persistent kernel)
+template <int K, typename WPtr>
 __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
-                                                 const TileBox& b, bool use_lds, const uint32_t* boxw, const uint8_t* __restrict__ src,
-                                                 uint32_t spitch)
+                                                 const TileBox& b, bool use_lds, const uint32_t* boxw, WPtr wtab,
+                                                 const uint8_t* __restrict__ src, uint32_t spitch)
 {
     const Geom& g = c.g;
     uint32_t pix[kPX];
@@ -550,7 +560,7 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
                 const bool in = (L.inside >> k) & 1;
                 const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
                 const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
-                pix[k] = blend_table<K>((lds_u32_ptr)boxw, lo, lpw, (glb_u32_ptr)(c.itab + a * (K * K)));
+                pix[k] = blend_table<K>((lds_u32_ptr)boxw, lo, lpw, wtab + a * (K * K / 2));
             }
         }
         done = L.inside;
@@ -589,147 +599,132 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
     store4(ua.u[z].dst + (int64_t)t.j * ua.u[z].dst_pitch + (int64_t)t.x0 * 3, pix, L.ok);
 }
 
-// BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes.  The units of one launch share the
-//   map (the reference computes ONE map per apply() call, remapper.py:381-398: both eyes of a pair,
-//   all frames of a batch), so a workgroup evaluates its tile's coordinates once and then serves
-//   `upb` consecutive units: stage box -> taps -> blend -> store per unit, the next unit's box
-//   loads in flight during the current unit's blend.
+// ---- one tile for up to `upb` units that share the map (plan-time boxes) ----
+// The units of one launch share the map (the reference computes ONE map per apply() call,
+// remapper.py:381-398: both eyes of a pair, all frames of a batch), so the workgroup evaluates the
+// tile's coordinates once and then serves the units one after the other: stage box -> taps ->
+// blend -> store, the next unit's box loads in flight during the current unit's blend.
+template <int VAR_W, int ROT, int K, int NT, typename WPtr>
+__device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitArgs& ua, const TileBox* __restrict__ boxes, int n_units,
+                                                int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw, double* tabw, WPtr wtab)
+{
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    const int tid = threadIdx.x;
+    const int z0 = zg * upb;
+    const TileIds t = tile_ids(g, z0, tid, tx, ty, tiles_x, NT / 16);
+    const int nu = min(upb, n_units - z0);
+    const uint8_t* __restrict__ src = ua.u[z0].src;
+    uint32_t spitch = (uint32_t)ua.u[z0].src_pitch;
+    uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
+    // everything the tile needs from global memory is requested up front: the box, the
+    // radial-table slice and the row / column table entries (one exposed latency per tile)
+    TileBox b;
+    const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
+    const int4 b0 = bp[0], b1 = bp[1];
+    b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y;
+    const bool tail = box_touches_image_end(b, g);
+    bool use_lds = box_fits(b, src, spitch, 4 * NT);
+    ChunkMap M;
+    make_chunk_map<NT>(b, tid, M);
+    Staged S;
+    if (use_lds) {
+        if (tail)
+            stage_load<true>(M, src, spitch, src_bytes, S);
+        else
+            stage_load<false>(M, src, spitch, src_bytes, S);
+    }
+    const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    d2 tv = {0.0, 0.0};
+    if (tab_lds && tid < b.nidx * 4)
+        tv = ((const d2*)(P.radial + (size_t)b.idx0 * kRadialCoefs))[tid];
+    RowCol rc;
+    load_rowcol<ROT>(P, t.xc, t.jc, rc);
+    if (use_lds)
+        stage_store(M, S, boxw);
+    if (tab_lds && tid < b.nidx * 4)
+        ((d2*)tabw)[tid] = tv;
+    __syncthreads();
+    LaneCoords L;
+    if (tab_lds)
+        lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+    else
+        lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
+    const bool incomplete = L.ok != (1u << t.npx) - 1;
+
+    for (int u = 0; u < nu; u++) {
+        const int z = z0 + u;
+        if (incomplete)
+            c.tile_flags[t.flag_tile + u * t.flag_stride] = 1;
+        // prefetch the next unit's box into registers while this unit is sampled
+        bool use_next = false;
+        const uint8_t* __restrict__ nsrc = src;
+        uint32_t npitch = spitch;
+        if (u + 1 < nu) {
+            nsrc = ua.u[z + 1].src;
+            npitch = (uint32_t)ua.u[z + 1].src_pitch;
+            src_bytes = (uint32_t)(g.src_h - 1) * npitch + (uint32_t)g.src_w * 3u;
+            use_next = box_fits(b, nsrc, npitch, 4 * NT);
+            if (use_next) {
+                if (tail)
+                    stage_load<true>(M, nsrc, npitch, src_bytes, S);
+                else
+                    stage_load<false>(M, nsrc, npitch, src_bytes, S);
+            }
+        }
+        sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, wtab, ua.u[z].src, spitch);
+        if (u + 1 < nu) {
+            __syncthreads();  // everyone is done reading this unit's box
+            if (use_next)
+                stage_store(M, S, boxw);
+            __syncthreads();
+            use_lds = use_next;
+            spitch = npitch;
+        }
+    }
+}
+
+// BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes, coordinates shared by `upb` units.
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
 template <int VAR_W, int ROT, int BOXES, int K>
 __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                        int upb)
 {
+    constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) int red[16];
     __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
     __shared__ __attribute__((aligned(16))) double tabw[BOXES ? kTabSlice * kRadialCoefs : 2];
-
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
-    const int tid = threadIdx.x;
-    const int z0 = BOXES ? blockIdx.z * upb : blockIdx.z;
-    const TileIds t = tile_ids(g, z0, tid);
-
-    RowCol rc;
-    LaneCoords L;
-    TileBox b;
-    Staged S;
+    const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
     if (BOXES) {
-        const int nu = min(upb, n_units - z0);
-        const uint8_t* __restrict__ src = ua.u[z0].src;
-        uint32_t spitch = (uint32_t)ua.u[z0].src_pitch;
-        uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
-        // everything the tile needs from global memory is requested up front: the box, the
-        // radial-table slice and the row / column table entries (one exposed latency per tile)
-        const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
-        const int4 b0 = bp[0], b1 = bp[1];
-        b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y;
-        const bool tail = box_touches_image_end(b, g);
-        bool use_lds = box_fits(b, src, spitch);
-        ChunkMap M;
-        make_chunk_map(b, tid, M);
-        if (use_lds) {
-            if (tail)
-                stage_load<true>(M, src, spitch, src_bytes, S);
-            else
-                stage_load<false>(M, src, spitch, src_bytes, S);
-        }
-        const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
-        typedef double __attribute__((ext_vector_type(2))) d2;
-        d2 tv = {0.0, 0.0};
-        if (tab_lds && tid < b.nidx * 4)
-            tv = ((const d2*)(P.radial + (size_t)b.idx0 * kRadialCoefs))[tid];
-        load_rowcol<ROT>(P, t.xc, t.jc, rc);
-        if (use_lds)
-            stage_store(M, S, boxw);
-        if (tab_lds && tid < b.nidx * 4)
-            ((d2*)tabw)[tid] = tv;
-        __syncthreads();
-        if (tab_lds)
-            lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
-        else
-            lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
-        const bool incomplete = L.ok != (1u << t.npx) - 1;
-
-        for (int u = 0; u < nu; u++) {
-            const int z = z0 + u;
-            if (incomplete)
-                c.tile_flags[t.flag_tile + u * t.flag_stride] = 1;
-            // prefetch the next unit's box into registers while this unit is sampled
-            bool use_next = false;
-            const uint8_t* __restrict__ nsrc = src;
-            uint32_t npitch = spitch;
-            if (u + 1 < nu) {
-                nsrc = ua.u[z + 1].src;
-                npitch = (uint32_t)ua.u[z + 1].src_pitch;
-                src_bytes = (uint32_t)(g.src_h - 1) * npitch + (uint32_t)g.src_w * 3u;
-                use_next = box_fits(b, nsrc, npitch);
-                if (use_next) {
-                    if (tail)
-                        stage_load<true>(M, nsrc, npitch, src_bytes, S);
-                    else
-                        stage_load<false>(M, nsrc, npitch, src_bytes, S);
-                }
-            }
-            sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, ua.u[z].src, spitch);
-            if (u + 1 < nu) {
-                __syncthreads();  // everyone is done reading this unit's box
-                if (use_next)
-                    stage_store(M, S, boxw);
-                __syncthreads();
-                use_lds = use_next;
-                spitch = npitch;
-            }
-        }
+        shared_map_tile<VAR_W, ROT, K, NT>(c, ua, boxes, n_units, upb, blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, boxw, tabw, wtab);
     } else {
-        const int z = z0;
+        const Geom& g = c.g;
+        const RayParams& P = c.ray;
+        const int tid = threadIdx.x;
+        const int z = blockIdx.z;
+        const TileIds t = tile_ids(g, z, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / 16);
         const uint8_t* __restrict__ src = ua.u[z].src;
         const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
+        RowCol rc;
         load_rowcol<ROT>(P, t.xc, t.jc, rc);
+        LaneCoords L;
         lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
-        b = reduce_box<K>(L, red, tid);
-        const bool use_lds = box_fits(b, src, spitch);
+        const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
+        const bool use_lds = box_fits(b, src, spitch, 4 * NT);
         if (use_lds) {
             ChunkMap M;
-            make_chunk_map(b, tid, M);
+            make_chunk_map<NT>(b, tid, M);
+            Staged S;
             stage_load<true>(M, src, spitch, src_bytes, S);
             stage_store(M, S, boxw);
         }
         __syncthreads();
         if (L.ok != (1u << t.npx) - 1)
             c.tile_flags[t.flag_tile] = 1;
-        sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, src, spitch);
-    }
-}
-
-static dim3 tile_grid(const Geom& g, int n_units)
-{
-    return dim3((g.dst_w + kTW - 1) / kTW, (g.dst_h + kTH - 1) / kTH, n_units);
-}
-
-size_t tile_box_bytes(const Geom& g)
-{
-    const dim3 d = tile_grid(g, 1);
-    return (size_t)d.x * d.y * sizeof(TileBox);
-}
-
-// plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
-template <int K>
-static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, hipStream_t stream)
-{
-    const dim3 block(256, 1, 1), grid = tile_grid(c.g, 1);
-    const bool rot = c.ray.has_rot != 0;
-    if (c.ray.var_is_w) {
-        if (rot)
-            hipLaunchKernelGGL((k_tile_boxes<1, 1, K>), grid, block, 0, stream, c, ua, boxes);
-        else
-            hipLaunchKernelGGL((k_tile_boxes<1, 0, K>), grid, block, 0, stream, c, ua, boxes);
-    } else {
-        if (rot)
-            hipLaunchKernelGGL((k_tile_boxes<0, 1, K>), grid, block, 0, stream, c, ua, boxes);
-        else
-            hipLaunchKernelGGL((k_tile_boxes<0, 0, K>), grid, block, 0, stream, c, ua, boxes);
+        sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, wtab, src, spitch);
     }
 }
 
@@ -743,13 +738,50 @@ bool tile_kernel_supports(const Geom& g)
     return g.cn == 3 && g.border == V1C_BORDER_CONSTANT && taps_of(g.interp) != 0 && g.src_w >= 3 && g.src_h >= 2;
 }
 
+// threads per workgroup (tile = 64 x threads/16) the plan-time boxes are computed for
+int tile_threads(const Geom&)
+{
+    return 256;
+}
+
+static dim3 tile_grid(const Geom& g, int nt, int nz)
+{
+    const int th = nt / 16;
+    return dim3((g.dst_w + kTW - 1) / kTW, (g.dst_h + th - 1) / th, nz);
+}
+
+size_t tile_box_bytes(const Geom& g)
+{
+    const dim3 d = tile_grid(g, tile_threads(g), 1);
+    return (size_t)d.x * d.y * sizeof(TileBox);
+}
+
+// plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
+template <int K, int NT>
+static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, hipStream_t stream)
+{
+    const dim3 block(NT, 1, 1), grid = tile_grid(c.g, NT, 1);
+    const bool rot = c.ray.has_rot != 0;
+    if (c.ray.var_is_w) {
+        if (rot)
+            hipLaunchKernelGGL((k_tile_boxes<1, 1, K, NT>), grid, block, 0, stream, c, ua, boxes);
+        else
+            hipLaunchKernelGGL((k_tile_boxes<1, 0, K, NT>), grid, block, 0, stream, c, ua, boxes);
+    } else {
+        if (rot)
+            hipLaunchKernelGGL((k_tile_boxes<0, 1, K, NT>), grid, block, 0, stream, c, ua, boxes);
+        else
+            hipLaunchKernelGGL((k_tile_boxes<0, 0, K, NT>), grid, block, 0, stream, c, ua, boxes);
+    }
+}
+
 hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream)
 {
     UnitArgs ua{};
     switch (taps_of(c.g.interp)) {
-    case 2: launch_boxes_k<2>(c, ua, (TileBox*)boxes, stream); break;
-    case 4: launch_boxes_k<4>(c, ua, (TileBox*)boxes, stream); break;
-    case 8: launch_boxes_k<8>(c, ua, (TileBox*)boxes, stream); break;
+    case 2: launch_boxes_k<2, 256>(c, ua, (TileBox*)boxes, stream); break;
+    case 4: launch_boxes_k<4, 256>(c, ua, (TileBox*)boxes, stream); break;
+    case 8: launch_boxes_k<8, 256>(c, ua, (TileBox*)boxes, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -760,7 +792,7 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     const int upb = bx ? std::min(n_units, kUnitsPerBlock) : 1;
-    const dim3 block(256, 1, 1), grid = tile_grid(c.g, (n_units + upb - 1) / upb);
+    const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
 #define V1C_TILE(VW, RT)                                                                                            \
     do {                                                                                                            \
         if (bx)                                                                                                     \
@@ -782,10 +814,14 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 #undef V1C_TILE
 }
 
-// `boxes` may be null (or the units may override the rotation): then boxes are reduced in-kernel
-hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes,
+// `boxes` may be null (the units override the rotation): then boxes are reduced in-kernel.
+// (A persistent variant keeping OpenCV's 128 KB Lanczos4 weight table in LDS was tried: with one
+// 512-thread workgroup per CU it cannot hide LDS latency and its 128-byte weight rows land on 8
+// banks -- 6x slower than reading the weights through L2.  See DESIGN.md 4.5.)
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int num_cus,
                                 hipStream_t stream)
 {
+    (void)num_cus;
     const TileBox* bx = (const TileBox*)boxes;
     switch (taps_of(c.g.interp)) {
     case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, stream); break;

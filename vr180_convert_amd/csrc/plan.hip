@@ -168,6 +168,7 @@ struct v1c_plan {
     KernelCtx ctx{};
     int tiles = 0;
     void* tile_boxes = nullptr;   // per-tile source boxes of the tiled kernel (plan rotation)
+    int num_cus = 256;
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     std::vector<void*> allocs;
 };
@@ -368,6 +369,9 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     return fail(V1C_E_HIP, std::string("tile boxes: ") + hipGetErrorString(e));
                 }
                 p->tile_boxes = bx;
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                    p->num_cus = prop.multiProcessorCount;
             }
         }
     }
@@ -438,7 +442,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 fast = (uint64_t)g.src_h * (uint64_t)ua.u[k].src_pitch < 0xFFFFFF00ull && ua.u[k].src_pitch < (1 << 24);
             if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
-                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, st));
+                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->num_cus, st));
             } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }

@@ -244,14 +244,19 @@ def remap_tensors(
             continue
         shared, rot = _split_single_rotation(chain)
         key = bytes(shared) + repr(tuple(srcs[k].shape)).encode()  # different source sizes: different plans
-        g = groups.setdefault(key, {"chain": shared, "src_hw": tuple(srcs[k].shape[:2]), "srcs": [], "dsts": [], "rots": []})
+        g = groups.setdefault(key, {"chain": shared, "full": chain, "src_hw": tuple(srcs[k].shape[:2]), "srcs": [], "dsts": [], "rots": []})
         g["srcs"].append(srcs[k])
         g["dsts"].append(dsts[k])
         g["rots"].append(rot)
     for g in groups.values():
-        plan = _plan_for(g["chain"], src_hw=g["src_hw"], dst_wh=dst_wh, cn=cn, interpolation=interpolation,
-                         border_mode=boarder_mode, border_value=boarder_value, device=dev)
-        plan.run(g["srcs"], g["dsts"], None if g["rots"][0] is None else g["rots"])
+        # one rotation for the whole group (or none): bake it into the plan, which then computes its
+        # tile boxes once and shares coordinates between units; rotations that differ per unit
+        # travel with the units and share the rotation-blanked plan
+        r0 = g["rots"][0]
+        uniform = r0 is None or all(np.array_equal(r, r0) for r in g["rots"])
+        plan = _plan_for(g["full"] if uniform else g["chain"], src_hw=g["src_hw"], dst_wh=dst_wh, cn=cn,
+                         interpolation=interpolation, border_mode=boarder_mode, border_value=boarder_value, device=dev)
+        plan.run(g["srcs"], g["dsts"], None if uniform else g["rots"])
         paths.append(plan.path)
     return paths
 
