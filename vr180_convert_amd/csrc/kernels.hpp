@@ -32,7 +32,8 @@ hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float
 bool tile_kernel_supports(const Geom& g);
 size_t tile_box_bytes(const Geom& g);
 hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream);
-hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int num_cus,
+int tile_half_dwords(const void* host_boxes, size_t n_tiles);
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 hipStream_t stream);
 
 }  // namespace v1c

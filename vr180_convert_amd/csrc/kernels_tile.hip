@@ -267,10 +267,10 @@ __device__ __forceinline__ TileBox reduce_box(const LaneCoords& L, int* red, int
     return b;
 }
 
-__device__ __forceinline__ bool box_fits(const TileBox& b, const uint8_t* src, uint32_t spitch, int max_chunks)
+__device__ __forceinline__ bool box_fits(const TileBox& b, const uint8_t* src, uint32_t spitch, int max_chunks, int box_dwords)
 {
     const int lpw = b.cpr * 4 + 4;
-    return (b.cpr > 0) & (b.cpr <= kMaxCpr) & (b.nrows * b.cpr <= max_chunks) & (b.nrows * lpw * 4 <= kBoxBytes) &
+    return (b.cpr > 0) & (b.cpr <= kMaxCpr) & (b.nrows * b.cpr <= max_chunks) & (b.nrows * lpw <= box_dwords) &
            (((((uintptr_t)src) | spitch) & 3) == 0);
 }
 
@@ -602,38 +602,65 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
 // ---- one tile for up to `upb` units that share the map (plan-time boxes) ----
 // The units of one launch share the map (the reference computes ONE map per apply() call,
 // remapper.py:381-398: both eyes of a pair, all frames of a batch), so the workgroup evaluates the
-// tile's coordinates once and then serves the units one after the other: stage box -> taps ->
-// blend -> store, the next unit's box loads in flight during the current unit's blend.
+// tile's coordinates once and then serves the units one after the other.  The LDS box is double
+// buffered (`boxw`, `boxw + half_dwords`; the plan sizes it from the largest tile box): the boxes
+// of the first two units are requested up front and become visible with the single barrier that
+// also publishes the radial-table slice; later units are prefetched into registers one iteration
+// ahead and cost one barrier each.
+#ifdef V1C_STAMPS
+// diagnostic build only: per-phase cycle sums of every wave's lane 0, added to c.xmap[0..7] (as u64)
+#define V1C_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                  \
+        if ((threadIdx.x & 63) == 0)                                                                   \
+            atomicAdd((unsigned long long*)c.xmap + (i), now_ - stamp_);                               \
+        stamp_ = __builtin_readcyclecounter();                                                         \
+    } while (0)
+#else
+#define V1C_STAMP(i)
+#endif
+
 template <int VAR_W, int ROT, int K, int NT, typename WPtr>
 __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitArgs& ua, const TileBox* __restrict__ boxes, int n_units,
-                                                int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw, double* tabw, WPtr wtab)
+                                                int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw, int half_dwords,
+                                                double* tabw, WPtr wtab)
 {
     const Geom& g = c.g;
     const RayParams& P = c.ray;
     const int tid = threadIdx.x;
+#ifdef V1C_STAMPS
+    unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
     const int z0 = zg * upb;
     const TileIds t = tile_ids(g, z0, tid, tx, ty, tiles_x, NT / 16);
     const int nu = min(upb, n_units - z0);
-    const uint8_t* __restrict__ src = ua.u[z0].src;
-    uint32_t spitch = (uint32_t)ua.u[z0].src_pitch;
-    uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
-    // everything the tile needs from global memory is requested up front: the box, the
-    // radial-table slice and the row / column table entries (one exposed latency per tile)
+    // everything the tile needs from global memory is requested up front: the boxes of the first
+    // two units, the radial-table slice and the row / column table entries (one exposed latency)
     TileBox b;
     const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
     const int4 b0 = bp[0], b1 = bp[1];
     b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y;
     const bool tail = box_touches_image_end(b, g);
-    bool use_lds = box_fits(b, src, spitch, 4 * NT);
     ChunkMap M;
     make_chunk_map<NT>(b, tid, M);
-    Staged S;
-    if (use_lds) {
-        if (tail)
-            stage_load<true>(M, src, spitch, src_bytes, S);
-        else
-            stage_load<false>(M, src, spitch, src_bytes, S);
-    }
+
+    auto issue = [&](int z, Staged& S) -> bool {  // start the box loads of unit z; false: it must gather from global memory
+        const uint8_t* __restrict__ src = ua.u[z].src;
+        const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+        const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
+        const bool fits = box_fits(b, src, spitch, 4 * NT, half_dwords);
+        if (fits) {
+            if (tail)
+                stage_load<true>(M, src, spitch, src_bytes, S);
+            else
+                stage_load<false>(M, src, spitch, src_bytes, S);
+        }
+        return fits;
+    };
+
+    Staged S0, S1;
+    const bool fit0 = issue(z0, S0);
+    const bool fit1 = nu > 1 ? issue(z0 + 1, S1) : false;
     const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
     typedef double __attribute__((ext_vector_type(2))) d2;
     d2 tv = {0.0, 0.0};
@@ -641,47 +668,45 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         tv = ((const d2*)(P.radial + (size_t)b.idx0 * kRadialCoefs))[tid];
     RowCol rc;
     load_rowcol<ROT>(P, t.xc, t.jc, rc);
-    if (use_lds)
-        stage_store(M, S, boxw);
+    V1C_STAMP(0);  // setup + issue of all loads
+    if (fit0)
+        stage_store(M, S0, boxw);
+    if (fit1)
+        stage_store(M, S1, boxw + half_dwords);
     if (tab_lds && tid < b.nidx * 4)
         ((d2*)tabw)[tid] = tv;
+    V1C_STAMP(1);  // wait for the loads + expand + LDS stores
     __syncthreads();
+    V1C_STAMP(2);  // barrier
     LaneCoords L;
     if (tab_lds)
         lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else
         lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
     const bool incomplete = L.ok != (1u << t.npx) - 1;
+    V1C_STAMP(3);  // coordinates
 
+    // Units 0 and 1 are in the two buffers.  Unit v >= 2 goes to buffer v & 1: its loads are issued
+    // (into S0) while unit v-2 is sampled, its LDS store happens at the top of iteration v-1 behind
+    // the barrier that also tells everyone is done with unit v-2, and the barrier at the top of
+    // iteration v makes it visible: one barrier per unit, none at all for a pair.
+    bool fit_cur = fit0, fit_nxt = fit1, fit_s = false;
     for (int u = 0; u < nu; u++) {
         const int z = z0 + u;
         if (incomplete)
             c.tile_flags[t.flag_tile + u * t.flag_stride] = 1;
-        // prefetch the next unit's box into registers while this unit is sampled
-        bool use_next = false;
-        const uint8_t* __restrict__ nsrc = src;
-        uint32_t npitch = spitch;
-        if (u + 1 < nu) {
-            nsrc = ua.u[z + 1].src;
-            npitch = (uint32_t)ua.u[z + 1].src_pitch;
-            src_bytes = (uint32_t)(g.src_h - 1) * npitch + (uint32_t)g.src_w * 3u;
-            use_next = box_fits(b, nsrc, npitch, 4 * NT);
-            if (use_next) {
-                if (tail)
-                    stage_load<true>(M, nsrc, npitch, src_bytes, S);
-                else
-                    stage_load<false>(M, nsrc, npitch, src_bytes, S);
-            }
-        }
-        sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, wtab, ua.u[z].src, spitch);
-        if (u + 1 < nu) {
-            __syncthreads();  // everyone is done reading this unit's box
-            if (use_next)
-                stage_store(M, S, boxw);
+        if (u >= 1 && nu > 2)
             __syncthreads();
-            use_lds = use_next;
-            spitch = npitch;
+        if (u + 1 < nu && u + 1 >= 2) {
+            if (fit_s)
+                stage_store(M, S0, boxw + ((u + 1) & 1) * half_dwords);
+            fit_nxt = fit_s;
         }
+        if (u + 2 < nu)
+            fit_s = issue(z + 2, S0);
+        sample_and_store<K>(c, ua, z, t, L, b, fit_cur, boxw + (u & 1) * half_dwords, wtab, ua.u[z].src, (uint32_t)ua.u[z].src_pitch);
+        fit_cur = fit_nxt;
+        V1C_STAMP(4 + (u & 1));  // taps + blend + store of one unit
     }
 }
 
@@ -690,16 +715,19 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
 //   reduced in-kernel, table read from global memory.
 template <int VAR_W, int ROT, int BOXES, int K>
 __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
-                                                       int upb)
+                                                       int upb, int half_dwords)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) int red[16];
-    __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
     __shared__ __attribute__((aligned(16))) double tabw[BOXES ? kTabSlice * kRadialCoefs : 2];
     const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
     if (BOXES) {
-        shared_map_tile<VAR_W, ROT, K, NT>(c, ua, boxes, n_units, upb, blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, boxw, tabw, wtab);
+        // two box buffers of half_dwords each, sized by the plan from its largest tile box
+        extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
+        shared_map_tile<VAR_W, ROT, K, NT>(c, ua, boxes, n_units, upb, blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, dyn_box,
+                                           half_dwords, tabw, wtab);
     } else {
+        __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
         const Geom& g = c.g;
         const RayParams& P = c.ray;
         const int tid = threadIdx.x;
@@ -713,7 +741,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         LaneCoords L;
         lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
         const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
-        const bool use_lds = box_fits(b, src, spitch, 4 * NT);
+        const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
         if (use_lds) {
             ChunkMap M;
             make_chunk_map<NT>(b, tid, M);
@@ -756,6 +784,24 @@ size_t tile_box_bytes(const Geom& g)
     return (size_t)d.x * d.y * sizeof(TileBox);
 }
 
+// LDS dwords one box buffer must hold so that every stageable tile box of `host_boxes` fits
+// (capped at kMaxHalfDwords: larger boxes gather from global memory)
+constexpr int kMaxHalfDwords = 8192;  // 32 KB per buffer
+
+int tile_half_dwords(const void* host_boxes, size_t n_tiles)
+{
+    const TileBox* b = (const TileBox*)host_boxes;
+    int m = 256;
+    for (size_t i = 0; i < n_tiles; i++) {
+        if (b[i].cpr <= 0 || b[i].cpr > kMaxCpr || b[i].nrows * b[i].cpr > 1024)
+            continue;
+        const int need = b[i].nrows * (b[i].cpr * 4 + 4);
+        if (need <= kMaxHalfDwords)
+            m = std::max(m, need);
+    }
+    return (m + 3) & ~3;
+}
+
 // plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
 template <int K, int NT>
 static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, hipStream_t stream)
@@ -788,17 +834,19 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream
 }
 
 template <int K>
-static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, hipStream_t stream)
+static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, int half_dwords,
+                          hipStream_t stream)
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     const int upb = bx ? std::min(n_units, kUnitsPerBlock) : 1;
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
-#define V1C_TILE(VW, RT)                                                                                            \
-    do {                                                                                                            \
-        if (bx)                                                                                                     \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K>), grid, block, 0, stream, c, ua, bx, n_units, upb);   \
-        else                                                                                                        \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 0, K>), grid, block, 0, stream, c, ua, bx, n_units, upb);   \
+    const size_t lds = bx ? (size_t)half_dwords * 8 + 16 : 0;  // two box buffers
+#define V1C_TILE(VW, RT)                                                                                                            \
+    do {                                                                                                                            \
+        if (bx)                                                                                                                     \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords);    \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 0, K>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords);    \
     } while (0)
     if (c.ray.var_is_w) {
         if (use_rot)
@@ -818,15 +866,14 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 // (A persistent variant keeping OpenCV's 128 KB Lanczos4 weight table in LDS was tried: with one
 // 512-thread workgroup per CU it cannot hide LDS latency and its 128-byte weight rows land on 8
 // banks -- 6x slower than reading the weights through L2.  See DESIGN.md 4.5.)
-hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int num_cus,
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 hipStream_t stream)
 {
-    (void)num_cus;
     const TileBox* bx = (const TileBox*)boxes;
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, stream); break;
-    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, stream); break;
-    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, stream); break;
+    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, stream); break;
+    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, stream); break;
+    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -168,7 +168,7 @@ struct v1c_plan {
     KernelCtx ctx{};
     int tiles = 0;
     void* tile_boxes = nullptr;   // per-tile source boxes of the tiled kernel (plan rotation)
-    int num_cus = 256;
+    int half_dwords = 256;        // LDS dwords per box buffer of the shared-map tile kernel
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     std::vector<void*> allocs;
 };
@@ -355,6 +355,16 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 return fail(V1C_E_HIP, std::string("tile flags: ") + hipGetErrorString(e));
             }
             p->ctx.tile_flags = (uint32_t*)d;
+#ifdef V1C_STAMPS
+            {
+                void* sb = nullptr;
+                if (hipMalloc(&sb, 64) == hipSuccess) {
+                    p->allocs.push_back(sb);
+                    (void)hipMemset(sb, 0, 64);
+                    p->ctx.xmap = (const float*)sb;
+                }
+            }
+#endif
             // source boxes of the tiled kernel, computed once (BGR, constant border, linear/cubic/lanczos4)
             const Geom& g = p->ctx.g;
             if (tile_kernel_supports(g)) {
@@ -369,9 +379,14 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     return fail(V1C_E_HIP, std::string("tile boxes: ") + hipGetErrorString(e));
                 }
                 p->tile_boxes = bx;
-                hipDeviceProp_t prop;
-                if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-                    p->num_cus = prop.multiProcessorCount;
+                // size the kernel's two LDS box buffers from the largest tile box of this plan
+                std::vector<char> hb(tile_box_bytes(g));
+                e = hipMemcpy(hb.data(), bx, hb.size(), hipMemcpyDeviceToHost);
+                if (e != hipSuccess) {
+                    v1c_plan_destroy(p);
+                    return fail(V1C_E_HIP, std::string("tile boxes readback: ") + hipGetErrorString(e));
+                }
+                p->half_dwords = tile_half_dwords(hb.data(), hb.size() / 32);
             }
         }
     }
@@ -383,6 +398,20 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
     *out = p;
     return V1C_OK;
 }
+
+#ifdef V1C_STAMPS
+// diagnostic build only (tools/README.md): per-phase cycle sums written by the tile kernel
+extern "C" int v1c_debug_read_stamps(v1c_plan* p, unsigned long long* out8)
+{
+    if (!p || !p->ctx.xmap)
+        return V1C_E_INVALID;
+    DeviceGuard dg(p->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out8, p->ctx.xmap, 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset((void*)p->ctx.xmap, 0, 64));
+    return V1C_OK;
+}
+#endif
 
 extern "C" int v1c_plan_path(const v1c_plan* p)
 {
@@ -442,7 +471,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 fast = (uint64_t)g.src_h * (uint64_t)ua.u[k].src_pitch < 0xFFFFFF00ull && ua.u[k].src_pitch < (1 << 24);
             if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
-                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->num_cus, st));
+                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords, st));
             } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }
