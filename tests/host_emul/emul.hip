@@ -59,7 +59,7 @@ int emul_get_map(const v1c_chain* ch, const double* rot_or_null, int w, int h, i
     RayAnalysis a = analyze_chain(*ch);
     if (!a.ok)
         return 1;
-    RadialTable T = build_radial_table(a.radial);
+    RadialTable T = build_radial_table(a.radial, table_intervals_for(3.14159265358979323846 / a.norm_s));  // as plan.hip
     if (stats) {
         stats[2] = T.var_is_w;
         stats[3] = T.n_invalid;

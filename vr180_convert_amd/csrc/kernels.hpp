@@ -34,6 +34,6 @@ size_t tile_box_bytes(const Geom& g);
 hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream);
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
-                                hipStream_t stream);
+                                bool shared_entry, hipStream_t stream);
 
 }  // namespace v1c

@@ -106,7 +106,9 @@ __device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, 
 
 // K = taps per axis: 2 (bilinear), 4 (bicubic), 8 (Lanczos4); top-left tap at ix - (K/2 - 1).
 // `tab` = radial table (global memory, or the tile's slice in LDS starting at entry `tab0`).
-template <int VAR_W, int ROT, int K, typename TabPtr>
+// OWN = 0: the plan proved that pixel 1's entry is valid for all 4 pixels of every lane
+// (plan.hip: shared_entry), so the per-pixel fallback is not compiled in.
+template <int VAR_W, int ROT, int K, int OWN, typename TabPtr>
 __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, const RowCol& rc, int npx, TabPtr tab,
                                             int tab0, int tabn, LaneCoords& L)
 {
@@ -168,21 +170,24 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
                 e[2 * q] = v.x, e[2 * q + 1] = v.y;
             }
         }
-        const bool ext = (__double2loint(e[kRadialDegree]) & 1) != 0;  // validated on |z| <= 1.5
+        // validity level of the entry (radial_fit.hpp): the polynomial holds on |z| <= 0.5 + level
+        const double zlim = 0.5 + (double)(__double2loint(e[kRadialDegree]) & 3);
         const double zc = (double)ic + 0.5;
         unsigned own = 0;  // pixels that must use their own entry
 #pragma unroll
         for (int k = 0; k < kPX; k++) {
             const double zk = tt[k] - zc;
-            const bool usec = (idx[k] == ic) | (ext & (fabs(zk) <= 1.5));
-            own |= (!usec & (bool)((in_table >> k) & 1)) ? 1u << k : 0u;
+            if (OWN) {
+                const bool usec = fabs(zk) <= zlim;
+                own |= (!usec & (bool)((in_table >> k) & 1)) ? 1u << k : 0u;
+            }
             double gk = e[kRadialDegree];
 #pragma unroll
             for (int q = kRadialDegree - 1; q >= 0; q--)
                 gk = fma(gk, zk, e[q]);
             G[k] = gk;
         }
-        if (own) {
+        if (OWN && own) {
 #pragma unroll
             for (int k = 0; k < kPX; k++) {
                 if (own & (1u << k)) {
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, t.jc, rc);
     LaneCoords L;
-    lane_coords<VAR_W, ROT, K>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
+    lane_coords<VAR_W, ROT, K, 1>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
     TileBox b = reduce_box<K, NW>(L, red, tid);
     const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
     if ((tid & 63) == 63)
@@ -620,7 +625,7 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
 #define V1C_STAMP(i)
 #endif
 
-template <int VAR_W, int ROT, int K, int NT, typename WPtr>
+template <int VAR_W, int ROT, int K, int OWN, int NT, typename WPtr>
 __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitArgs& ua, const TileBox* __restrict__ boxes, int n_units,
                                                 int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw, int half_dwords,
                                                 double* tabw, WPtr wtab)
@@ -680,9 +685,9 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     V1C_STAMP(2);  // barrier
     LaneCoords L;
     if (tab_lds)
-        lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, OWN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else
-        lane_coords<VAR_W, ROT, K>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
     const bool incomplete = L.ok != (1u << t.npx) - 1;
     V1C_STAMP(3);  // coordinates
 
@@ -713,7 +718,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
 // BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes, coordinates shared by `upb` units.
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
-template <int VAR_W, int ROT, int BOXES, int K>
+template <int VAR_W, int ROT, int BOXES, int K, int OWN>
 __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                        int upb, int half_dwords)
 {
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
     if (BOXES) {
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
         extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-        shared_map_tile<VAR_W, ROT, K, NT>(c, ua, boxes, n_units, upb, blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, dyn_box,
+        shared_map_tile<VAR_W, ROT, K, OWN, NT>(c, ua, boxes, n_units, upb, blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, dyn_box,
                                            half_dwords, tabw, wtab);
     } else {
         __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         RowCol rc;
         load_rowcol<ROT>(P, t.xc, t.jc, rc);
         LaneCoords L;
-        lane_coords<VAR_W, ROT, K>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
         const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
         const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
         if (use_lds) {
@@ -835,18 +840,24 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream
 
 template <int K>
 static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, int half_dwords,
-                          hipStream_t stream)
+                          bool shared_entry, hipStream_t stream)
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     const int upb = bx ? std::min(n_units, kUnitsPerBlock) : 1;
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
     const size_t lds = bx ? (size_t)half_dwords * 8 + 16 : 0;  // two box buffers
-#define V1C_TILE(VW, RT)                                                                                                            \
-    do {                                                                                                                            \
-        if (bx)                                                                                                                     \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords);    \
-        else                                                                                                                        \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 0, K>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords);    \
+#define V1C_TILE_O(VW, RT, BX, OW) \
+    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords)
+#define V1C_TILE(VW, RT)                \
+    do {                                \
+        if (bx && shared_entry)         \
+            V1C_TILE_O(VW, RT, 1, 0);   \
+        else if (bx)                    \
+            V1C_TILE_O(VW, RT, 1, 1);   \
+        else if (shared_entry)          \
+            V1C_TILE_O(VW, RT, 0, 0);   \
+        else                            \
+            V1C_TILE_O(VW, RT, 0, 1);   \
     } while (0)
     if (c.ray.var_is_w) {
         if (use_rot)
@@ -860,20 +871,22 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
             V1C_TILE(0, 0);
     }
 #undef V1C_TILE
+#undef V1C_TILE_O
 }
 
 // `boxes` may be null (the units override the rotation): then boxes are reduced in-kernel.
 // (A persistent variant keeping OpenCV's 128 KB Lanczos4 weight table in LDS was tried: with one
 // 512-thread workgroup per CU it cannot hide LDS latency and its 128-byte weight rows land on 8
 // banks -- 6x slower than reading the weights through L2.  See DESIGN.md 4.5.)
+// `shared_entry`: no lane needs more than pixel 1's table entry (proved by the caller).
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
-                                hipStream_t stream)
+                                bool shared_entry, hipStream_t stream)
 {
     const TileBox* bx = (const TileBox*)boxes;
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, stream); break;
-    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, stream); break;
-    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, stream); break;
+    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, stream); break;
+    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, stream); break;
+    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -170,6 +170,9 @@ struct v1c_plan {
     void* tile_boxes = nullptr;   // per-tile source boxes of the tiled kernel (plan rotation)
     int half_dwords = 256;        // LDS dwords per box buffer of the shared-map tile kernel
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
+    bool disable_shared_entry = false;  // V1C_DISABLE_SHARED_ENTRY=1: keep the per-pixel table fallback compiled in
+    bool plan_shared_entry = false;     // one table entry serves a lane's 4 pixels (ray_entry_is_shared)
+    double ray_step = 0;                // largest angle between horizontally adjacent output rays
     std::vector<void*> allocs;
 };
 
@@ -290,6 +293,8 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
     {
         const char* e = std::getenv("V1C_DISABLE_FAST");
         p->disable_fast = e && e[0] == '1';
+        e = std::getenv("V1C_DISABLE_SHARED_ENTRY");
+        p->disable_shared_entry = e && e[0] == '1';
     }
     rc = plan_common(p, device, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, border_val);
     if (rc) {
@@ -317,7 +322,9 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
 
     p->ana = analyze_chain(*chain);
     if (p->ana.ok) {
-        p->table = build_radial_table(p->ana.radial);
+        // NormalizeTransformer + lon = x * pi/2: adjacent output pixels' rays are <= pi / s apart
+        p->ray_step = 3.14159265358979323846 / p->ana.norm_s;
+        p->table = build_radial_table(p->ana.radial, table_intervals_for(p->ray_step));
         if (ray_table_usable(p->table)) {
             p->mode = MODE_RAY;
             const RayAnalysis& a = p->ana;
@@ -342,6 +349,14 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             p->ray_no_rot_safe = !a.has_rot && ray_reach_is_safe(p->table, ht.m_reach);
             p->front_hemisphere = ht.front_hemisphere;
             p->ray_plan_rot_safe = a.has_rot && ht.front_hemisphere && ray_reach_is_safe(p->table, rotated_reach(a.rot));
+            p->plan_shared_entry = (p->ray_no_rot_safe && ray_entry_is_shared(p->table, ht.m_reach, p->ray_step)) ||
+                                   (p->ray_plan_rot_safe && ray_entry_is_shared(p->table, rotated_reach(a.rot), p->ray_step));
+            if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+                std::fprintf(stderr,
+                             "[v1c] ray plan: var=%s n_int=%d first_invalid=%d first_below_level1=%d first_below_level2=%d m_reach=%.6f "
+                             "ray_step=%.3e no_rot_safe=%d plan_rot_safe=%d shared_entry=%d\n",
+                             r.var_is_w ? "w" : "m", r.n_int, p->table.first_invalid, p->table.first_below_level[1], p->table.first_below_level[2],
+                             ht.m_reach, p->ray_step, (int)p->ray_no_rot_safe, (int)p->ray_plan_rot_safe, (int)p->plan_shared_entry);
             // tile flags for kMaxUnitsPerLaunch units
             void* d = nullptr;
             const size_t nflag = (size_t)p->tiles * kMaxUnitsPerLaunch * sizeof(uint32_t);
@@ -469,23 +484,30 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             bool fast = p->tile_boxes != nullptr && !p->disable_fast;
             for (int k = 0; k < n && fast; k++)
                 fast = (uint64_t)g.src_h * (uint64_t)ua.u[k].src_pitch < 0xFFFFFF00ull && ua.u[k].src_pitch < (1 << 24);
-            if (fast) {
-                // precomputed tile boxes describe the plan's own rotation only
-                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords, st));
-            } else {
-                HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
-            }
             // the fix-up pass is skipped when no pixel can land in a flagged table interval: proven at
-            // plan time for the chain's own rotation, per unit for overriding rotations
+            // plan time for the chain's own rotation, per unit for overriding rotations; likewise
+            // `shared_entry` (one table entry per lane, no per-pixel fallback in the kernel)
             bool need_fixup = !(p->ray_no_rot_safe || p->ray_plan_rot_safe);
+            bool shared_entry = p->plan_shared_entry;
             if (any_rot) {
                 need_fixup = !p->front_hemisphere;
+                shared_entry = p->front_hemisphere;
                 for (int k = 0; k < n && !need_fixup; k++) {
                     const double* r = ua.u[k].has_rot ? ua.u[k].rot : p->ana.rot;
-                    const bool covered = ua.u[k].has_rot || p->ana.has_rot ? ray_reach_is_safe(p->table, rotated_reach(r))
-                                                                           : p->ray_no_rot_safe;
+                    const bool rotated = ua.u[k].has_rot || p->ana.has_rot;
+                    const bool covered = rotated ? ray_reach_is_safe(p->table, rotated_reach(r)) : p->ray_no_rot_safe;
                     need_fixup = !covered;
+                    shared_entry = shared_entry && covered &&
+                                   (rotated ? ray_entry_is_shared(p->table, rotated_reach(r), p->ray_step) : p->plan_shared_entry);
                 }
+                shared_entry = shared_entry && !need_fixup;
+            }
+            if (fast) {
+                // precomputed tile boxes describe the plan's own rotation only
+                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
+                                             shared_entry && !p->disable_shared_entry, st));
+            } else {
+                HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }
             if (need_fixup)
                 HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, ua, n, st));

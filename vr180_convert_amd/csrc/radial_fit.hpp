@@ -39,8 +39,9 @@ struct RadialTable {
     double inv_step = 0;
     double u_max = 0;
     int first_invalid = 0;  // index of the first flagged interval (== n_int if none)
+    int first_below_level[3] = {0, 0, 0};  // index of the first interval whose validity level is < 0 / 1 / 2
     int n_invalid = 0;
-    int n_extended = 0;     // intervals whose polynomial is also valid on the 3x wider range
+    int n_extended = 0;     // intervals whose polynomial is valid beyond their own range (level >= 1)
     std::vector<double> coef;  // n_int * kRadialCoefs
 };
 
@@ -182,87 +183,88 @@ inline bool solve_vandermonde(int n, const long double* z, const long double* y,
     return true;
 }
 
-inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w)
+// Fit one table.  Every interval i (table variable u in [i, i+1) * step, z = u / step - (i + 0.5))
+// gets the polynomial of the WIDEST range that validates:
+//   level 2: |z| <= 2.5   level 1: |z| <= 1.5   level 0: |z| <= 0.5 (its own interval only)
+// (fitting on the wide range keeps the noise of the high coefficients harmless there: nodes on
+// [-0.5, 0.5] leave ~1e-16 of long-double rounding in c7, which 1.5^7 would amplify past the
+// tolerance).  The level is stored in the two low mantissa bits of c7; the DOUBLE Horner the
+// kernels run is validated with those bits already in place.  kernels_tile.hip uses pixel 1's
+// entry for all 4 pixels of a lane wherever the level allows.
+inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w, int n_int = kTableIntervals)
 {
     RadialTable T;
     T.var_is_w = var_is_w;
-    T.n_int = kTableIntervals;
+    T.n_int = n_int;
     T.u_max = var_is_w ? std::sqrt(kTableMMax / 2) : kTableMMax;
     // a step that is exactly representable keeps t = u * inv_step monotone and cheap
     T.inv_step = std::ldexp(std::floor(std::ldexp(T.n_int / T.u_max, 20)), -20);
     const long double step = 1.0L / (long double)T.inv_step;
     T.coef.assign((size_t)T.n_int * kRadialCoefs, NAN);
     T.first_invalid = T.n_int;
+    T.first_below_level[0] = T.first_below_level[1] = T.first_below_level[2] = T.n_int;
     const int n = kRadialCoefs;
-    long double zn[16];
+    long double cheb[16];
     for (int k = 0; k < n; k++)
-        zn[k] = 0.5L * cosl(M_PIl * (2 * k + 1) / (2.0L * n));  // Chebyshev nodes on [-0.5, 0.5]
+        cheb[k] = cosl(M_PIl * (2 * k + 1) / (2.0L * n));  // Chebyshev nodes on [-1, 1]
     const double tol = 1.5e-15;
     for (int i = 0; i < T.n_int; i++) {
         const long double a = i * step;
-        long double y[16], c[16];
-        bool good = true;
-        for (int k = 0; k < n && good; k++)
-            good = G_of_u(st, var_is_w, a + step * (zn[k] + 0.5L), y[k]);
-        if (good)
-            good = solve_vandermonde(n, zn, y, c);
         double cd[16];
-        bool ext_ok = false;
-        if (good) {
+        int level = -1;
+        for (int lv = 2; lv >= 0 && level < 0; lv--) {
+            // (the table variable is never negative: nothing to cover left of u = 0)
+            const long double zlo = std::max(-(0.5L + lv), -(i + 0.5L)), zhi = 0.5L + lv;
+            long double zn[16], y[16], c[16];
+            bool good = true;
+            for (int k = 0; k < n && good; k++) {
+                zn[k] = 0.5L * (zlo + zhi) + 0.5L * (zhi - zlo) * cheb[k];
+                good = G_of_u(st, var_is_w, a + step * (zn[k] + 0.5L), y[k]);
+            }
+            if (!good || !solve_vandermonde(n, zn, y, c))
+                continue;
             for (int k = 0; k < n; k++)
                 cd[k] = (double)c[k];
-            // The LSB of c7 is a flag: 1 = "this polynomial is also within tolerance on the 3x wider
-            // range z in [-1.5, 1.5]" (kernels_tile.hip then uses one entry for a lane's 4 pixels).
-            // Validate the DOUBLE Horner the kernels run, with the flag bit already in place.
-            auto set_flag = [&](bool on) {
-                uint64_t bits;
-                std::memcpy(&bits, &cd[n - 1], 8);
-                bits = on ? (bits | 1ull) : (bits & ~1ull);
-                std::memcpy(&cd[n - 1], &bits, 8);
-            };
-            auto check = [&](long double zlo, long double zhi, int ntest) {
-                std::vector<long double> gt(ntest), zt(ntest);
-                long double gmax = 0;
-                for (int q = 0; q < ntest; q++) {
-                    zt[q] = zlo + (zhi - zlo) * (q + 0.5L) / ntest;
-                    if (!G_of_u(st, var_is_w, a + step * (zt[q] + 0.5L), gt[q]))
-                        return false;
-                    gmax = fmaxl(gmax, fabsl(gt[q]));
-                }
-                for (int q = 0; q < ntest; q++) {
-                    const double z = (double)zt[q];
-                    double g = cd[n - 1];
-                    for (int k = n - 2; k >= 0; k--)
-                        g = std::fma(g, z, cd[k]);
-                    if (!(fabsl((long double)g - gt[q]) <= tol * gmax))
-                        return false;
-                }
-                return true;
-            };
-            set_flag(true);
-            // (interval 0 has nothing on its left: the table variable is never negative)
-            ext_ok = check(i == 0 ? -0.5L : -1.5L, 1.5L, 12 * n + 1);
-            if (!ext_ok) {
-                set_flag(false);
-                good = check(-0.5L, 0.5L, 4 * n + 1);
+            uint64_t bits;
+            std::memcpy(&bits, &cd[n - 1], 8);
+            bits = (bits & ~3ull) | (uint64_t)lv;
+            std::memcpy(&cd[n - 1], &bits, 8);
+            const int ntest = (4 * n + 1) * (2 * lv + 1);
+            long double gmax = 0;
+            std::vector<long double> gt(ntest), zt(ntest);
+            for (int q = 0; q < ntest && good; q++) {
+                zt[q] = zlo + (zhi - zlo) * (q + 0.5L) / ntest;
+                good = G_of_u(st, var_is_w, a + step * (zt[q] + 0.5L), gt[q]);
+                gmax = fmaxl(gmax, fabsl(gt[q]));
             }
+            for (int q = 0; q < ntest && good; q++) {
+                const double z = (double)zt[q];
+                double g = cd[n - 1];
+                for (int k = n - 2; k >= 0; k--)
+                    g = std::fma(g, z, cd[k]);
+                good = fabsl((long double)g - gt[q]) <= tol * gmax;
+            }
+            if (good)
+                level = lv;
         }
-        if (good) {
+        for (int lv = 0; lv < 3; lv++)
+            if (level < lv && T.first_below_level[lv] == T.n_int)
+                T.first_below_level[lv] = i;
+        if (level >= 0) {
             for (int k = 0; k < n; k++)
                 T.coef[(size_t)i * n + k] = cd[k];
-            T.n_extended += ext_ok;
+            T.n_extended += level >= 1;
         } else {
             T.n_invalid++;
-            if (T.first_invalid == T.n_int)
-                T.first_invalid = i;
         }
     }
+    T.first_invalid = T.first_below_level[0];
     return T;
 }
 
 // Choose the table variable: m when that fits the front hemisphere (theta <= 90 deg) without a
 // flagged interval, otherwise whichever of m / w flags fewer intervals there.
-inline RadialTable build_radial_table(const std::vector<v1c_op>& st)
+inline RadialTable build_radial_table(const std::vector<v1c_op>& st, int n_int = kTableIntervals)
 {
     auto bad_front = [](const RadialTable& T) {
         const double u_front = T.var_is_w ? std::sqrt(0.5) : 1.0;
@@ -272,10 +274,10 @@ inline RadialTable build_radial_table(const std::vector<v1c_op>& st)
             bad += std::isnan(T.coef[(size_t)i * kRadialCoefs]);
         return bad;
     };
-    RadialTable M = fit_radial_table(st, 0);
+    RadialTable M = fit_radial_table(st, 0, n_int);
     if (bad_front(M) == 0)
         return M;
-    RadialTable W = fit_radial_table(st, 1);
+    RadialTable W = fit_radial_table(st, 1, n_int);
     return bad_front(W) < bad_front(M) ? W : M;
 }
 
@@ -339,6 +341,33 @@ inline bool ray_table_usable(const RadialTable& T)
 inline double rotated_reach(const double* rot)
 {
     return rot[8] >= 0 ? 1.0 + std::sqrt(rot[6] * rot[6] + rot[7] * rot[7]) : 2.0;
+}
+
+// true when one table entry may serve the 4 horizontally adjacent pixels of a lane
+// (kernels_tile.hip, OWN = 0): with pixel 1's entry centred at zc, |t_1 - zc| <= 0.5 and
+// |t_k - t_1| <= 2 * delta, so every pixel stays inside the validated range |z| <= 0.5 + level
+// when delta <= level / 2 -- provided every entry a pixel can select has that level.
+// delta = table units per output pixel: adjacent rays are at most `ray_step` radians apart
+// (rotations preserve angles), |d m| <= |d v| <= angle and |d w| = |d sin(theta/2)| <= angle / 2.
+inline bool ray_entry_is_shared(const RadialTable& T, double m_reach, double ray_step)
+{
+    const double delta = T.inv_step * (T.var_is_w ? 0.5 : 1.0) * ray_step;
+    const double u = (T.var_is_w ? std::sqrt(m_reach / 2) : m_reach) * (1 + 1e-9);
+    for (int lv = 1; lv <= 2; lv++)
+        if (delta <= 0.499 * lv && u * T.inv_step + 1.0 < (double)T.first_below_level[lv])
+            return true;
+    return false;
+}
+
+// table resolution for an output whose adjacent rays are `ray_step` apart: the finest of
+// 1024 / 512 / 256 intervals that keeps a lane's 4 pixels within one level-2 entry
+inline int table_intervals_for(double ray_step)
+{
+    // delta <= 0.998 with inv_step <= n / u_max; m: u_max = 1.9375 (the larger delta per interval count)
+    for (int n = kTableIntervals; n > 256; n /= 2)
+        if ((n / kTableMMax) * ray_step * 1.0 <= 0.99 && (n / std::sqrt(kTableMMax / 2)) * 0.5 * ray_step <= 0.99)
+            return n;
+    return 256;
 }
 
 // true when no pixel of an unrotated chain can land in a flagged interval
