@@ -56,11 +56,12 @@ __device__ __forceinline__ int wave_min_to_lane63(int v)
     return v;
 }
 
-__device__ __noinline__ uint32_t slow_pixel_linear3_t(const uint8_t* src, int64_t pitch, int h, int w, Geom g, float x, float y)
+// (sx, sy) = cv2's fixed-point coordinates cvRound(32 x), cvRound(32 y)
+__device__ __forceinline__ uint32_t slow_pixel_linear3_t(const uint8_t* src, int64_t pitch, int h, int w, Geom g, int sx, int sy)
 {
     uint8_t px[3] = {0, 0, 0};
     const Image im{src, pitch, h, w};
-    sample_linear<3>(im, g, x, y, px);
+    sample_linear_t<3>(im, g, taps_from_fixed(sx, sy), px);
     return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
 }
 
@@ -82,7 +83,6 @@ constexpr int kUnitsPerBlock = V1C_UPB;  // units sharing the map that one workg
 struct LaneCoords {
     int idx_lo, idx_hi;        // range of table entries of the lane's in-table pixels (k_tile_boxes)
     int sx[kPX], sy[kPX];      // cv2's fixed point: cvRound(32 x)
-    float fx[kPX], fy[kPX];    // 32 * float32(x)
     unsigned ok;               // coordinate valid (inside the radial table's domain), bit per pixel
     unsigned inside;           // ... and the whole 2x2 cell (plus 8 readable bytes) inside the source
 };
@@ -214,15 +214,15 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
     for (int k = 0; k < kPX; k++) {
         const double x32 = fma(G[k] * kx, fx_[k], cx32);
         const double y32 = ROT ? fma(G[k] * ky, fy_[k], cy32) : fma(G[k], ky, cy32);
-        L.fx[k] = (float)x32, L.fy[k] = (float)y32;  // = 32 * float32(x)
+        const float fxk = (float)x32, fyk = (float)y32;  // = 32 * float32(x)
         // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
-        const bool good = (bool)((in_table >> k) & 1) & (fabsf(L.fx[k]) < 1073741824.0f) & (fabsf(L.fy[k]) < 1073741824.0f);
+        const bool good = (bool)((in_table >> k) & 1) & (fabsf(fxk) < 1073741824.0f) & (fabsf(fyk) < 1073741824.0f);
         const bool okk = good & (k < npx);
         L.ok |= okk ? 1u << k : 0u;
         // branch-free: the conversion always sees an in-range float (NaN -> clamped by med3);
         // pixels that are not `good` are never used
-        L.sx[k] = __float2int_rn(__builtin_amdgcn_fmed3f(L.fx[k], -1073741824.0f, 1073741824.0f));
-        L.sy[k] = __float2int_rn(__builtin_amdgcn_fmed3f(L.fy[k], -1073741824.0f, 1073741824.0f));
+        L.sx[k] = __float2int_rn(__builtin_amdgcn_fmed3f(fxk, -1073741824.0f, 1073741824.0f));
+        L.sy[k] = __float2int_rn(__builtin_amdgcn_fmed3f(fyk, -1073741824.0f, 1073741824.0f));
         const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
         // whole footprint inside the source (remapBilinear / remapBicubic / remapLanczos4 inlier
         // test); the bilinear path additionally wants 8 readable bytes per row for its global-memory
@@ -589,15 +589,29 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
     // everything else that has valid coordinates: border-aware generic sampler
     const unsigned slow = L.ok & ~done;
     if (slow) {
+        if (K == 2) {
+            // one inlined copy in a rolled loop (a call would pin every live value above the 40
+            // caller-saved VGPRs)
+#pragma unroll 1
+            for (int k = 0; k < kPX; k++) {
+                if (slow & (1u << k)) {
+                    const int fsx = k == 0 ? L.sx[0] : k == 1 ? L.sx[1] : k == 2 ? L.sx[2] : L.sx[3];
+                    const int fsy = k == 0 ? L.sy[0] : k == 1 ? L.sy[1] : k == 2 ? L.sy[2] : L.sy[3];
+                    const uint32_t r = slow_pixel_linear3_t(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, fsx, fsy);
 #pragma unroll
-        for (int k = 0; k < kPX; k++)
-            if (slow & (1u << k)) {
-                if (K == 2)
-                    pix[k] = slow_pixel_linear3_t(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, L.fx[k] * 0.03125f, L.fy[k] * 0.03125f);
-                else
-                    pix[k] = slow_pixel_table3_t<K>(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, c.itab, L.fx[k] * 0.03125f,
-                                                    L.fy[k] * 0.03125f);
+                    for (int q = 0; q < kPX; q++)
+                        pix[q] = q == k ? r : pix[q];
+                }
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPX; k++)
+                if (slow & (1u << k))
+                    // (float)sx / 32 re-quantises to sx while |sx| < 2^24; beyond that the footprint is
+                    // outside the source either way (saturated short coordinates)
+                    pix[k] = slow_pixel_table3_t<K>(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, c.itab, (float)L.sx[k] * 0.03125f,
+                                                    (float)L.sy[k] * 0.03125f);
+        }
     }
     if (!t.active)
         return;

@@ -402,6 +402,22 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     return fail(V1C_E_HIP, std::string("tile boxes readback: ") + hipGetErrorString(e));
                 }
                 p->half_dwords = tile_half_dwords(hb.data(), hb.size() / 32);
+                if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1') {
+                    // histogram of the LDS dwords each tile box needs
+                    const int* bi = (const int*)hb.data();
+                    const size_t nt = hb.size() / 32;
+                    int hist[12] = {0};
+                    for (size_t i = 0; i < nt; i++) {
+                        const int cpr = bi[i * 8 + 2], nrows = bi[i * 8 + 3];
+                        const int need = cpr > 0 ? nrows * (cpr * 4 + 4) : 0;  // = kernels_tile.hip LDS row pitch
+                        int k = 0;
+                        while (k < 11 && need > (512 << k) / 2)
+                            k++;
+                        hist[k]++;
+                    }
+                    std::fprintf(stderr, "[v1c] tile boxes: %zu tiles, half_dwords=%d; need<=256:%d <=512:%d <=1k:%d <=2k:%d <=4k:%d <=8k:%d <=16k:%d more:%d\n",
+                                 nt, p->half_dwords, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7] + hist[8] + hist[9] + hist[10] + hist[11]);
+                }
             }
         }
     }

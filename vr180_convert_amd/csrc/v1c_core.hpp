@@ -356,6 +356,17 @@ struct Taps {
     int fx, fy;  // 1/32 fractions
 };
 
+// from cv2's fixed-point coordinates sx = cvRound(x*32), sy = cvRound(y*32)
+V1C_HDF Taps taps_from_fixed(int sx, int sy)
+{
+    Taps t;
+    t.ix = clamp_short(sx >> 5);
+    t.iy = clamp_short(sy >> 5);
+    t.fx = sx & 31;
+    t.fy = sy & 31;
+    return t;
+}
+
 V1C_HDF Taps quantize(float x, float y)
 {
     // RemapInvoker, planar float maps: sx = cvRound(x*32); ix = sat<short>(sx >> 5); fx = sx & 31
@@ -419,9 +430,8 @@ V1C_HD bool sample_nearest(const Image& s, const Geom& g, float x, float y, uint
 // + fix-up turns into {32767, 0, 0, 1}; for uint8 pixels both give (sum + 2^14) >> 15 == p00, so
 // the two-step lerp below ((h0*(32-fy) + h1*fy + 512) >> 10) is bit-identical.
 template <int CN>
-V1C_HD bool sample_linear(const Image& s, const Geom& g, float x, float y, uint8_t* out)
+V1C_HD bool sample_linear_t(const Image& s, const Geom& g, const Taps t, uint8_t* out)
 {
-    const Taps t = quantize(x, y);
     const int wx1 = t.fx, wx0 = 32 - t.fx, wy1 = t.fy, wy0 = 32 - t.fy;
     if (CN == 3 && (unsigned)t.ix < (unsigned)(s.w - 2) && (unsigned)t.iy < (unsigned)(s.h - 1)) {
         // whole 2x2 cell inside and 8 readable bytes per row: two unaligned 8-byte loads
@@ -472,6 +482,12 @@ V1C_HD bool sample_linear(const Image& s, const Geom& g, float x, float y, uint8
         out[k] = (uint8_t)((h0 * wy0 + h1 * wy1 + 512) >> 10);
     }
     return true;
+}
+
+template <int CN>
+V1C_HD bool sample_linear(const Image& s, const Geom& g, float x, float y, uint8_t* out)
+{
+    return sample_linear_t<CN>(s, g, quantize(x, y), out);
 }
 
 // CUBIC (K = 4) / LANCZOS4 (K = 8): remapBicubic / remapLanczos4 with the int16 table built by
