@@ -532,61 +532,37 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     }
 }
 
-// ---- taps, blend, slow-path patch and store: shared tail of the kernels ----
-// `wtab` = OpenCV's int16 weight table for K = 4 / 8 (global memory, or LDS in the persistent kernel)
-template <int K, typename WPtr>
-__device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
-                                                 const TileBox& b, bool use_lds, const uint32_t* boxw, WPtr wtab,
-                                                 const uint8_t* __restrict__ src, uint32_t spitch)
+// ---- the 2x2 taps of a lane's 4 pixels from a staged BGRx box (bilinear) ----
+struct Taps2 {
+    uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
+};
+
+__device__ __forceinline__ void read_taps_lds(const LaneCoords& L, const TileBox& b, const uint32_t* boxw, Taps2& T)
+{
+    const int lpw = b.cpr * 4 + 4;
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+        const bool in = (L.inside >> k) & 1;
+        const uint32_t lo = in ? __umul24(iy - b.y0, lpw) + (uint32_t)(ix - b.x0) : 0u;
+        T.alo[k] = boxw[lo], T.ahi[k] = boxw[lo + 1];
+        T.blo[k] = boxw[lo + lpw], T.bhi[k] = boxw[lo + lpw + 1];
+    }
+}
+
+__device__ __forceinline__ void blend_taps(const Taps2& T, const LaneCoords& L, uint32_t (&pix)[kPX])
+{
+#pragma unroll
+    for (int k = 0; k < kPX; k++)
+        pix[k] = blend3<4>(T.alo[k], T.ahi[k], T.blo[k], T.bhi[k], L.sx[k], L.sy[k]);
+}
+
+// ---- slow-path patch (pixels with valid coordinates the tiled path did not produce) and store ----
+template <int K>
+__device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
+                                                uint32_t (&pix)[kPX], unsigned done, const uint8_t* __restrict__ src)
 {
     const Geom& g = c.g;
-    uint32_t pix[kPX];
-    unsigned done = 0;  // pixels produced by the tiled path
-    if (use_lds) {
-        const int lpw = b.cpr * 4 + 4;
-        if (K == 2) {
-            uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
-#pragma unroll
-            for (int k = 0; k < kPX; k++) {
-                const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-                const bool in = (L.inside >> k) & 1;
-                const uint32_t lo = in ? __umul24(iy - b.y0, lpw) + (uint32_t)(ix - b.x0) : 0u;
-                alo[k] = boxw[lo], ahi[k] = boxw[lo + 1];
-                blo[k] = boxw[lo + lpw], bhi[k] = boxw[lo + lpw + 1];
-            }
-#pragma unroll
-            for (int k = 0; k < kPX; k++)
-                pix[k] = blend3<4>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
-        } else {
-            constexpr int off = K / 2 - 1;
-#pragma unroll
-            for (int k = 0; k < kPX; k++) {
-                const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-                const bool in = (L.inside >> k) & 1;
-                const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
-                const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
-                pix[k] = blend_table<K>((lds_u32_ptr)boxw, lo, lpw, wtab + a * (K * K / 2));
-            }
-        }
-        done = L.inside;
-    } else if (K == 2) {
-        uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
-#pragma unroll
-        for (int k = 0; k < kPX; k++) {
-            const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-            const bool in = (L.inside >> k) & 1;
-            const uint32_t off = in ? __umul24(iy, spitch) + (uint32_t)(ix * 3) : 0u;
-            const u64pair a = load_u64_unaligned(src + off);
-            const u64pair bq = load_u64_unaligned(src + off + spitch);
-            alo[k] = a.lo, ahi[k] = a.hi, blo[k] = bq.lo, bhi[k] = bq.hi;
-        }
-#pragma unroll
-        for (int k = 0; k < kPX; k++)
-            pix[k] = blend3<3>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
-        done = L.inside;
-    }
-
-    // everything else that has valid coordinates: border-aware generic sampler
     const unsigned slow = L.ok & ~done;
     if (slow) {
         if (K == 2) {
@@ -616,6 +592,54 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
     if (!t.active)
         return;
     store4(ua.u[z].dst + (int64_t)t.j * ua.u[z].dst_pitch + (int64_t)t.x0 * 3, pix, L.ok);
+}
+
+// ---- taps, blend, slow-path patch and store: shared tail of the kernels ----
+// `wtab` = OpenCV's int16 weight table for K = 4 / 8 (global memory, or LDS in the persistent kernel)
+template <int K, typename WPtr>
+__device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
+                                                 const TileBox& b, bool use_lds, const uint32_t* boxw, WPtr wtab,
+                                                 const uint8_t* __restrict__ src, uint32_t spitch)
+{
+    const Geom& g = c.g;
+    uint32_t pix[kPX];
+    unsigned done = 0;  // pixels produced by the tiled path
+    if (use_lds) {
+        const int lpw = b.cpr * 4 + 4;
+        if (K == 2) {
+            Taps2 T;
+            read_taps_lds(L, b, boxw, T);
+            blend_taps(T, L, pix);
+        } else {
+            constexpr int off = K / 2 - 1;
+#pragma unroll
+            for (int k = 0; k < kPX; k++) {
+                const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+                const bool in = (L.inside >> k) & 1;
+                const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
+                const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
+                pix[k] = blend_table<K>((lds_u32_ptr)boxw, lo, lpw, wtab + a * (K * K / 2));
+            }
+        }
+        done = L.inside;
+    } else if (K == 2) {
+        uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+            const bool in = (L.inside >> k) & 1;
+            const uint32_t off = in ? __umul24(iy, spitch) + (uint32_t)(ix * 3) : 0u;
+            const u64pair a = load_u64_unaligned(src + off);
+            const u64pair bq = load_u64_unaligned(src + off + spitch);
+            alo[k] = a.lo, ahi[k] = a.hi, blo[k] = bq.lo, bhi[k] = bq.hi;
+        }
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            pix[k] = blend3<3>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
+        done = L.inside;
+    }
+
+    patch_and_store<K>(c, ua, z, t, L, pix, done, src);
 }
 
 // ---- one tile for up to `upb` units that share the map (plan-time boxes) ----
@@ -709,6 +733,31 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     // (into S0) while unit v-2 is sampled, its LDS store happens at the top of iteration v-1 behind
     // the barrier that also tells everyone is done with unit v-2, and the barrier at the top of
     // iteration v makes it visible: one barrier per unit, none at all for a pair.
+    if (nu <= 2) {
+        // a pair (apply_lr: the two eyes): both boxes are already visible, no further barrier --
+        // straight-line code lets the second unit's LDS reads overlap the first unit's blend
+        if (incomplete) {
+            c.tile_flags[t.flag_tile] = 1;
+            if (nu == 2)
+                c.tile_flags[t.flag_tile + t.flag_stride] = 1;
+        }
+        if (K == 2 && nu == 2 && fit0 && fit1) {
+            // taps of both eyes first: the second eye's LDS latency hides behind the first eye's blend
+            Taps2 T0, T1;
+            read_taps_lds(L, b, boxw, T0);
+            read_taps_lds(L, b, boxw + half_dwords, T1);
+            uint32_t pix[kPX];
+            blend_taps(T0, L, pix);
+            patch_and_store<K>(c, ua, z0, t, L, pix, L.inside, ua.u[z0].src);
+            blend_taps(T1, L, pix);
+            patch_and_store<K>(c, ua, z0 + 1, t, L, pix, L.inside, ua.u[z0 + 1].src);
+            return;
+        }
+        sample_and_store<K>(c, ua, z0, t, L, b, fit0, boxw, wtab, ua.u[z0].src, (uint32_t)ua.u[z0].src_pitch);
+        if (nu == 2)
+            sample_and_store<K>(c, ua, z0 + 1, t, L, b, fit1, boxw + half_dwords, wtab, ua.u[z0 + 1].src, (uint32_t)ua.u[z0 + 1].src_pitch);
+        return;
+    }
     bool fit_cur = fit0, fit_nxt = fit1, fit_s = false;
     for (int u = 0; u < nu; u++) {
         const int z = z0 + u;
