@@ -246,17 +246,20 @@ def main() -> None:
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Two events on the launch stream bracket the K steps: (e1 - e0) / K is the average GPU time of
+    # a step's launch(es) including the gaps between them.  (An event pair around every step would
+    # add two packets per launch and, whenever the host is the slower side, measure host latency.)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()
+    e0.record()
+    for _ in range(args.steps):
         step()
-        e1.record()
+    e1.record()
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = allreduce_max(elapsed, dev)
-    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+    kernel_ms = e0.elapsed_time(e1) / args.steps
     kernel_ms_max = allreduce_max(kernel_ms, dev)
 
     units = 2 * max(frames, 1)

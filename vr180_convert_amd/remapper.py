@@ -183,6 +183,26 @@ def _host_map(transformer: TransformerBase, *, radius, size_input, size_output):
     return xmap.astype(np.float32), ymap.astype(np.float32)
 
 
+_LOWERED: "OrderedDict[tuple, _abi.Chain]" = OrderedDict()
+
+
+def _lower_cached(t: TransformerBase, *, radius, size_input, size_output) -> _abi.Chain:
+    """``lower_for_get_map`` memoised on the chain's dataclass repr (its full parameter set): a
+    steady stream of identical calls -- frames of a video, bench steps -- lowers once.  Reprs that
+    may be abbreviated (large arrays) or are not parameter-complete (no dataclass repr) are not cached."""
+    r = repr(t)
+    if len(r) > 4096 or "..." in r or " object at 0x" in r:
+        return lower_for_get_map(t, radius=radius, size_input=size_input, size_output=size_output)
+    key = (r, float(radius), tuple(size_input), tuple(size_output))
+    ch = _LOWERED.get(key)
+    if ch is None:
+        ch = lower_for_get_map(t, radius=radius, size_input=size_input, size_output=size_output)
+        _LOWERED[key] = ch
+        while len(_LOWERED) > 64:
+            _LOWERED.popitem(last=False)
+    return ch
+
+
 def remap_tensors(
     transformer: TransformerBase | Sequence[TransformerBase],
     srcs: Sequence[torch.Tensor],
@@ -223,7 +243,7 @@ def remap_tensors(
     for k, t in enumerate(per_unit):
         if id(t) not in lowered:
             try:
-                lowered[id(t)] = lower_for_get_map(t, radius=radius, size_input=size_input, size_output=dst_wh)
+                lowered[id(t)] = _lower_cached(t, radius=radius, size_input=size_input, size_output=dst_wh)
             except NotLowerable as e:
                 LOG.warning("transformer chain is not lowerable (%s): map evaluated by its own NumPy transform()", e)
                 lowered[id(t)] = None
