@@ -21,6 +21,7 @@
 // memory; pixels with taps outside the source go through the generic border-aware sampler;
 // pixels outside the radial table's domain are left to the fix-up launch (kernels.hip MODE_FIXUP).
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.hpp"
 
@@ -663,7 +664,9 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
 #define V1C_STAMP(i)
 #endif
 
-template <int VAR_W, int ROT, int K, int OWN, int NT, typename WPtr>
+// PAIR = 1: the launch has at most 2 units per workgroup (apply_lr's two eyes): only the
+// straight-line path is compiled, which needs ~30 fewer VGPRs (6 waves per SIMD instead of 4).
+template <int VAR_W, int ROT, int K, int OWN, int PAIR, int NT, typename WPtr>
 __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitArgs& ua, const TileBox* __restrict__ boxes, int n_units,
                                                 int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw, int half_dwords,
                                                 double* tabw, WPtr wtab)
@@ -733,7 +736,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     // (into S0) while unit v-2 is sampled, its LDS store happens at the top of iteration v-1 behind
     // the barrier that also tells everyone is done with unit v-2, and the barrier at the top of
     // iteration v makes it visible: one barrier per unit, none at all for a pair.
-    if (nu <= 2) {
+    if (PAIR || nu <= 2) {
         // a pair (apply_lr: the two eyes): both boxes are already visible, no further barrier --
         // straight-line code lets the second unit's LDS reads overlap the first unit's blend
         if (incomplete) {
@@ -758,6 +761,8 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
             sample_and_store<K>(c, ua, z0 + 1, t, L, b, fit1, boxw + half_dwords, wtab, ua.u[z0 + 1].src, (uint32_t)ua.u[z0 + 1].src_pitch);
         return;
     }
+    if (PAIR)
+        return;
     bool fit_cur = fit0, fit_nxt = fit1, fit_s = false;
     for (int u = 0; u < nu; u++) {
         const int z = z0 + u;
@@ -781,7 +786,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
 // BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes, coordinates shared by `upb` units.
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
-template <int VAR_W, int ROT, int BOXES, int K, int OWN>
+template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR>
 __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                        int upb, int half_dwords)
 {
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
     if (BOXES) {
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
         extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-        shared_map_tile<VAR_W, ROT, K, OWN, NT>(c, ua, boxes, n_units, upb, blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, dyn_box,
+        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT>(c, ua, boxes, n_units, upb, blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, dyn_box,
                                            half_dwords, tabw, wtab);
     } else {
         __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
@@ -906,11 +911,24 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
                           bool shared_entry, hipStream_t stream)
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
-    const int upb = bx ? std::min(n_units, kUnitsPerBlock) : 1;
+    static const int upb_max = [] {  // V1C_UPB=<n>: A/B override of the units per workgroup
+        const char* e = std::getenv("V1C_UPB");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 1 && v <= kUnitsPerBlock ? v : kUnitsPerBlock;
+    }();
+    const int upb = bx ? std::min(n_units, upb_max) : 1;
+    const bool pair = bx && upb <= 2;
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
     const size_t lds = bx ? (size_t)half_dwords * 8 + 16 : 0;  // two box buffers
-#define V1C_TILE_O(VW, RT, BX, OW) \
-    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords)
+#define V1C_TILE_P(VW, RT, BX, OW, PR) \
+    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords)
+#define V1C_TILE_O(VW, RT, BX, OW)          \
+    do {                                    \
+        if (BX && pair)                     \
+            V1C_TILE_P(VW, RT, BX, OW, BX); \
+        else                                \
+            V1C_TILE_P(VW, RT, BX, OW, 0);  \
+    } while (0)
 #define V1C_TILE(VW, RT)                \
     do {                                \
         if (bx && shared_entry)         \
@@ -935,6 +953,7 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     }
 #undef V1C_TILE
 #undef V1C_TILE_O
+#undef V1C_TILE_P
 }
 
 // `boxes` may be null (the units override the rotation): then boxes are reduced in-kernel.
