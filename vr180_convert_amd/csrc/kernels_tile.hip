@@ -360,21 +360,37 @@ __device__ __forceinline__ void stage_store(const ChunkMap& M, const Staged& S, 
 }
 
 // ---- bilinear blend of one pixel from its two tap pairs; SEL_HI = byte index of px1 ----
-template <int SEL_HI>
-__device__ __forceinline__ uint32_t blend3(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, int sx, int sy)
+// (sum_ij p_ij * wx_i * wy_j + 512) >> 10 with the four 10-bit products as two u16 pairs: per
+// channel 2 x v_perm_b32 (tap pair -> two zero-extended u16) + 2 x v_dot2_u32_u16.  Identical to
+// the two-step lerp of sample_linear (v1c_core.hpp): the same integers are summed, nothing overflows.
+typedef unsigned short __attribute__((ext_vector_type(2))) ushort2v;
+
+struct BlendW {
+    uint32_t wa, wb;  // (wx0 * wy0, wx1 * wy0) and (wx0 * wy1, wx1 * wy1) as u16 pairs
+};
+
+__device__ __forceinline__ BlendW blend_weights(int sx, int sy)
 {
     const uint32_t fq = sx & 31, fr = sy & 31;
-    const uint32_t wxp = (32u - fq) | (fq << 8);  // bytes (wx0, wx1, 0, 0)
-    const uint32_t wy0 = 32u - fr, wy1 = fr;
+    const uint32_t wxp = (32u - fq) | (fq << 16);  // u16 pair (wx0, wx1); products stay below 2^16
+    BlendW w;
+    w.wa = __umul24(wxp, 32u - fr);
+    w.wb = __umul24(wxp, fr);
+    return w;
+}
+
+template <int SEL_HI>
+__device__ __forceinline__ uint32_t blend3(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, const BlendW w)
+{
     uint32_t o = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        // bytes (p0c, p1c, 0, 0) of the pixel pair
-        constexpr uint32_t base = 0x0c0c0000u | ((uint32_t)SEL_HI << 8);
-        const uint32_t sel = base + (uint32_t)ch * 0x0101u;
-        const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(ahi, alo, sel), wxp, 0u, false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(bhi, blo, sel), wxp, 0u, false);
-        const uint32_t v = __umul24(h1, wy1) + (__umul24(h0, wy0) + 512u);
+        // bytes (p0c, 0, p1c, 0) of the pixel pair
+        constexpr uint32_t base = 0x0c000c00u | ((uint32_t)SEL_HI << 16);
+        const uint32_t sel = base + (uint32_t)ch * 0x00010001u;
+        const uint32_t pa = __builtin_amdgcn_perm(ahi, alo, sel), pb = __builtin_amdgcn_perm(bhi, blo, sel);
+        uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pa), __builtin_bit_cast(ushort2v, w.wa), 512u, false);
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pb), __builtin_bit_cast(ushort2v, w.wb), v, false);
         o |= (v >> 10) << (8 * ch);
     }
     return o;
@@ -555,7 +571,7 @@ __device__ __forceinline__ void blend_taps(const Taps2& T, const LaneCoords& L, 
 {
 #pragma unroll
     for (int k = 0; k < kPX; k++)
-        pix[k] = blend3<4>(T.alo[k], T.ahi[k], T.blo[k], T.bhi[k], L.sx[k], L.sy[k]);
+        pix[k] = blend3<4>(T.alo[k], T.ahi[k], T.blo[k], T.bhi[k], blend_weights(L.sx[k], L.sy[k]));
 }
 
 // ---- slow-path patch (pixels with valid coordinates the tiled path did not produce) and store ----
@@ -636,7 +652,7 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
         }
 #pragma unroll
         for (int k = 0; k < kPX; k++)
-            pix[k] = blend3<3>(alo[k], ahi[k], blo[k], bhi[k], L.sx[k], L.sy[k]);
+            pix[k] = blend3<3>(alo[k], ahi[k], blo[k], bhi[k], blend_weights(L.sx[k], L.sy[k]));
         done = L.inside;
     }
 
