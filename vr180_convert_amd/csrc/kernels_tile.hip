@@ -75,7 +75,9 @@ struct u128 {
 // idx0 / nidx: range of radial-table entries the tile's in-table pixels use (nidx == 0: unknown)
 struct TileBox {
     int x0, y0, cpr, nrows;
-    int idx0, nidx, pad0, pad1;
+    int idx0, nidx;
+    int interior;  // 1: every pixel of the tile has valid coordinates and its whole footprint inside the source
+    int pad1;
 };
 
 constexpr int kTabSlice = 64;  // radial-table entries a workgroup may keep in LDS (4 KB)
@@ -109,7 +111,9 @@ __device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, 
 // `tab` = radial table (global memory, or the tile's slice in LDS starting at entry `tab0`).
 // OWN = 0: the plan proved that pixel 1's entry is valid for all 4 pixels of every lane
 // (plan.hip: shared_entry), so the per-pixel fallback is not compiled in.
-template <int VAR_W, int ROT, int K, int OWN, typename TabPtr>
+// INTERIOR = 1: the plan found every pixel of this tile valid and inside (TileBox::interior, same
+// arithmetic): the validity / inside tests are skipped.
+template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, typename TabPtr>
 __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, const RowCol& rc, int npx, TabPtr tab,
                                             int tab0, int tabn, LaneCoords& L)
 {
@@ -204,7 +208,7 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
         }
     }
 
-    L.ok = 0, L.inside = 0;
+    L.ok = INTERIOR ? 0xFu : 0u, L.inside = INTERIOR ? 0xFu : 0u;
     L.idx_lo = 0x7fffffff, L.idx_hi = -0x7fffffff;
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
@@ -216,6 +220,10 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
         const double x32 = fma(G[k] * kx, fx_[k], cx32);
         const double y32 = ROT ? fma(G[k] * ky, fy_[k], cy32) : fma(G[k], ky, cy32);
         const float fxk = (float)x32, fyk = (float)y32;  // = 32 * float32(x)
+        if (INTERIOR) {
+            L.sx[k] = __float2int_rn(fxk), L.sy[k] = __float2int_rn(fyk);
+            continue;
+        }
         // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
         const bool good = (bool)((in_table >> k) & 1) & (fabsf(fxk) < 1073741824.0f) & (fabsf(fyk) < 1073741824.0f);
         const bool okk = good & (k < npx);
@@ -531,8 +539,9 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, t.jc, rc);
     LaneCoords L;
-    lane_coords<VAR_W, ROT, K, 1>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
+    lane_coords<VAR_W, ROT, K, 1, 0>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
     TileBox b = reduce_box<K, NW>(L, red, tid);
+    const int interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L.ok == 0xFu) & (L.inside == 0xFu)));
     const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
     if ((tid & 63) == 63)
         red2[(tid >> 6) * 2] = lo, red2[(tid >> 6) * 2 + 1] = nhi;
@@ -544,7 +553,8 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
         const int i1 = -n1;
         b.idx0 = i0 <= i1 ? i0 : 0;
         b.nidx = i0 <= i1 ? i1 - i0 + 1 : 0;
-        b.pad0 = b.pad1 = 0;
+        b.interior = interior;
+        b.pad1 = 0;
         boxes[t.box_tile] = b;
     }
 }
@@ -554,13 +564,14 @@ struct Taps2 {
     uint32_t alo[kPX], ahi[kPX], blo[kPX], bhi[kPX];
 };
 
+template <bool ALL_IN = false>
 __device__ __forceinline__ void read_taps_lds(const LaneCoords& L, const TileBox& b, const uint32_t* boxw, Taps2& T)
 {
     const int lpw = b.cpr * 4 + 4;
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
         const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-        const bool in = (L.inside >> k) & 1;
+        const bool in = ALL_IN || ((L.inside >> k) & 1);
         const uint32_t lo = in ? __umul24(iy - b.y0, lpw) + (uint32_t)(ix - b.x0) : 0u;
         T.alo[k] = boxw[lo], T.ahi[k] = boxw[lo + 1];
         T.blo[k] = boxw[lo + lpw], T.bhi[k] = boxw[lo + lpw + 1];
@@ -741,10 +752,13 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     __syncthreads();
     V1C_STAMP(2);  // barrier
     LaneCoords L;
-    if (tab_lds)
-        lane_coords<VAR_W, ROT, K, OWN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+    const bool interior = tab_lds & (b.interior != 0);  // wave-uniform: no validity / inside tests needed
+    if (interior)
+        lane_coords<VAR_W, ROT, K, OWN, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+    else if (tab_lds)
+        lane_coords<VAR_W, ROT, K, OWN, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else
-        lane_coords<VAR_W, ROT, K, OWN>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
     const bool incomplete = L.ok != (1u << t.npx) - 1;
     V1C_STAMP(3);  // coordinates
 
@@ -763,8 +777,13 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         if (K == 2 && nu == 2 && fit0 && fit1) {
             // taps of both eyes first: the second eye's LDS latency hides behind the first eye's blend
             Taps2 T0, T1;
-            read_taps_lds(L, b, boxw, T0);
-            read_taps_lds(L, b, boxw + half_dwords, T1);
+            if (interior) {
+                read_taps_lds<true>(L, b, boxw, T0);
+                read_taps_lds<true>(L, b, boxw + half_dwords, T1);
+            } else {
+                read_taps_lds(L, b, boxw, T0);
+                read_taps_lds(L, b, boxw + half_dwords, T1);
+            }
             uint32_t pix[kPX];
             blend_taps(T0, L, pix);
             patch_and_store<K>(c, ua, z0, t, L, pix, L.inside, ua.u[z0].src);
@@ -828,7 +847,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         RowCol rc;
         load_rowcol<ROT>(P, t.xc, t.jc, rc);
         LaneCoords L;
-        lane_coords<VAR_W, ROT, K, OWN>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
         const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
         const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
         if (use_lds) {
