@@ -200,6 +200,15 @@ int v1c_remap_lut(int device, void* stream,
 int v1c_get_radius(int device, void* stream, const uint8_t* img, int h, int w,
                    int64_t pitch, int cn, int threshold, double* radius);
 
+/* merge=True of apply_lr(), remapper.py:485-497: red/cyan anaglyph of two remapped eyes, both
+ * (h, w, 3) uint8 on the device; `out` is (h, w, 3) float64 with row pitch out_pitch BYTES:
+ *   out[c] = (mean_L * colL[c] + mean_R * colR[c]) / 255,  colL = (0,128,255), colR = (255,128,0),
+ *   mean = float64 mean of the 3 channels -- the reference's NumPy float64 expression, operation
+ * by operation (no FMA contraction).  The cv.putText labels (:498-516) stay with the caller.   */
+int v1c_anaglyph(int device, void* stream,
+                 const uint8_t* left, int64_t left_pitch, const uint8_t* right, int64_t right_pitch,
+                 int h, int w, double* out, int64_t out_pitch);
+
 /* The int16 fixed-point weight table the engine uses for INTER_CUBIC (1024*4*4 entries) or
  * INTER_LANCZOS4 (1024*8*8 entries), laid out [fy*32+fx][ky][kx]: OpenCV's initInterTab2D
  * (SURVEY.md Appendix A item 3).  Host-only (no device needed); `out` is a HOST buffer.

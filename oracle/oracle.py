@@ -275,3 +275,15 @@ def apply_lr(spec, left: np.ndarray, right: np.ndarray, **kw) -> np.ndarray:
     else:
         ims = apply(spec, [left, right], **kw)
     return np.concatenate(ims, axis=1)
+
+
+def anaglyph(left: np.ndarray, right: np.ndarray) -> np.ndarray:
+    """``merge=True`` of apply_lr, reference remapper.py:485-497, as the NumPy expression the
+    reference evaluates (float64): per-eye channel mean times a colour, summed, / 255.  The
+    cv.putText labels (:498-516) are not part of it."""
+    colors = [(0, 128, 255), (255, 128, 0)]
+    combine = np.mean(left, axis=-1)[..., None] * np.array(colors[0]).reshape([1] * (left.ndim - 1) + [3]) + (
+        np.mean(right, axis=-1)[..., None] * np.array(colors[1]).reshape([1] * (right.ndim - 1) + [3])
+    )
+    combine /= 255
+    return combine

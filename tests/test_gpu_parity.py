@@ -255,6 +255,37 @@ def test_apply_lr_files_auto_radius_and_tuple(V, oracle_mod, tmp_path):
         get_radius_smart("auto", [torch.full((64, 80, 3), 90, dtype=torch.uint8, device="cuda")])
 
 
+def test_anaglyph_merge_bit_exact(V, oracle_mod, dev, tmp_path):
+    """apply_lr(merge=True), remapper.py:485-497: the device anaglyph equals the reference's NumPy
+    float64 expression bit for bit (same operations, no contraction), also on pitched SBS halves."""
+    rng = np.random.default_rng(7)
+    for h, w in ((1, 1), (37, 53), (128, 300)):
+        sbs = torch.from_numpy(rng.integers(0, 256, (h, 2 * w, 3), dtype=np.uint8)).to(dev)
+        got = V.anaglyph_tensors(sbs[:, :w], sbs[:, w:])
+        assert got.dtype == torch.float64 and tuple(got.shape) == (h, w, 3)
+        host = sbs.cpu().numpy()
+        want = oracle_mod.anaglyph(host[:, :w], host[:, w:])
+        assert np.array_equal(got.cpu().numpy(), want)
+    # extremes: all-white eyes give exactly (255, 256, 255) / ... as NumPy does
+    white = torch.full((4, 4, 3), 255, dtype=torch.uint8, device=dev)
+    assert np.array_equal(V.anaglyph_tensors(white, white).cpu().numpy(), oracle_mod.anaglyph(white.cpu().numpy(), white.cpu().numpy()))
+    with pytest.raises(ValueError):
+        V.anaglyph_tensors(white, white[:2])
+    # through apply_lr: the merged picture written to disk is the anaglyph of the remapped halves
+    from vr180_convert_amd import _io
+    from vr180_convert_amd.synth import pattern
+
+    img = pattern(160, 160)
+    spec = [("equirect_enc", True), CS.EQUI]
+    out_p = tmp_path / "merged.png"
+    V.apply_lr(CS.to_product(spec), left_path=img, right_path=np.ascontiguousarray(img[:, ::-1]), out_path=out_p,
+               size_output=(96, 96), interpolation=1, radius="max", merge=True)
+    halves = oracle_mod.apply_lr(spec, img, np.ascontiguousarray(img[:, ::-1]), size_output=(96, 96), interpolation=1, radius="max")
+    want = oracle_mod.anaglyph(halves[:, :96], halves[:, 96:])
+    if _io._cv is None:  # no labels without cv2: the file holds the rounded anaglyph itself
+        assert np.array_equal(_io.imread(out_p), np.clip(np.rint(want), 0, 255).astype(np.uint8))
+
+
 def test_user_defined_transformer_takes_lut_path(V, oracle_mod, dev):
     """README.md:204-219: any TransformerBase subclass must work; its map comes from its own
     transform(), the gather runs on the GPU (v1c_remap_lut)."""

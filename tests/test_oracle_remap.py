@@ -122,3 +122,14 @@ def test_known_answer_reference_docs_pair(oracle_mod, golden_dir):
                   size_output=(2048, 2048), interpolation=O.INTER_LINEAR, radius="max")[0]
     d = bad.astype(np.float64) - ref[:, :2048]
     assert 10 * np.log10(255.0**2 / np.mean(d * d)) < 20.0
+
+
+def test_anaglyph_known_values(oracle_mod):
+    """apply_lr(merge=True), remapper.py:485-497: mean over channels x colour per eye, / 255."""
+    O = oracle_mod
+    left = np.array([[[30, 60, 90], [255, 255, 255]]], np.uint8)   # means 60, 255
+    right = np.array([[[0, 0, 0], [255, 255, 255]]], np.uint8)    # means 0, 255
+    out = O.anaglyph(left, right)
+    assert out.dtype == np.float64 and out.shape == (1, 2, 3)
+    assert np.array_equal(out[0, 0], np.array([0.0, 60 * 128 / 255, 60.0]))
+    assert np.array_equal(out[0, 1], np.array([255.0, (255.0 * 128 + 255.0 * 128) / 255, 255.0]))

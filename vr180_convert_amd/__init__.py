@@ -15,7 +15,7 @@ from .chain import (
     TransformerBase,
     ZoomTransformer,
 )
-from .remapper import apply, apply_lr, apply_lr_tensors, get_map, remap_tensors
+from .remapper import anaglyph_tensors, apply, apply_lr, apply_lr_tensors, get_map, remap_tensors
 
 __all__ = [
     "TransformerBase",
@@ -34,5 +34,6 @@ __all__ = [
     "get_map",
     # additions of this engine (device-resident entry points)
     "apply_lr_tensors",
+    "anaglyph_tensors",
     "remap_tensors",
 ]

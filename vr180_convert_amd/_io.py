@@ -42,15 +42,11 @@ def imwrite(path: Any, image: np.ndarray) -> bool:
     return True
 
 
-def anaglyph(left: np.ndarray, right: np.ndarray) -> np.ndarray:
-    """``merge=True`` of apply_lr (reference remapper.py:485-516): per-eye channel mean times a
-    colour, summed, / 255.  The "L" / "R" labels need cv2.putText and are drawn only when cv2 is
-    importable."""
+def draw_anaglyph_labels(combine: np.ndarray) -> np.ndarray:
+    """The "L" / "R" labels of apply_lr(merge=True) (reference remapper.py:498-516): they need
+    cv2.putText and are drawn only when cv2 is importable.  The anaglyph itself is computed on the
+    device (remapper.anaglyph_tensors)."""
     colors = [(0, 128, 255), (255, 128, 0)]
-    combine = np.mean(left, axis=-1)[..., None] * np.array(colors[0]).reshape(1, 1, 3) + (
-        np.mean(right, axis=-1)[..., None] * np.array(colors[1]).reshape(1, 1, 3)
-    )
-    combine /= 255
     if _cv is not None:  # pragma: no cover
         _cv.putText(combine, "L", (0, len(combine[1]) // 10), _cv.FONT_HERSHEY_SIMPLEX, len(combine) // 1000, colors[0], 2, _cv.LINE_AA)
         _cv.putText(combine, "R", (len(combine[1]) // 2, len(combine[0]) // 10), _cv.FONT_HERSHEY_SIMPLEX, len(combine) // 1000, colors[1], 2, _cv.LINE_AA)

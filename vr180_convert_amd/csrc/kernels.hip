@@ -287,4 +287,38 @@ hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float
     return hipGetLastError();
 }
 
+// ---- anaglyph merge (remapper.py:485-497) ----
+// One thread per pixel: 3 + 3 bytes in, 3 doubles (24 B, 8-byte aligned) out.  The arithmetic is
+// the reference's NumPy float64 expression, operation by operation; contraction stays off so that
+// mean * colour + mean * colour is two roundings of the products and one of the sum.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void k_anaglyph(const uint8_t* __restrict__ left, int64_t lp, const uint8_t* __restrict__ right,
+                                                  int64_t rp, int h, int w, double* __restrict__ out, int64_t op)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h)
+        return;
+    const uint8_t* l = left + (int64_t)y * lp + (int64_t)x * 3;
+    const uint8_t* r = right + (int64_t)y * rp + (int64_t)x * 3;
+    // np.mean(img, axis=-1): float64 sum of the three uint8 channels (exact) divided by 3
+    const double ml = (double)((int)l[0] + (int)l[1] + (int)l[2]) / 3.0;
+    const double mr = (double)((int)r[0] + (int)r[1] + (int)r[2]) / 3.0;
+    double* o = (double*)((char*)out + (int64_t)y * op) + (int64_t)x * 3;
+    const double cl[3] = {0.0, 128.0, 255.0}, cr[3] = {255.0, 128.0, 0.0};  // colors[0], colors[1] (:489)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double a = ml * cl[c], b = mr * cr[c];
+        o[c] = (a + b) / 255.0;  // combine /= 255 (:497)
+    }
+}
+#pragma clang fp contract(fast)
+
+hipError_t launch_anaglyph(const uint8_t* left, int64_t left_pitch, const uint8_t* right, int64_t right_pitch, int h, int w,
+                           double* out, int64_t out_pitch, hipStream_t stream)
+{
+    const dim3 block(256, 1, 1), grid((w + 255) / 256, h, 1);
+    hipLaunchKernelGGL(k_anaglyph, grid, block, 0, stream, left, left_pitch, right, right_pitch, h, w, out, out_pitch);
+    return hipGetLastError();
+}
+
 }  // namespace v1c

@@ -36,4 +36,8 @@ int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 bool shared_entry, hipStream_t stream);
 
+// merge=True of apply_lr (remapper.py:485-497)
+hipError_t launch_anaglyph(const uint8_t* left, int64_t left_pitch, const uint8_t* right, int64_t right_pitch, int h, int w,
+                           double* out, int64_t out_pitch, hipStream_t stream);
+
 }  // namespace v1c

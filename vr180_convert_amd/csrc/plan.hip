@@ -656,6 +656,22 @@ extern "C" int v1c_remap_lut(int device, void* stream, const uint8_t* src, int s
     return V1C_OK;
 }
 
+// merge=True of apply_lr(), remapper.py:485-497 (labels :498-516 stay with the caller).
+extern "C" int v1c_anaglyph(int device, void* stream, const uint8_t* left, int64_t left_pitch, const uint8_t* right,
+                            int64_t right_pitch, int h, int w, double* out, int64_t out_pitch)
+{
+    if (!left || !right || !out || h <= 0 || w <= 0 || h > 65535)
+        return fail(V1C_E_INVALID, "v1c_anaglyph: bad arguments");
+    if (left_pitch < (int64_t)w * 3 || right_pitch < (int64_t)w * 3 || out_pitch < (int64_t)w * 24 || (out_pitch & 7) ||
+        ((uintptr_t)out & 7))
+        return fail(V1C_E_INVALID, "v1c_anaglyph: pitch smaller than a row, or the float64 output is not 8-byte aligned");
+    DeviceGuard dg(device);
+    if (!dg.ok)
+        return fail(V1C_E_NODEVICE, "hipSetDevice failed");
+    HIP_TRY(launch_anaglyph(left, left_pitch, right, right_pitch, h, w, out, out_pitch, (hipStream_t)stream));
+    return V1C_OK;
+}
+
 // get_radius(), transformer.py:108-140.  One row (or column) of the image: copied to the host and
 // scanned there -- O(max(W, H)) bytes, synchronous by nature (the reference returns a float).
 extern "C" int v1c_get_radius(int device, void* stream, const uint8_t* img, int h, int w, int64_t pitch, int cn,

@@ -444,6 +444,22 @@ def apply_lr_tensors(
     return out
 
 
+def anaglyph_tensors(left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
+    """``merge=True`` of apply_lr on the device (reference remapper.py:485-497): per-eye channel
+    mean times a colour, summed, / 255 -- a float64 ``(H, W, 3)`` tensor like the reference's
+    ``combine`` (the "L" / "R" labels of :498-516 are not drawn here).  Current stream, no sync."""
+    _check_image_tensor(left, "left")
+    _check_image_tensor(right, "right")
+    if left.shape != right.shape or left.shape[2] != 3 or left.device != right.device:
+        raise ValueError("anaglyph needs two (H, W, 3) uint8 tensors of the same shape on one device")
+    h, w = int(left.shape[0]), int(left.shape[1])
+    out = torch.empty((h, w, 3), dtype=torch.float64, device=left.device)
+    rc = _native.lib().v1c_anaglyph(left.device.index, _stream_ptr(left.device), left.data_ptr(), left.stride(0),
+                                    right.data_ptr(), right.stride(0), h, w, out.data_ptr(), out.stride(0) * 8)
+    _native.check(rc, "v1c_anaglyph")
+    return out
+
+
 def apply_lr(
     transformer: TransformerBase | tuple[TransformerBase, TransformerBase],
     *,
@@ -472,9 +488,13 @@ def apply_lr(
     sbs = apply_lr_tensors(transformer, lt, rt, size_output=size_output, interpolation=interpolation,
                            boarder_mode=boarder_mode, boarder_value=boarder_value,
                            radius=_radius_for_pair(radius, transformer, left, right))
-    combine = sbs.cpu().numpy()
     if merge:
-        combine = _io.anaglyph(combine[:, : size_output[0]], combine[:, size_output[0] :])
+        # red/cyan anaglyph of the two halves, on the device (remapper.py:485-497); the labels need
+        # cv2.putText and are drawn on the host copy when cv2 is importable (:498-516)
+        w = size_output[0]
+        combine = _io.draw_anaglyph_labels(anaglyph_tensors(sbs[:, :w], sbs[:, w:]).cpu().numpy())
+    else:
+        combine = sbs.cpu().numpy()
     if out_path is not None:
         _io.imwrite(out_path, combine)
         LOG.info(f"Saved to {Path(out_path).absolute()}")
