@@ -470,3 +470,19 @@ def test_shared_map_unit_loop_mixed_alignment(V, oracle_mod, dev, interp):
     want = oracle_mod.apply(spec, imgs, size_output=(size, size), interpolation=interp, radius=size / 2)
     for f in range(11):
         assert np.array_equal(dsts[f].cpu().numpy(), want[f]), (interp, f)
+
+
+@pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"}, {"V1C_DISABLE_FAST": "1"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_kernel_variants_bit_exact(env):
+    """The instantiations the default configuration does not reach (per-pixel table fallback,
+    one / three units per workgroup, generic kernels) give the same bytes: tests/variant_probe.py
+    in a subprocess, because the engine reads these switches once per process."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    probe = Path(__file__).with_name("variant_probe.py")
+    r = subprocess.run([sys.executable, str(probe)], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
