@@ -445,6 +445,39 @@ __device__ __noinline__ uint32_t blend_table(lds_u32_ptr boxw, uint32_t lo, int 
     return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
 }
 
+// The same for the two eyes of a pair: both read their taps at the same box offset with the SAME
+// weights (one map per apply() call), so the weight row -- 128 B per pixel for Lanczos4, an L2
+// read -- is fetched once for both.  Returns (pixel of box A) | (pixel of box B) << 32.
+template <int K, typename WPtr>
+__device__ __noinline__ uint64_t blend_table_pair(lds_u32_ptr boxa, lds_u32_ptr boxb, uint32_t lo, int lpw, WPtr w)
+{
+    int a0 = 1 << 14, a1 = 1 << 14, a2 = 1 << 14, b0 = 1 << 14, b1 = 1 << 14, b2 = 1 << 14;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        uint32_t da[K], db[K];
+#pragma unroll
+        for (int q = 0; q < K; q++)
+            da[q] = boxa[lo + r * lpw + q], db[q] = boxb[lo + r * lpw + q];
+        uint32_t wr[K / 2];
+#pragma unroll
+        for (int q = 0; q < K / 2; q++)
+            wr[q] = w[r * (K / 2) + q];
+#pragma unroll
+        for (int q = 0; q < K / 2; q++) {
+            const short2v ww = __builtin_bit_cast(short2v, wr[q]);
+            a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(da[2 * q + 1], da[2 * q], 0x0c040c00u)), ww, a0, false);
+            a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(da[2 * q + 1], da[2 * q], 0x0c050c01u)), ww, a1, false);
+            a2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(da[2 * q + 1], da[2 * q], 0x0c060c02u)), ww, a2, false);
+            b0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(db[2 * q + 1], db[2 * q], 0x0c040c00u)), ww, b0, false);
+            b1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(db[2 * q + 1], db[2 * q], 0x0c050c01u)), ww, b1, false);
+            b2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(db[2 * q + 1], db[2 * q], 0x0c060c02u)), ww, b2, false);
+        }
+    }
+    const uint32_t pa = (uint32_t)min(max(a0 >> 15, 0), 255) | ((uint32_t)min(max(a1 >> 15, 0), 255) << 8) | ((uint32_t)min(max(a2 >> 15, 0), 255) << 16);
+    const uint32_t pb = (uint32_t)min(max(b0 >> 15, 0), 255) | ((uint32_t)min(max(b1 >> 15, 0), 255) << 8) | ((uint32_t)min(max(b2 >> 15, 0), 255) << 16);
+    return (uint64_t)pa | ((uint64_t)pb << 32);
+}
+
 // Border-aware K x K sampler for the rare pixel whose footprint leaves the source (same
 // arithmetic as sample_table<3, K> in v1c_core.hpp, loops kept rolled: a small register
 // footprint matters more than speed here because the callee's VGPRs count against the kernel).
@@ -766,7 +799,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     // (into S0) while unit v-2 is sampled, its LDS store happens at the top of iteration v-1 behind
     // the barrier that also tells everyone is done with unit v-2, and the barrier at the top of
     // iteration v makes it visible: one barrier per unit, none at all for a pair.
-    if (PAIR || nu <= 2) {
+    if (PAIR) {
         // a pair (apply_lr: the two eyes): both boxes are already visible, no further barrier --
         // straight-line code lets the second unit's LDS reads overlap the first unit's blend
         if (incomplete) {
@@ -791,13 +824,29 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
             patch_and_store<K>(c, ua, z0 + 1, t, L, pix, L.inside, ua.u[z0 + 1].src);
             return;
         }
+        if (K != 2 && nu == 2 && fit0 && fit1) {
+            // K x K taps of both eyes against one fetch of the weight row
+            constexpr int off = K / 2 - 1;
+            const int lpw = b.cpr * 4 + 4;
+            uint32_t pa[kPX], pb[kPX];
+#pragma unroll
+            for (int k = 0; k < kPX; k++) {
+                const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+                const bool in = (L.inside >> k) & 1;
+                const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
+                const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
+                const uint64_t pp = blend_table_pair<K>((lds_u32_ptr)boxw, (lds_u32_ptr)(boxw + half_dwords), lo, lpw, wtab + a * (K * K / 2));
+                pa[k] = (uint32_t)pp, pb[k] = (uint32_t)(pp >> 32);
+            }
+            patch_and_store<K>(c, ua, z0, t, L, pa, L.inside, ua.u[z0].src);
+            patch_and_store<K>(c, ua, z0 + 1, t, L, pb, L.inside, ua.u[z0 + 1].src);
+            return;
+        }
         sample_and_store<K>(c, ua, z0, t, L, b, fit0, boxw, wtab, ua.u[z0].src, (uint32_t)ua.u[z0].src_pitch);
         if (nu == 2)
             sample_and_store<K>(c, ua, z0 + 1, t, L, b, fit1, boxw + half_dwords, wtab, ua.u[z0 + 1].src, (uint32_t)ua.u[z0 + 1].src_pitch);
         return;
     }
-    if (PAIR)
-        return;
     bool fit_cur = fit0, fit_nxt = fit1, fit_s = false;
     for (int u = 0; u < nu; u++) {
         const int z = z0 + u;
