@@ -31,6 +31,9 @@ constexpr int kTW = 64, kTH = 16;          // output tile (px)
 #ifndef V1C_BOX_KB
 #define V1C_BOX_KB 24
 #endif
+#ifndef V1C_XCD_SWIZZLE
+#define V1C_XCD_SWIZZLE 1
+#endif
 #ifndef V1C_UPB
 #define V1C_UPB 8
 #endif
@@ -881,7 +884,21 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
     if (BOXES) {
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
         extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT>(c, ua, boxes, n_units, upb, blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, dyn_box,
+        // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
+        // L2), so consecutive ids would scatter neighbouring tiles -- which share source rows --
+        // over all L2s.  Give each XCD a contiguous run of tiles instead.
+        int tx = blockIdx.x, ty = blockIdx.y;
+#if V1C_XCD_SWIZZLE
+        {
+            const unsigned ntile = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned per = ntile >> 3;  // tiles per XCD; the remainder keeps its natural order
+            if (lin < per * 8u) {
+                const unsigned m = (lin & 7u) * per + (lin >> 3);
+                ty = (int)(m / gridDim.x), tx = (int)(m - (unsigned)ty * gridDim.x);
+            }
+        }
+#endif
+        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, gridDim.x, dyn_box,
                                            half_dwords, tabw, wtab);
     } else {
         __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
