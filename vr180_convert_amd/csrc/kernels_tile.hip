@@ -870,6 +870,22 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     }
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+// consecutive ids would scatter neighbouring tiles -- which share source rows -- over all L2s.
+// Give each XCD a contiguous run of tiles instead (C2: FETCH_SIZE 128 -> 61 MB per launch).
+__device__ __forceinline__ void xcd_tile(int& tx, int& ty)
+{
+    tx = blockIdx.x, ty = blockIdx.y;
+#if V1C_XCD_SWIZZLE
+    const unsigned ntile = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned per = ntile >> 3;  // tiles per XCD; the remainder keeps its natural order
+    if (lin < per * 8u) {
+        const unsigned m = (lin & 7u) * per + (lin >> 3);
+        ty = (int)(m / gridDim.x), tx = (int)(m - (unsigned)ty * gridDim.x);
+    }
+#endif
+}
+
 // BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes, coordinates shared by `upb` units.
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
@@ -882,22 +898,10 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
     __shared__ __attribute__((aligned(16))) double tabw[BOXES ? kTabSlice * kRadialCoefs : 2];
     const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
     if (BOXES) {
+        int tx, ty;
+        xcd_tile(tx, ty);
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
         extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-        // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
-        // L2), so consecutive ids would scatter neighbouring tiles -- which share source rows --
-        // over all L2s.  Give each XCD a contiguous run of tiles instead.
-        int tx = blockIdx.x, ty = blockIdx.y;
-#if V1C_XCD_SWIZZLE
-        {
-            const unsigned ntile = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-            const unsigned per = ntile >> 3;  // tiles per XCD; the remainder keeps its natural order
-            if (lin < per * 8u) {
-                const unsigned m = (lin & 7u) * per + (lin >> 3);
-                ty = (int)(m / gridDim.x), tx = (int)(m - (unsigned)ty * gridDim.x);
-            }
-        }
-#endif
         shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, gridDim.x, dyn_box,
                                            half_dwords, tabw, wtab);
     } else {
@@ -906,6 +910,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         const RayParams& P = c.ray;
         const int tid = threadIdx.x;
         const int z = blockIdx.z;
+        // (natural tile order here: with one source per unit the swizzle measured 6 % slower on C5)
         const TileIds t = tile_ids(g, z, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / 16);
         const uint8_t* __restrict__ src = ua.u[z].src;
         const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
