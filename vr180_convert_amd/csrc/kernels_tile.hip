@@ -27,7 +27,11 @@
 
 namespace v1c {
 
-constexpr int kTW = 64, kTH = 16;          // output tile (px)
+#ifndef V1C_TILE_W
+#define V1C_TILE_W 64
+#endif
+constexpr int kTW = V1C_TILE_W;            // output tile width (px); height = threads / kLanesX
+constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_BOX_KB
 #define V1C_BOX_KB 24
 #endif
@@ -542,8 +546,8 @@ struct TileIds {
 __device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid, int tx, int ty, int tiles_x, int th)
 {
     TileIds t;
-    const int lx = tid & 15, ly = tid >> 4;
-    t.x0 = (tx * 16 + lx) * kPX;
+    const int lx = tid % kLanesX, ly = tid / kLanesX;
+    t.x0 = (tx * kLanesX + lx) * kPX;
     t.j = ty * th + ly;
     t.active = (t.x0 < g.dst_w) & (t.j < g.dst_h);
     t.xc = min(t.x0, ((g.dst_w + 3) & ~3) - 4), t.jc = min(t.j, g.dst_h - 1);  // clamped for table reads
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     __shared__ __attribute__((aligned(16))) int red[4 * NW];
     __shared__ int red2[2 * NW];
     const int tid = threadIdx.x;
-    const TileIds t = tile_ids(c.g, 0, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / 16);
+    const TileIds t = tile_ids(c.g, 0, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / kLanesX);
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, t.jc, rc);
     LaneCoords L;
@@ -741,7 +745,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     unsigned long long stamp_ = __builtin_readcyclecounter();
 #endif
     const int z0 = zg * upb;
-    const TileIds t = tile_ids(g, z0, tid, tx, ty, tiles_x, NT / 16);
+    const TileIds t = tile_ids(g, z0, tid, tx, ty, tiles_x, NT / kLanesX);
     const int nu = min(upb, n_units - z0);
     // everything the tile needs from global memory is requested up front: the boxes of the first
     // two units, the radial-table slice and the row / column table entries (one exposed latency)
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         const int tid = threadIdx.x;
         const int z = blockIdx.z;
         // (natural tile order here: with one source per unit the swizzle measured 6 % slower on C5)
-        const TileIds t = tile_ids(g, z, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / 16);
+        const TileIds t = tile_ids(g, z, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / kLanesX);
         const uint8_t* __restrict__ src = ua.u[z].src;
         const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
@@ -953,7 +957,7 @@ int tile_threads(const Geom&)
 
 static dim3 tile_grid(const Geom& g, int nt, int nz)
 {
-    const int th = nt / 16;
+    const int th = nt / kLanesX;
     return dim3((g.dst_w + kTW - 1) / kTW, (g.dst_h + th - 1) / th, nz);
 }
 
