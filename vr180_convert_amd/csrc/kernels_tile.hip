@@ -1,25 +1,34 @@
-// kernels_tile.hip -- LDS-tiled kernel for the hot configurations (BGR, BORDER_CONSTANT, fused ray
-// path; INTER_LINEAR, and with K x K table taps INTER_CUBIC / INTER_LANCZOS4).  Same arithmetic as kernels.hip: the tests compare both with
-// the oracle bit for bit.
+// kernels_tile.hip -- LDS-tiled kernels for the hot configurations: BGR, BORDER_CONSTANT, fused ray
+// path, INTER_LINEAR and (with K x K table taps) INTER_CUBIC / INTER_LANCZOS4.  Same arithmetic as
+// kernels.hip: the tests compare both with the oracle bit for bit.
 //
 // Why tiles: rocprof counters on a gather-from-global version show the vector L1 (TCP) as the
 // limit -- it retires about one 64-byte access per clock, a wave's 64 unaligned 8-byte gathers
 // cost ~100 accesses per load instruction (no coalescing) and a dwordx4 table read 16.  Here
 //   * a workgroup owns a 64 x 16 output tile (lane = 4 px of one row, wave = 64 px x 4 rows);
+//     tiles are dealt to the XCDs in contiguous runs so that shared halo rows hit one L2;
 //   * the bounding box of the tile's source taps is copied from HBM to LDS with 12-byte,
 //     row-contiguous, dword-aligned loads (one wave load = 768 contiguous bytes = 256 pixels for
 //     ~13 L1 accesses) and kept 4 bytes per pixel in LDS (BGRx: three v_perm_b32 expand 4 pixels
 //     into one ds_write_b128), so a 2x2 cell is two ALIGNED ds_read2_b32 (unaligned 8-byte LDS
 //     reads of packed BGR measured ~60 stall cycles each);
-//   * the box of every tile is computed ONCE per plan by k_tile_boxes (the map does not depend on
-//     the pixels), so the hot kernel starts its staging loads before any coordinate math and has
-//     no reduction; units that override the rotation (per-frame calibration) use the BOXES = 0
-//     variant, which reduces the box in-kernel with DPP mins;
-//   * each lane reads ONE 64-byte radial-table entry for its 4 pixels: intervals whose polynomial
-//     was validated at plan time on the 3x wider range carry a flag in the LSB of c7.
+//   * the box of every tile, the slice of the radial table it uses and whether all of its pixels
+//     are valid and inside the source ("interior") are computed ONCE per plan by k_tile_boxes (the
+//     map does not depend on the pixels), so the hot kernel starts its staging loads before any
+//     coordinate math and has no reduction; units that override the rotation (per-frame
+//     calibration) use the BOXES = 0 variant, which reduces the box in-kernel with DPP mins;
+//   * the coordinates of a tile are computed once and shared by every unit of the launch that
+//     uses the same map (the reference computes ONE map per apply() call): the two eyes of a pair
+//     (PAIR = 1: straight-line code, 6 waves per SIMD) or up to 8 frames of a batch (loop with a
+//     register prefetch of the unit after next);
+//   * each lane reads ONE 64-byte radial-table entry for its 4 pixels; the plan proves from the
+//     validity levels of the table (radial_fit.hpp) that this is enough (OWN = 0) or keeps the
+//     per-pixel fallback compiled in (OWN = 1).
 // Tiles whose box does not fit the LDS budget (strong rotation / minification) gather from global
 // memory; pixels with taps outside the source go through the generic border-aware sampler;
 // pixels outside the radial table's domain are left to the fix-up launch (kernels.hip MODE_FIXUP).
+// Compile-time switches for A/B measurements: V1C_TILE_W (64), V1C_UPB (8), V1C_XCD_SWIZZLE (1),
+// V1C_STAMPS (per-phase cycle counters); run-time: V1C_UPB=<n>.
 #include <algorithm>
 #include <cstdlib>
 
