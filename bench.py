@@ -179,8 +179,8 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
