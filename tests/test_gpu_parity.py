@@ -472,6 +472,31 @@ def test_shared_map_unit_loop_mixed_alignment(V, oracle_mod, dev, interp):
         assert np.array_equal(dsts[f].cpu().numpy(), want[f]), (interp, f)
 
 
+def test_plan_run_is_graph_capturable(V, dev):
+    """v1c_plan_run neither allocates nor synchronises -- a warmed-up call can be
+    captured into a HIP graph on a side stream and replayed."""
+    from vr180_convert_amd.synth import noise_disc
+
+    size = 256
+    t = CS.to_product([("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI])
+    l, r = (torch.from_numpy(noise_disc(size, size, k)).to(dev) for k in (0, 1))
+    ref = V.apply_lr_tensors(t, l, r, size_output=(size, size), interpolation=1, radius="max").clone()
+    out = torch.empty_like(ref)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):  # warm-up on the capture stream: the plan exists before capture starts
+        V.apply_lr_tensors(t, l, r, out=out, size_output=(size, size), interpolation=1, radius="max")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        V.apply_lr_tensors(t, l, r, out=out, size_output=(size, size), interpolation=1, radius="max")
+    for _ in range(2):
+        out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"}, {"V1C_DISABLE_FAST": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_variants_bit_exact(env):
