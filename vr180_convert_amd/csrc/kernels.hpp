@@ -31,7 +31,7 @@ hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float
 // hot configuration (CN = 3, INTER_LINEAR, BORDER_CONSTANT, ray mode): kernels_tile.hip
 bool tile_kernel_supports(const Geom& g);
 size_t tile_box_bytes(const Geom& g);
-hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream);
+hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream);
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 bool shared_entry, hipStream_t stream);

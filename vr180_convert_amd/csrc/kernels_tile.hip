@@ -577,7 +577,10 @@ __device__ __forceinline__ bool box_touches_image_end(const TileBox& b, const Ge
 
 // Plan-time pass: the source box and the radial-table slice of every 64 x (NT/16) tile (chain
 // rotation as stored in the plan).
-template <int VAR_W, int ROT, int K, int NT>
+// OWN as in the kernel that will consume the boxes: with OWN = 0 a pixel is evaluated with pixel 1's
+// table entry, with OWN = 1 possibly with its own -- both within tolerance, but the box must
+// bound the coordinates the consumer will actually compute.
+template <int VAR_W, int ROT, int K, int NT, int OWN>
 __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes)
 {
     constexpr int NW = NT / 64;
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, t.jc, rc);
     LaneCoords L;
-    lane_coords<VAR_W, ROT, K, 1, 0>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
+    lane_coords<VAR_W, ROT, K, OWN, 0>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
     TileBox b = reduce_box<K, NW>(L, red, tid);
     const int interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L.ok == 0xFu) & (L.inside == 0xFu)));
     const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
@@ -996,30 +999,39 @@ int tile_half_dwords(const void* host_boxes, size_t n_tiles)
 
 // plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
 template <int K, int NT>
-static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, hipStream_t stream)
+static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, bool shared_entry, hipStream_t stream)
 {
     const dim3 block(NT, 1, 1), grid = tile_grid(c.g, NT, 1);
     const bool rot = c.ray.has_rot != 0;
+#define V1C_BOXES(VW, RT)                                                                                         \
+    do {                                                                                                          \
+        if (shared_entry)                                                                                         \
+            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0>), grid, block, 0, stream, c, ua, boxes);           \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1>), grid, block, 0, stream, c, ua, boxes);           \
+    } while (0)
     if (c.ray.var_is_w) {
         if (rot)
-            hipLaunchKernelGGL((k_tile_boxes<1, 1, K, NT>), grid, block, 0, stream, c, ua, boxes);
+            V1C_BOXES(1, 1);
         else
-            hipLaunchKernelGGL((k_tile_boxes<1, 0, K, NT>), grid, block, 0, stream, c, ua, boxes);
+            V1C_BOXES(1, 0);
     } else {
         if (rot)
-            hipLaunchKernelGGL((k_tile_boxes<0, 1, K, NT>), grid, block, 0, stream, c, ua, boxes);
+            V1C_BOXES(0, 1);
         else
-            hipLaunchKernelGGL((k_tile_boxes<0, 0, K, NT>), grid, block, 0, stream, c, ua, boxes);
+            V1C_BOXES(0, 0);
     }
+#undef V1C_BOXES
 }
 
-hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, hipStream_t stream)
+// `shared_entry`: the value the launches consuming these boxes will pass to launch_ray_lin3_tile
+hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream)
 {
     UnitArgs ua{};
     switch (taps_of(c.g.interp)) {
-    case 2: launch_boxes_k<2, 256>(c, ua, (TileBox*)boxes, stream); break;
-    case 4: launch_boxes_k<4, 256>(c, ua, (TileBox*)boxes, stream); break;
-    case 8: launch_boxes_k<8, 256>(c, ua, (TileBox*)boxes, stream); break;
+    case 2: launch_boxes_k<2, 256>(c, ua, (TileBox*)boxes, shared_entry, stream); break;
+    case 4: launch_boxes_k<4, 256>(c, ua, (TileBox*)boxes, shared_entry, stream); break;
+    case 8: launch_boxes_k<8, 256>(c, ua, (TileBox*)boxes, shared_entry, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -387,7 +387,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 e = hipMalloc(&bx, tile_box_bytes(g));
                 if (e == hipSuccess) {
                     p->allocs.push_back(bx);
-                    e = launch_tile_boxes(p->ctx, bx, nullptr);
+                    e = launch_tile_boxes(p->ctx, bx, p->plan_shared_entry && !p->disable_shared_entry, nullptr);
                 }
                 if (e != hipSuccess) {
                     v1c_plan_destroy(p);
