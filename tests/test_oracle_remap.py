@@ -133,3 +133,22 @@ def test_anaglyph_known_values(oracle_mod):
     assert out.dtype == np.float64 and out.shape == (1, 2, 3)
     assert np.array_equal(out[0, 0], np.array([0.0, 60 * 128 / 255, 60.0]))
     assert np.array_equal(out[0, 1], np.array([255.0, (255.0 * 128 + 255.0 * 128) / 255, 255.0]))
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2, 4])
+def test_oracle_remap_equals_live_cv2_when_present(oracle_mod, interp):
+    """where opencv-python is importable it is the live third-party oracle for
+    Appendix A -- the restatement must then equal cv2.remap bit for bit (all border modes).
+    Neither this container nor the GPU image ships cv2: the test documents and keeps the hook."""
+    cv2 = pytest.importorskip("cv2")
+    O = oracle_mod
+    rng = np.random.default_rng(11)
+    src = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
+    xm = rng.uniform(-12, 95, (70, 90)).astype(np.float32)
+    ym = rng.uniform(-12, 73, (70, 90)).astype(np.float32)
+    xm[3, 4] = np.nan
+    ym[5, 6] = np.inf
+    for border in (0, 1, 2, 3, 4):
+        want = cv2.remap(src, xm, ym, interpolation=interp, borderMode=border, borderValue=(7, 0, 0))
+        got = O.remap(src, xm, ym, interp, border, 7)
+        assert np.array_equal(got, want), (interp, border, int((got != want).sum()))
