@@ -193,5 +193,32 @@ def main() -> None:
     print("done")
 
 
+def rotation_match_golden() -> None:
+    """`rotation_match` (remapper.py:93-143) on seeded point sets.  `as_quat_array` only wraps the
+    reference's result (w, x, y, z) -- the placeholder returns the array, so the fixture holds what
+    the reference computed; the sign of an eigenvector is arbitrary (q and -q are one rotation)."""
+    import vr180_convert.remapper as RR
+
+    RR.as_quat_array = lambda a: np.asarray(a, dtype=float)
+    rng = np.random.default_rng(20240619)
+    out = {}
+    for k, (n, noise) in enumerate([(12, 0.0), (200, 1e-3), (64, 5e-2)]):
+        a = rng.normal(size=(n, 3))
+        a /= np.linalg.norm(a, axis=-1, keepdims=True)
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0.05, 1.0)
+        m = quat_to_matrix([np.cos(ang / 2), *(np.sin(ang / 2) * axis)])
+        b = a @ m.T + noise * rng.normal(size=(n, 3))
+        q = np.asarray(RR.rotation_match(a, b), dtype=float)
+        out[f"a{k}"], out[f"b{k}"], out[f"q{k}"] = a, b, q
+    np.savez_compressed(Path(__file__).resolve().parent / "rotation_match.npz", **out)
+    print("rotation_match.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rotation_match":
+        rotation_match_golden()
+    else:
+        main()
+        rotation_match_golden()
