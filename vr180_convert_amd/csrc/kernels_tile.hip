@@ -93,7 +93,7 @@ struct TileBox {
     int x0, y0, cpr, nrows;
     int idx0, nidx;
     int interior;  // 1: every pixel of the tile has valid coordinates and its whole footprint inside the source
-    int pad1;
+    int magic;     // ceil(2^20 / cpr): floor(ch / cpr) == (ch * magic) >> 20 for ch < 16k, cpr <= 64 (chunk map)
 };
 
 constexpr int kTabSlice = 64;  // radial-table entries a workgroup may keep in LDS (4 KB)
@@ -294,6 +294,8 @@ __device__ __forceinline__ TileBox reduce_box(const LaneCoords& L, int* red, int
     b.y0 = by0 - off;
     b.cpr = bx0r <= bx1 ? (bx1 - off + K - b.x0 + 3) >> 2 : 0;
     b.nrows = by1 - by0 + K;
+    b.idx0 = b.nidx = b.interior = 0;
+    b.magic = b.cpr > 0 ? (int)(((1u << 20) + (unsigned)b.cpr - 1u) / (unsigned)b.cpr) : 0;
     return b;
 }
 
@@ -323,7 +325,7 @@ __device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkM
 {
     const int nchunks = b.nrows * b.cpr;
     const int lpw = b.cpr * 4 + 4;  // LDS row pitch in dwords (+4: rotate the banks from row to row)
-    const uint32_t magic = ((1u << 20) + b.cpr - 1) / b.cpr;  // exact floor(ch / cpr) for ch < 16k, cpr <= 64
+    const uint32_t magic = (uint32_t)b.magic;  // exact floor(ch / cpr) for ch < 16k, cpr <= 64
     M.valid = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
         b.idx0 = i0 <= i1 ? i0 : 0;
         b.nidx = i0 <= i1 ? i1 - i0 + 1 : 0;
         b.interior = interior;
-        b.pad1 = 0;
+        b.magic = b.cpr > 0 ? (int)(((1u << 20) + (unsigned)b.cpr - 1u) / (unsigned)b.cpr) : 0;
         boxes[t.box_tile] = b;
     }
 }
@@ -764,7 +766,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     TileBox b;
     const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
     const int4 b0 = bp[0], b1 = bp[1];
-    b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y;
+    b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y, b.interior = b1.z, b.magic = b1.w;
     const bool tail = box_touches_image_end(b, g);
     ChunkMap M;
     make_chunk_map<NT>(b, tid, M);
