@@ -891,7 +891,9 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
 // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
 // consecutive ids would scatter neighbouring tiles -- which share source rows -- over all L2s.
 // Give each XCD a contiguous run of tiles instead (C2: FETCH_SIZE 128 -> 61 MB per launch).
-__device__ __forceinline__ void xcd_tile(int& tx, int& ty)
+// `magic` = floor(2^32 / gridDim.x) + 1 from the host: floor(m / gridDim.x) == mulhi(m, magic) for
+// every tile index (m * gridDim.x < 2^32).
+__device__ __forceinline__ void xcd_tile(unsigned magic, int& tx, int& ty)
 {
     tx = blockIdx.x, ty = blockIdx.y;
 #if V1C_XCD_SWIZZLE
@@ -899,7 +901,8 @@ __device__ __forceinline__ void xcd_tile(int& tx, int& ty)
     const unsigned per = ntile >> 3;  // tiles per XCD; the remainder keeps its natural order
     if (lin < per * 8u) {
         const unsigned m = (lin & 7u) * per + (lin >> 3);
-        ty = (int)(m / gridDim.x), tx = (int)(m - (unsigned)ty * gridDim.x);
+        ty = gridDim.x == 1 ? (int)m : (int)__umulhi(m, magic);  // (2^32 / 1 + 1 does not fit the magic)
+        tx = (int)(m - (unsigned)ty * gridDim.x);
     }
 #endif
 }
@@ -909,7 +912,7 @@ __device__ __forceinline__ void xcd_tile(int& tx, int& ty)
 //   reduced in-kernel, table read from global memory.
 template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR>
 __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
-                                                       int upb, int half_dwords)
+                                                       int upb, int half_dwords, unsigned tiles_x_magic)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) int red[16];
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
     const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
     if (BOXES) {
         int tx, ty;
-        xcd_tile(tx, ty);
+        xcd_tile(tiles_x_magic, tx, ty);
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
         extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
         shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, gridDim.x, dyn_box,
@@ -1054,7 +1057,8 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
     const size_t lds = bx ? (size_t)half_dwords * 8 + 16 : 0;  // two box buffers
 #define V1C_TILE_P(VW, RT, BX, OW, PR) \
-    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords)
+    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords, \
+                       (unsigned)(0x100000000ull / grid.x) + 1u)
 #define V1C_TILE_O(VW, RT, BX, OW)          \
     do {                                    \
         if (BX && pair)                     \
