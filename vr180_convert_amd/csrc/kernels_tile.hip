@@ -681,16 +681,18 @@ __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitAr
 template <int K, typename WPtr>
 __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
                                                  const TileBox& b, bool use_lds, const uint32_t* boxw, WPtr wtab,
-                                                 const uint8_t* __restrict__ src, uint32_t spitch)
+                                                 const uint8_t* __restrict__ src, uint32_t spitch, bool all_in = false)
 {
-    const Geom& g = c.g;
     uint32_t pix[kPX];
     unsigned done = 0;  // pixels produced by the tiled path
     if (use_lds) {
         const int lpw = b.cpr * 4 + 4;
         if (K == 2) {
             Taps2 T;
-            read_taps_lds(L, b, boxw, T);
+            if (all_in)  // interior tile: no tap predication
+                read_taps_lds<true>(L, b, boxw, T);
+            else
+                read_taps_lds(L, b, boxw, T);
             blend_taps(T, L, pix);
         } else {
             constexpr int off = K / 2 - 1;
@@ -882,7 +884,8 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         }
         if (u + 2 < nu)
             fit_s = issue(z + 2, S0);
-        sample_and_store<K>(c, ua, z, t, L, b, fit_cur, boxw + (u & 1) * half_dwords, wtab, ua.u[z].src, (uint32_t)ua.u[z].src_pitch);
+        sample_and_store<K>(c, ua, z, t, L, b, fit_cur, boxw + (u & 1) * half_dwords, wtab, ua.u[z].src, (uint32_t)ua.u[z].src_pitch,
+                            interior);
         fit_cur = fit_nxt;
         V1C_STAMP(4 + (u & 1));  // taps + blend + store of one unit
     }
