@@ -639,6 +639,13 @@ __device__ __forceinline__ void blend_taps(const Taps2& T, const LaneCoords& L, 
         pix[k] = blend3<4>(T.alo[k], T.ahi[k], T.blo[k], T.bhi[k], blend_weights(L.sx[k], L.sy[k]));
 }
 
+// interior tile: every lane is active with 4 valid pixels -- three dword stores when the row
+// pointer is dword-aligned (wave-uniform per unit: dst and its pitch), bytes otherwise
+__device__ __forceinline__ void store_interior(const UnitArgs& ua, int z, const TileIds& t, const uint32_t (&pix)[kPX])
+{
+    store4(ua.u[z].dst + (int64_t)t.j * ua.u[z].dst_pitch + (int64_t)t.x0 * 3, pix, 0xFu);
+}
+
 // ---- slow-path patch (pixels with valid coordinates the tiled path did not produce) and store ----
 template <int K>
 __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
@@ -833,14 +840,18 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         if (K == 2 && nu == 2 && fit0 && fit1) {
             // taps of both eyes first: the second eye's LDS latency hides behind the first eye's blend
             Taps2 T0, T1;
-            if (interior) {
+            uint32_t pix[kPX];
+            if (interior) {  // no predication, no slow-path test, unconditional stores
                 read_taps_lds<true>(L, b, boxw, T0);
                 read_taps_lds<true>(L, b, boxw + half_dwords, T1);
-            } else {
-                read_taps_lds(L, b, boxw, T0);
-                read_taps_lds(L, b, boxw + half_dwords, T1);
+                blend_taps(T0, L, pix);
+                store_interior(ua, z0, t, pix);
+                blend_taps(T1, L, pix);
+                store_interior(ua, z0 + 1, t, pix);
+                return;
             }
-            uint32_t pix[kPX];
+            read_taps_lds(L, b, boxw, T0);
+            read_taps_lds(L, b, boxw + half_dwords, T1);
             blend_taps(T0, L, pix);
             patch_and_store<K>(c, ua, z0, t, L, pix, L.inside, ua.u[z0].src);
             blend_taps(T1, L, pix);
