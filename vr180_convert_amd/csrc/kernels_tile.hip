@@ -237,7 +237,11 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
         const double y32 = ROT ? fma(G[k] * ky, fy_[k], cy32) : fma(G[k], ky, cy32);
         const float fxk = (float)x32, fyk = (float)y32;  // = 32 * float32(x)
         if (INTERIOR) {
-            L.sx[k] = __float2int_rn(fxk), L.sy[k] = __float2int_rn(fyk);
+            // cvRound by the 1.5 * 2^23 trick (two full-rate instructions instead of v_rndne_f32 +
+            // v_cvt_i32_f32): the add rounds to the nearest integer, ties to even, exactly like
+            // rint(); valid for |32 x| < 2^22, and interior coordinates are inside the source (< 2^20)
+            L.sx[k] = __float_as_int(fxk + 12582912.0f) - 0x4B400000;
+            L.sy[k] = __float_as_int(fyk + 12582912.0f) - 0x4B400000;
             continue;
         }
         // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
