@@ -534,9 +534,11 @@ __device__ __noinline__ uint32_t slow_pixel_table3_t(const uint8_t* src, int64_t
     return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
 }
 
-__device__ __forceinline__ void store4(uint8_t* drow, const uint32_t (&pix)[kPX], unsigned ok)
+// `aligned`: the lane's 12 bytes start on a dword boundary.  x0 * 3 is a multiple of 12, so this is
+// a property of the unit (dst and its pitch), wave-uniform -- see dst_rows_dword_aligned().
+__device__ __forceinline__ void store4(uint8_t* drow, const uint32_t (&pix)[kPX], unsigned ok, bool aligned)
 {
-    if (ok == 0xFu && (((uintptr_t)drow) & 3) == 0) {
+    if (ok == 0xFu && aligned) {
         uint32_t* d32 = (uint32_t*)drow;
         d32[0] = pix[0] | (pix[1] << 24);
         d32[1] = (pix[1] >> 8) | (pix[2] << 16);
@@ -645,9 +647,21 @@ __device__ __forceinline__ void blend_taps(const Taps2& T, const LaneCoords& L, 
 
 // interior tile: every lane is active with 4 valid pixels -- three dword stores when the row
 // pointer is dword-aligned (wave-uniform per unit: dst and its pitch), bytes otherwise
+__device__ __forceinline__ bool dst_rows_dword_aligned(const UnitArgs& ua, int z)
+{
+    return ((((uintptr_t)ua.u[z].dst) | (uintptr_t)ua.u[z].dst_pitch) & 3u) == 0;
+}
+
+// first byte of the lane's 4 pixels: 32-bit offset (the host checks dst_h * dst_pitch < 2^32 and
+// dst_pitch < 2^24 before it selects these kernels)
+__device__ __forceinline__ uint8_t* dst_ptr(const UnitArgs& ua, int z, const TileIds& t)
+{
+    return ua.u[z].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[z].dst_pitch) + (uint32_t)t.x0 * 3u);
+}
+
 __device__ __forceinline__ void store_interior(const UnitArgs& ua, int z, const TileIds& t, const uint32_t (&pix)[kPX])
 {
-    store4(ua.u[z].dst + (int64_t)t.j * ua.u[z].dst_pitch + (int64_t)t.x0 * 3, pix, 0xFu);
+    store4(dst_ptr(ua, z, t), pix, 0xFu, dst_rows_dword_aligned(ua, z));
 }
 
 // ---- slow-path patch (pixels with valid coordinates the tiled path did not produce) and store ----
@@ -684,7 +698,7 @@ __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitAr
     }
     if (!t.active)
         return;
-    store4(ua.u[z].dst + (int64_t)t.j * ua.u[z].dst_pitch + (int64_t)t.x0 * 3, pix, L.ok);
+    store4(dst_ptr(ua, z, t), pix, L.ok, dst_rows_dword_aligned(ua, z));
 }
 
 // ---- taps, blend, slow-path patch and store: shared tail of the kernels ----

@@ -495,11 +495,12 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, ua, n, st));
                 continue;
             }
-            // hand-tuned kernel for BGR + bilinear + constant border; 32-bit source offsets
+            // hand-tuned tile kernels; 32-bit source and destination offsets
             const Geom& g = p->ctx.g;
             bool fast = p->tile_boxes != nullptr && !p->disable_fast;
             for (int k = 0; k < n && fast; k++)
-                fast = (uint64_t)g.src_h * (uint64_t)ua.u[k].src_pitch < 0xFFFFFF00ull && ua.u[k].src_pitch < (1 << 24);
+                fast = (uint64_t)g.src_h * (uint64_t)ua.u[k].src_pitch < 0xFFFFFF00ull && ua.u[k].src_pitch < (1 << 24) &&
+                       (uint64_t)g.dst_h * (uint64_t)ua.u[k].dst_pitch < 0xFFFFFF00ull && ua.u[k].dst_pitch < (1 << 24);
             // the fix-up pass is skipped when no pixel can land in a flagged table interval: proven at
             // plan time for the chain's own rotation, per unit for overriding rotations; likewise
             // `shared_entry` (one table entry per lane, no per-pixel fallback in the kernel)
