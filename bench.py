@@ -12,7 +12,7 @@ with no data-path collective, so scaling is weak and the value is N pairs per st
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused remap launch):
 algorithmic bytes per launch (3 B * (source + destination pixels), both eyes: SURVEY.md 8d)
-over its average duration measured with events on the launch stream.  `cpu_baseline` is the
+over its average duration: two events on the launch stream bracket the K timed steps.  `cpu_baseline` is the
 oracle (plain-C port of the reference path, oracle/) timed on this box's host cores on the same
 workload, rank 0 at N=1 only.
 """
