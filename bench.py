@@ -289,9 +289,10 @@ def main() -> None:
             "metric": "Mpixels/s dual-fisheye->SBS-equirect remap; achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64 coordinates (fused chain), u8 pixels with int32 fixed-point blend",
+            "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (seeded uint8 noise inside the fisheye circle, black outside), resident in HBM",
             "config": {"workload": f"{args.workload}: {cfg['desc']}", "units_per_step_per_gpu": units,
+                       "arithmetic": "f64 coordinates (fused chain), u8 pixels with int32 fixed-point blend",
                        "sharding": "frames over ranks, no collective", "kernel_path": paths},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
