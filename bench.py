@@ -241,6 +241,13 @@ def main() -> None:
         if world > 1:
             dist.barrier()
 
+    # Setup, not a step: ~25 ms of device work so that the shader clock has left its idle state
+    # before the W warm-up steps (a step is ~0.07 ms; the CPU-side input synthesis above leaves the
+    # GPU idle for about a second).  The timed region below is exactly K steps.
+    spin = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    for _ in range(40):
+        spin.add_(1)
+    del spin
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
