@@ -142,6 +142,25 @@ def test_fused_apply_bit_exact_vs_oracle(V, oracle_mod, dev, name):
     assert nd == 0, f"{name}: {nd} bytes differ, max |d| = {int(np.abs(got.astype(int) - want).max())}"
 
 
+@pytest.mark.parametrize("border", [1, 2, 3, 4])
+@pytest.mark.parametrize("interp", [1, 2, 4])
+def test_tile_kernels_other_border_modes(V, oracle_mod, dev, interp, border):
+    """REPLICATE / REFLECT / WRAP / REFLECT_101 run the tile kernels too (the border only matters to
+    pixels whose footprint leaves the source): a zoomed-out chain puts a third of the output outside."""
+    from vr180_convert_amd.synth import noise_disc
+
+    size = 200
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), ("zoom", 0.6), CS.EQUI]
+    imgs = [noise_disc(size, size, 30 + f) for f in range(3)]
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    dsts = [torch.empty((231, 277, 3), dtype=torch.uint8, device=dev) for _ in imgs]
+    paths = V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=size / 2, interpolation=interp, boarder_mode=border)
+    assert paths == ["ray"]
+    want = oracle_mod.apply(spec, imgs, size_output=(277, 231), interpolation=interp, border_mode=border, radius=size / 2)
+    for d, w in zip(dsts, want):
+        assert np.array_equal(d.cpu().numpy(), w), (interp, border, int((d.cpu().numpy() != w).sum()))
+
+
 def test_seeded_random_cases_bit_exact(V, oracle_mod, dev):
     """Differential sweep: seeded random output / source sizes (odd, tiny, non-square), radii,
     chains of the ray and literal kinds, interpolations, border modes / values and unit counts --

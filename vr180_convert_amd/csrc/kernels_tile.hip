@@ -1,4 +1,4 @@
-// kernels_tile.hip -- LDS-tiled kernels for the hot configurations: BGR, BORDER_CONSTANT, fused ray
+// kernels_tile.hip -- LDS-tiled kernels for the hot configurations: BGR, every border mode but TRANSPARENT, fused ray
 // path, INTER_LINEAR and (with K x K table taps) INTER_CUBIC / INTER_LANCZOS4.  Same arithmetic as
 // kernels.hip: the tests compare both with the oracle bit for bit.
 //
@@ -504,30 +504,32 @@ __device__ __noinline__ uint64_t blend_table_pair(lds_u32_ptr boxa, lds_u32_ptr 
 // arithmetic as sample_table<3, K> in v1c_core.hpp, loops kept rolled: a small register
 // footprint matters more than speed here because the callee's VGPRs count against the kernel).
 template <int K>
-__device__ __noinline__ uint32_t slow_pixel_table3_t(const uint8_t* src, int64_t pitch, int h, int w, Geom g, const short* itab,
-                                                     float x, float y)
+// (border mode and the packed BGR border value as plain scalars: a Geom passed by value to a
+// non-inlined function had its byte members mis-read -- cval[2] came back as 63)
+__device__ __noinline__ uint32_t slow_pixel_table3_t(const uint8_t* src, int64_t pitch, int h, int w, int border, uint32_t cval_bgr,
+                                                     const short* itab, float x, float y)
 {
+    const int cv0 = (int)(cval_bgr & 255u), cv1 = (int)((cval_bgr >> 8) & 255u), cv2 = (int)((cval_bgr >> 16) & 255u);
     const Taps t = quantize(x, y);
     const short* __restrict__ wt = itab + (size_t)(t.fy * 32 + t.fx) * (K * K);
     constexpr int off = K / 2 - 1;
     const int sx = t.ix - off, sy = t.iy - off;
-    if (sx >= w || sx + K <= 0 || sy >= h || sy + K <= 0)  // BORDER_CONSTANT: footprint entirely outside
-        return (uint32_t)g.cval[0] | ((uint32_t)g.cval[1] << 8) | ((uint32_t)g.cval[2] << 16);
+    if (border == V1C_BORDER_CONSTANT && (sx >= w || sx + K <= 0 || sy >= h || sy + K <= 0))  // footprint entirely outside
+        return cval_bgr & 0xffffffu;
     int a0 = 1 << 14, a1 = 1 << 14, a2 = 1 << 14;
 #pragma unroll 1
     for (int i = 0; i < K; i++) {
-        const int yi = sy + i;
-        const bool yin = (unsigned)yi < (unsigned)h;
-        const uint8_t* S = src + (int64_t)(yin ? yi : 0) * pitch;
+        const int yi = border_index(sy + i, h, border);  // -1: outside under BORDER_CONSTANT
+        const uint8_t* S = src + (int64_t)(yi < 0 ? 0 : yi) * pitch;
 #pragma unroll 1
         for (int j = 0; j < K; j++) {
-            const int xj = sx + j;
-            const bool in = yin & ((unsigned)xj < (unsigned)w);
+            const int xj = border_index(sx + j, w, border);
+            const bool in = (yi >= 0) & (xj >= 0);
             const int wv = wt[i * K + j];
             const uint8_t* p = S + (in ? xj : 0) * 3;
-            a0 += (in ? (int)p[0] : (int)g.cval[0]) * wv;
-            a1 += (in ? (int)p[1] : (int)g.cval[1]) * wv;
-            a2 += (in ? (int)p[2] : (int)g.cval[2]) * wv;
+            a0 += (in ? (int)p[0] : cv0) * wv;
+            a1 += (in ? (int)p[1] : cv1) * wv;
+            a2 += (in ? (int)p[2] : cv2) * wv;
         }
     }
     const int o0 = min(max(a0 >> 15, 0), 255), o1 = min(max(a1 >> 15, 0), 255), o2 = min(max(a2 >> 15, 0), 255);
@@ -692,8 +694,9 @@ __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitAr
                 if (slow & (1u << k))
                     // (float)sx / 32 re-quantises to sx while |sx| < 2^24; beyond that the footprint is
                     // outside the source either way (saturated short coordinates)
-                    pix[k] = slow_pixel_table3_t<K>(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, c.itab, (float)L.sx[k] * 0.03125f,
-                                                    (float)L.sy[k] * 0.03125f);
+                    pix[k] = slow_pixel_table3_t<K>(src, ua.u[z].src_pitch, g.src_h, g.src_w, g.border,
+                                                    (uint32_t)g.cval[0] | ((uint32_t)g.cval[1] << 8) | ((uint32_t)g.cval[2] << 16), c.itab,
+                                                    (float)L.sx[k] * 0.03125f, (float)L.sy[k] * 0.03125f);
         }
     }
     if (!t.active)
@@ -995,7 +998,9 @@ static int taps_of(int interp)
 
 bool tile_kernel_supports(const Geom& g)
 {
-    return g.cn == 3 && g.border == V1C_BORDER_CONSTANT && taps_of(g.interp) != 0 && g.src_w >= 3 && g.src_h >= 2;
+    // every border mode but TRANSPARENT (whose skipped pixels the tiled stores cannot express): the
+    // border only matters to pixels whose footprint leaves the source, and those take the generic samplers
+    return g.cn == 3 && g.border != V1C_BORDER_TRANSPARENT && taps_of(g.interp) != 0 && g.src_w >= 3 && g.src_h >= 2;
 }
 
 // threads per workgroup (tile = 64 x threads/16) the plan-time boxes are computed for
