@@ -550,7 +550,8 @@ def test_plan_run_is_graph_capturable(V, dev):
         assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"}, {"V1C_DISABLE_FAST": "1"}],
+@pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_DISABLE_MPOLY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"},
+                                 {"V1C_DISABLE_FAST": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_variants_bit_exact(env):
     """The instantiations the default configuration does not reach (per-pixel table fallback,

@@ -129,7 +129,10 @@ __device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, 
 // (plan.hip: shared_entry), so the per-pixel fallback is not compiled in.
 // INTERIOR = 1: the plan found every pixel of this tile valid and inside (TileBox::interior, same
 // arithmetic): the validity / inside tests are skipped.
-template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, typename TabPtr>
+// MPOLY = 1 (w-tables, OWN = 0 only): `tab` is the table of polynomials in m (RayParams::radial_m):
+// the interval index comes from an fp32 square root and G = poly6(m - m_c) -- no fp64 root.  The
+// plan flags the tiles where every entry a lane can pick is valid at the level the lanes need.
+template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, int MPOLY, typename TabPtr>
 __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, const RowCol& rc, int npx, TabPtr tab,
                                             int tab0, int tabn, LaneCoords& L)
 {
@@ -153,9 +156,9 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
     // factors of G (see ray_eval): x32 = (G*kx)*fx_[k] + cx32 ; y32 = (G*ky)*fy_[k] + cy32 (rotation)
     //                                                          y32 = G*ky + cy32          (none)
     const double kx = ROT ? rx32 : rx32 * cl, ky = ROT ? ry32 : ry32 * sl;
-    double fx_[kPX], fy_[kPX], tt[kPX];
+    double fx_[kPX], fy_[kPX], tt[kPX], mm[kPX];
     int idx[kPX];
-    unsigned in_table = 0;
+    unsigned in_table = MPOLY ? 0xFu : 0u;
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
         double m;
@@ -168,6 +171,11 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
             fy_[k] = 1.0;
             m = fma(cl, qlon[k], hl);
         }
+        mm[k] = m;
+        if (MPOLY) {
+            tt[k] = 0.0, idx[k] = 0;
+            continue;
+        }
         const double u = VAR_W ? fast_sqrt_half(m) : m;
         tt[k] = u * P.inv_step;
         const int ir = table_index(tt[k]);
@@ -177,7 +185,31 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
 
     // radial table: one entry (that of pixel 1) serves all 4 pixels where it may
     double G[kPX];
-    {
+    if (MPOLY) {
+        // interval of pixel 1 from an fp32 root (an index off by one near an interval boundary is
+        // covered by the 0.01 margin the entries were validated with)
+        const int ic = (int)(__builtin_amdgcn_sqrtf((float)(0.5 * mm[1])) * P.inv_step_f);
+        for (int k = 0; k < kPX; k++)
+            idx[k] = ic;
+        double e[kRadialCoefs];
+        typedef double __attribute__((ext_vector_type(2))) d2;
+        const uint32_t rel = (uint32_t)min(max(ic - tab0, 0), tabn - 1);
+        const d2* p2 = (const d2*)(tab + rel * (uint32_t)kRadialCoefs);
+#pragma unroll
+        for (int q = 0; q < kRadialCoefs / 2; q++) {
+            const d2 v = p2[q];
+            e[2 * q] = v.x, e[2 * q + 1] = v.y;
+        }
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const double dk = mm[k] - e[kRadialCoefs - 1];  // m - m_c
+            double gk = e[kRadialCoefs - 2];
+#pragma unroll
+            for (int q = kRadialCoefs - 3; q >= 0; q--)
+                gk = fma(gk, dk, e[q]);
+            G[k] = gk;
+        }
+    } else {
         const int ic = idx[1];
         double e[kRadialCoefs];
         {
@@ -601,20 +633,39 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, t.jc, rc);
     LaneCoords L;
-    lane_coords<VAR_W, ROT, K, OWN, 0>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
+    lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
     TileBox b = reduce_box<K, NW>(L, red, tid);
-    const int interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L.ok == 0xFu) & (L.inside == 0xFu)));
+    int interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L.ok == 0xFu) & (L.inside == 0xFu))) ? 1 : 0;
     const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
     if ((tid & 63) == 63)
         red2[(tid >> 6) * 2] = lo, red2[(tid >> 6) * 2 + 1] = nhi;
     __syncthreads();
+    int i0 = red2[0], n1 = red2[1];
+    for (int w = 1; w < NW; w++)
+        i0 = min(i0, red2[2 * w]), n1 = min(n1, red2[2 * w + 1]);
+    const int i1 = -n1;
+    // Interior tiles of a w-table whose every reachable interval (one either side for the fp32
+    // index) has a valid polynomial in m: the consumer will evaluate THAT (no fp64 square root), so
+    // the box and the interior verdict are recomputed from those coordinates (bit 1 of `interior`).
+    const bool mpoly = VAR_W && OWN == 0 && c.ray.radial_m != nullptr && interior && i0 <= i1 && i0 - 1 >= c.ray.mp_first_ok &&
+                       i1 - i0 + 3 <= kTabSlice;
+    if (mpoly) {
+        __syncthreads();  // red / red2 are reused
+        LaneCoords L2;
+        lane_coords<VAR_W, ROT, K, 0, 0, 1>(c, ua, 0, rc, t.npx, c.ray.radial_m, 0, c.ray.n_int, L2);
+        b = reduce_box<K, NW>(L2, red, tid);
+        interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L2.ok == 0xFu) & (L2.inside == 0xFu)));
+        interior = interior ? 3 : 0;  // (not interior any more: an ordinary tile, evaluated through w)
+        if (!interior) {
+            __syncthreads();
+            b = reduce_box<K, NW>(L, red, tid);
+        }
+    }
     if (tid == 0) {
-        int i0 = red2[0], n1 = red2[1];
-        for (int w = 1; w < NW; w++)
-            i0 = min(i0, red2[2 * w]), n1 = min(n1, red2[2 * w + 1]);
-        const int i1 = -n1;
-        b.idx0 = i0 <= i1 ? i0 : 0;
-        b.nidx = i0 <= i1 ? i1 - i0 + 1 : 0;
+        // (m-polynomial tiles keep one more entry either side of the slice for the fp32 index)
+        const int j0 = interior == 3 ? i0 - 1 : i0, j1 = interior == 3 ? i1 + 1 : i1;
+        b.idx0 = i0 <= i1 ? j0 : 0;
+        b.nidx = i0 <= i1 ? j1 - j0 + 1 : 0;
         b.interior = interior;
         b.magic = b.cpr > 0 ? (int)(((1u << 20) + (unsigned)b.cpr - 1u) / (unsigned)b.cpr) : 0;
         boxes[t.box_tile] = b;
@@ -821,8 +872,9 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
     typedef double __attribute__((ext_vector_type(2))) d2;
     d2 tv = {0.0, 0.0};
+    const bool mpoly = VAR_W && OWN == 0 && (b.interior & 2) != 0;  // slice of the polynomials in m instead
     if (tab_lds && tid < b.nidx * 4)
-        tv = ((const d2*)(P.radial + (size_t)b.idx0 * kRadialCoefs))[tid];
+        tv = ((const d2*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs))[tid];
     RowCol rc;
     load_rowcol<ROT>(P, t.xc, t.jc, rc);
     V1C_STAMP(0);  // setup + issue of all loads
@@ -837,12 +889,14 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     V1C_STAMP(2);  // barrier
     LaneCoords L;
     const bool interior = tab_lds & (b.interior != 0);  // wave-uniform: no validity / inside tests needed
-    if (interior)
-        lane_coords<VAR_W, ROT, K, OWN, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+    if (VAR_W && OWN == 0 && interior && mpoly)
+        lane_coords<VAR_W, ROT, K, 0, 1, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+    else if (interior)
+        lane_coords<VAR_W, ROT, K, OWN, 1, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (tab_lds)
-        lane_coords<VAR_W, ROT, K, OWN, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else
-        lane_coords<VAR_W, ROT, K, OWN, 0>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
     const bool incomplete = L.ok != (1u << t.npx) - 1;
     V1C_STAMP(3);  // coordinates
 
@@ -974,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         RowCol rc;
         load_rowcol<ROT>(P, t.xc, t.jc, rc);
         LaneCoords L;
-        lane_coords<VAR_W, ROT, K, OWN, 0>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
         const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
         const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
         if (use_lds) {

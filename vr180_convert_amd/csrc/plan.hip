@@ -171,6 +171,7 @@ struct v1c_plan {
     int half_dwords = 256;        // LDS dwords per box buffer of the shared-map tile kernel
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     bool disable_shared_entry = false;  // V1C_DISABLE_SHARED_ENTRY=1: keep the per-pixel table fallback compiled in
+    bool disable_mpoly = false;         // V1C_DISABLE_MPOLY=1: no m-polynomial table (every tile takes the square root)
     bool plan_shared_entry = false;     // one table entry serves a lane's 4 pixels (ray_entry_is_shared)
     double ray_step = 0;                // largest angle between horizontally adjacent output rays
     std::vector<void*> allocs;
@@ -295,6 +296,8 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
         p->disable_fast = e && e[0] == '1';
         e = std::getenv("V1C_DISABLE_SHARED_ENTRY");
         p->disable_shared_entry = e && e[0] == '1';
+        e = std::getenv("V1C_DISABLE_MPOLY");
+        p->disable_mpoly = e && e[0] == '1';
     }
     rc = plan_common(p, device, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, border_val);
     if (rc) {
@@ -351,6 +354,25 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             p->ray_plan_rot_safe = a.has_rot && ht.front_hemisphere && ray_reach_is_safe(p->table, rotated_reach(a.rot));
             p->plan_shared_entry = (p->ray_no_rot_safe && ray_entry_is_shared(p->table, ht.m_reach, p->ray_step)) ||
                                    (p->ray_plan_rot_safe && ray_entry_is_shared(p->table, rotated_reach(a.rot), p->ray_step));
+            // w-tables: polynomials in m on the same intervals for the tiles that can do without
+            // the fp64 square root (kernels_tile.hip, lane_coords<..., MPOLY>)
+            r.radial_m = nullptr, r.mp_first_ok = r.n_int, r.inv_step_f = (float)r.inv_step;
+            if (r.var_is_w && p->plan_shared_entry && !p->disable_shared_entry && !p->disable_mpoly) {
+                const double reach = a.has_rot ? rotated_reach(a.rot) : ht.m_reach;
+                const int lv = shared_entry_level(p->table, p->ray_step);
+                const MPolyTable mp = fit_mpoly_table(p->ana.radial, p->table);
+                const int first = lv > 0 ? mpoly_first_ok(mp, p->table, reach, lv) : r.n_int;
+                if (first < r.n_int / 2) {  // worth a second table: most of the image qualifies
+                    if ((rc = upload(p, mp.coef, &r.radial_m))) {
+                        v1c_plan_destroy(p);
+                        return rc;
+                    }
+                    r.mp_first_ok = first;
+                }
+            }
+            if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+                std::fprintf(stderr, "[v1c] m-polynomial table: %s, first usable interval %d of %d\n", r.radial_m ? "yes" : "no",
+                             r.mp_first_ok, r.n_int);
             if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
                 std::fprintf(stderr,
                              "[v1c] ray plan: var=%s n_int=%d first_invalid=%d first_below_level1=%d first_below_level2=%d m_reach=%.6f "

@@ -262,6 +262,106 @@ inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w,
     return T;
 }
 
+// ---- polynomials in m on the w-uniform intervals (tables whose variable is w) ----
+// Interval i of a w-table (w in [i, i+1) / inv_step) also gets a degree-6 polynomial of G in
+// delta = m - m_c, m = 2 w^2, m_c = 2 w_c^2: entry = {c0..c6, m_c}.  Away from m = 0 (interval >= ~100
+// of 1024) this is as accurate as the polynomial in w and lets the kernel skip the fp64 square
+// root: the interval index only needs an fp32 root.  Levels as in fit_radial_table (range
+// |z| <= 0.5 + level in w-interval units, plus 0.01 for the fp32 index), stored in the low
+// mantissa bits of c6; intervals that do not validate are NaN.
+constexpr int kMPolyDegree = 6;
+
+struct MPolyTable {
+    std::vector<double> coef;               // n_int * kRadialCoefs
+    std::vector<signed char> level;         // -1: invalid
+};
+
+inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTable& T)
+{
+    MPolyTable M;
+    const int n_int = T.n_int, n = kMPolyDegree + 1;
+    M.coef.assign((size_t)n_int * kRadialCoefs, NAN);
+    M.level.assign(n_int, -1);
+    const long double step = 1.0L / (long double)T.inv_step;
+    long double cheb[16];
+    for (int k = 0; k < n; k++)
+        cheb[k] = cosl(M_PIl * (2 * k + 1) / (2.0L * n));
+    const double tol = 1.5e-15;
+    for (int i = 0; i < n_int; i++) {
+        const long double wc = (i + 0.5L) * step;
+        const double mc = (double)(2 * wc * wc);  // the double the kernel subtracts
+        for (int lv = 2; lv >= 0 && M.level[i] < 0; lv--) {
+            const long double zr = 0.5L + lv + 0.01L;
+            const long double wl = (i + 0.5L - zr) * step, wh = (i + 0.5L + zr) * step;
+            if (!(wl > 0) || !(wh < 1))
+                continue;
+            const long double dl = 2 * wl * wl - mc, dh = 2 * wh * wh - mc, scale = fmaxl(fabsl(dl), fabsl(dh));
+            long double dn[16], y[16], c[16];
+            bool good = true;
+            for (int k = 0; k < n && good; k++) {
+                const long double d = 0.5L * (dl + dh) + 0.5L * (dh - dl) * cheb[k];
+                dn[k] = d / scale;
+                good = G_of_u(st, 1, sqrtl((mc + d) / 2), y[k]);
+            }
+            if (!good || !solve_vandermonde(n, dn, y, c))
+                continue;
+            double cd[16];
+            long double pw = 1;
+            for (int k = 0; k < n; k++, pw *= scale)
+                cd[k] = (double)(c[k] / pw);
+            uint64_t bits;
+            std::memcpy(&bits, &cd[n - 1], 8);
+            bits = (bits & ~3ull) | (uint64_t)lv;
+            std::memcpy(&cd[n - 1], &bits, 8);
+            const int ntest = (4 * n + 1) * (2 * lv + 1);
+            long double gmax = 0;
+            std::vector<long double> gt(ntest);
+            std::vector<double> mt(ntest);
+            for (int q = 0; q < ntest && good; q++) {
+                const long double w = (i + 0.5L - zr + 2 * zr * (q + 0.5L) / ntest) * step;
+                mt[q] = (double)(2 * w * w);  // the kernel holds m as a double
+                good = G_of_u(st, 1, sqrtl((long double)mt[q] / 2), gt[q]);
+                gmax = fmaxl(gmax, fabsl(gt[q]));
+            }
+            for (int q = 0; q < ntest && good; q++) {
+                const double d = mt[q] - mc;
+                double g = cd[n - 1];
+                for (int k = n - 2; k >= 0; k--)
+                    g = std::fma(g, d, cd[k]);
+                good = fabsl((long double)g - gt[q]) <= tol * gmax;
+            }
+            if (good) {
+                M.level[i] = (signed char)lv;
+                for (int k = 0; k < n; k++)
+                    M.coef[(size_t)i * kRadialCoefs + k] = cd[k];
+                M.coef[(size_t)i * kRadialCoefs + kRadialCoefs - 1] = mc;
+            }
+        }
+    }
+    return M;
+}
+
+// smallest index such that every interval from it up to the one holding `m_reach` (+2) has a level
+// >= `lv`; n_int if there is none.
+inline int mpoly_first_ok(const MPolyTable& M, const RadialTable& T, double m_reach, int lv)
+{
+    const int last = std::min(T.n_int - 1, (int)(std::sqrt(m_reach / 2) * (1 + 1e-9) * T.inv_step) + 2);
+    int first = T.n_int;
+    for (int i = last; i >= 0 && M.level[i] >= lv; i--)
+        first = i;
+    return first;
+}
+
+// level a lane needs so that pixel 1's entry covers its 4 pixels (see ray_entry_is_shared); 0 if none
+inline int shared_entry_level(const RadialTable& T, double ray_step)
+{
+    const double delta = T.inv_step * (T.var_is_w ? 0.5 : 1.0) * ray_step;
+    for (int lv = 1; lv <= 2; lv++)
+        if (delta <= 0.499 * lv)
+            return lv;
+    return 0;
+}
+
 // Choose the table variable: m when that fits the front hemisphere (theta <= 90 deg) without a
 // flagged interval, otherwise whichever of m / w flags fewer intervals there.
 inline RadialTable build_radial_table(const std::vector<v1c_op>& st, int n_int = kTableIntervals)
