@@ -376,13 +376,16 @@ __device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkM
 
 // ---- issue the box loads (4 source pixels = 12 bytes per chunk) ----
 // TAIL: the box may reach past the last byte of the image (decided per tile, wave-uniform)
-template <bool TAIL>
+// ZERO: clear the slots without a chunk (the batch loop's register prefetch schedules better with
+// defined values: measured 9 % on C3; the pair path saves the 24 moves)
+template <bool TAIL, bool ZERO>
 __device__ __forceinline__ void stage_load(const ChunkMap& M, const uint8_t* __restrict__ src, uint32_t spitch, uint32_t src_bytes,
                                            Staged& S)
 {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        S.w0[q] = S.w1[q] = S.w2[q] = 0;
+        if (ZERO)
+            S.w0[q] = S.w1[q] = S.w2[q] = 0;
         if (M.valid & (1u << q)) {
             const uint32_t goff = __umul24(M.row[q], spitch) + M.xbyte[q];
             if (!TAIL || goff + 12u <= src_bytes) {
@@ -859,9 +862,9 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         const bool fits = box_fits(b, src, spitch, 4 * NT, half_dwords);
         if (fits) {
             if (tail)
-                stage_load<true>(M, src, spitch, src_bytes, S);
+                stage_load<true, !PAIR>(M, src, spitch, src_bytes, S);
             else
-                stage_load<false>(M, src, spitch, src_bytes, S);
+                stage_load<false, !PAIR>(M, src, spitch, src_bytes, S);
         }
         return fits;
     };
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
             ChunkMap M;
             make_chunk_map<NT>(b, tid, M);
             Staged S;
-            stage_load<true>(M, src, spitch, src_bytes, S);
+            stage_load<true, true>(M, src, spitch, src_bytes, S);
             stage_store(M, S, boxw);
         }
         __syncthreads();
