@@ -425,40 +425,46 @@ __device__ __forceinline__ void stage_store(const ChunkMap& M, const Staged& S, 
 }
 
 // ---- bilinear blend of one pixel from its two tap pairs; SEL_HI = byte index of px1 ----
-// (sum_ij p_ij * wx_i * wy_j + 512) >> 10 with the four 10-bit products as two u16 pairs: per
-// channel 2 x v_perm_b32 (tap pair -> two zero-extended u16) + 2 x v_dot2_u32_u16.  Identical to
-// the two-step lerp of sample_linear (v1c_core.hpp): the same integers are summed, nothing overflows.
+// out = (sum_ij p_ij * wx_i * wy_j + 512) >> 10 with the four 10-bit products as two u16 pairs,
+// scaled by 64 so that the result byte is byte 2 of the accumulator:
+//   (64 * sum + 32768) >> 16 == (sum + 512) >> 10.
+// Per channel 2 x v_perm_b32 (tap pair -> two zero-extended u16) + 2 x v_dot2_u32_u16; two more
+// v_perm_b32 pack the three result bytes.  Identical to the two-step lerp of sample_linear
+// (v1c_core.hpp).  The one product that does not fit 16 bits after scaling, 1024 * 64 (both
+// fractions zero, the other three weights 0), is stored as 65535: (65535 p + 32768) >> 16 == p.
 typedef unsigned short __attribute__((ext_vector_type(2))) ushort2v;
 
 struct BlendW {
-    uint32_t wa, wb;  // (wx0 * wy0, wx1 * wy0) and (wx0 * wy1, wx1 * wy1) as u16 pairs
+    uint32_t wa, wb;  // 64 * (wx0 * wy0, wx1 * wy0) and 64 * (wx0 * wy1, wx1 * wy1) as u16 pairs
 };
 
 __device__ __forceinline__ BlendW blend_weights(int sx, int sy)
 {
     const uint32_t fq = sx & 31, fr = sy & 31;
     const uint32_t wxp = (32u - fq) | (fq << 16);  // u16 pair (wx0, wx1); products stay below 2^16
+    const uint32_t ra = __umul24(wxp, 32u - fr), rb = __umul24(wxp, fr);
     BlendW w;
-    w.wa = __umul24(wxp, 32u - fr);
-    w.wb = __umul24(wxp, fr);
+    w.wa = (ra << 6) - ((ra >> 10) & 1u);  // low half 1024 -> 65536 would carry: 0x00010000 - 1 = 0x0000ffff
+    w.wb = rb << 6;                        // (at most 992 per half)
     return w;
 }
 
 template <int SEL_HI>
 __device__ __forceinline__ uint32_t blend3(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, const BlendW w)
 {
-    uint32_t o = 0;
+    uint32_t v[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         // bytes (p0c, 0, p1c, 0) of the pixel pair
         constexpr uint32_t base = 0x0c000c00u | ((uint32_t)SEL_HI << 16);
         const uint32_t sel = base + (uint32_t)ch * 0x00010001u;
         const uint32_t pa = __builtin_amdgcn_perm(ahi, alo, sel), pb = __builtin_amdgcn_perm(bhi, blo, sel);
-        uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pa), __builtin_bit_cast(ushort2v, w.wa), 512u, false);
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pb), __builtin_bit_cast(ushort2v, w.wb), v, false);
-        o |= (v >> 10) << (8 * ch);
+        v[ch] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pa), __builtin_bit_cast(ushort2v, w.wa), 32768u, false);
+        v[ch] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pb), __builtin_bit_cast(ushort2v, w.wb), v[ch], false);
     }
-    return o;
+    // byte 2 of each accumulator (byte 3 is zero: the sums stay below 2^24)
+    const uint32_t bg = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u);
+    return __builtin_amdgcn_perm(v[2], bg, 0x0c060100u);
 }
 
 // ---- K x K taps (bicubic / Lanczos4) from the BGRx box with OpenCV's int16 table ----
