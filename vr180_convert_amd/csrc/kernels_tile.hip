@@ -129,8 +129,9 @@ __device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, 
 // (plan.hip: shared_entry), so the per-pixel fallback is not compiled in.
 // INTERIOR = 1: the plan found every pixel of this tile valid and inside (TileBox::interior, same
 // arithmetic): the validity / inside tests are skipped.
-// MPOLY = 1 (w-tables, OWN = 0 only): `tab` is the table of polynomials in m (RayParams::radial_m):
-// the interval index comes from an fp32 square root and G = poly6(m - m_c) -- no fp64 root.  The
+// MPOLY = 1 (OWN = 0 only): `tab` is the table of polynomials in m (RayParams::radial_m): the
+// interval index comes from fp32 arithmetic (an fp32 square root for w-tables) and
+// G = poly6(m - m_c) -- no fp64 root, no index conversion in fp64.  The
 // plan flags the tiles where every entry a lane can pick is valid at the level the lanes need.
 template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, int MPOLY, typename TabPtr>
 __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, const RowCol& rc, int npx, TabPtr tab,
@@ -188,7 +189,7 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
     if (MPOLY) {
         // interval of pixel 1 from an fp32 root (an index off by one near an interval boundary is
         // covered by the 0.01 margin the entries were validated with)
-        const int ic = (int)(__builtin_amdgcn_sqrtf((float)(0.5 * mm[1])) * P.inv_step_f);
+        const int ic = VAR_W ? (int)(__builtin_amdgcn_sqrtf((float)(0.5 * mm[1])) * P.inv_step_f) : (int)((float)mm[1] * P.inv_step_f);
         for (int k = 0; k < kPX; k++)
             idx[k] = ic;
         double e[kRadialCoefs];
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     // Interior tiles of a w-table whose every reachable interval (one either side for the fp32
     // index) has a valid polynomial in m: the consumer will evaluate THAT (no fp64 square root), so
     // the box and the interior verdict are recomputed from those coordinates (bit 1 of `interior`).
-    const bool mpoly = VAR_W && OWN == 0 && c.ray.radial_m != nullptr && interior && i0 <= i1 && i0 - 1 >= c.ray.mp_first_ok &&
+    const bool mpoly = OWN == 0 && c.ray.radial_m != nullptr && interior && i0 <= i1 && i0 - 1 >= c.ray.mp_first_ok &&
                        i1 - i0 + 3 <= kTabSlice;
     if (mpoly) {
         __syncthreads();  // red / red2 are reused
@@ -881,7 +882,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
     typedef double __attribute__((ext_vector_type(2))) d2;
     d2 tv = {0.0, 0.0};
-    const bool mpoly = VAR_W && OWN == 0 && (b.interior & 2) != 0;  // slice of the polynomials in m instead
+    const bool mpoly = OWN == 0 && (b.interior & 2) != 0;  // slice of the polynomials in m instead
     if (tab_lds && tid < b.nidx * 4)
         tv = ((const d2*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs))[tid];
     RowCol rc;
@@ -898,7 +899,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     V1C_STAMP(2);  // barrier
     LaneCoords L;
     const bool interior = tab_lds & (b.interior != 0);  // wave-uniform: no validity / inside tests needed
-    if (VAR_W && OWN == 0 && interior && mpoly)
+    if (OWN == 0 && interior && mpoly)
         lane_coords<VAR_W, ROT, K, 0, 1, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (interior)
         lane_coords<VAR_W, ROT, K, OWN, 1, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);

@@ -354,10 +354,10 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             p->ray_plan_rot_safe = a.has_rot && ht.front_hemisphere && ray_reach_is_safe(p->table, rotated_reach(a.rot));
             p->plan_shared_entry = (p->ray_no_rot_safe && ray_entry_is_shared(p->table, ht.m_reach, p->ray_step)) ||
                                    (p->ray_plan_rot_safe && ray_entry_is_shared(p->table, rotated_reach(a.rot), p->ray_step));
-            // w-tables: polynomials in m on the same intervals for the tiles that can do without
-            // the fp64 square root (kernels_tile.hip, lane_coords<..., MPOLY>)
+            // polynomials in m on the same intervals: tiles whose intervals all qualify need no fp64
+            // square root (w-tables) and no fp64 index arithmetic (kernels_tile.hip, lane_coords<..., MPOLY>)
             r.radial_m = nullptr, r.mp_first_ok = r.n_int, r.inv_step_f = (float)r.inv_step;
-            if (r.var_is_w && p->plan_shared_entry && !p->disable_shared_entry && !p->disable_mpoly) {
+            if (p->plan_shared_entry && !p->disable_shared_entry && !p->disable_mpoly) {
                 const double reach = a.has_rot ? rotated_reach(a.rot) : ht.m_reach;
                 const int lv = shared_entry_level(p->table, p->ray_step);
                 const MPolyTable mp = fit_mpoly_table(p->ana.radial, p->table);

@@ -287,21 +287,24 @@ inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTab
     for (int k = 0; k < n; k++)
         cheb[k] = cosl(M_PIl * (2 * k + 1) / (2.0L * n));
     const double tol = 1.5e-15;
+    // table variable u (w or m) -> m
+    auto m_of_u = [&](long double u) { return T.var_is_w ? 2 * u * u : u; };
     for (int i = 0; i < n_int; i++) {
-        const long double wc = (i + 0.5L) * step;
-        const double mc = (double)(2 * wc * wc);  // the double the kernel subtracts
+        const long double uc = (i + 0.5L) * step;
+        const double mc = (double)m_of_u(uc);  // the double the kernel subtracts
         for (int lv = 2; lv >= 0 && M.level[i] < 0; lv--) {
             const long double zr = 0.5L + lv + 0.01L;
-            const long double wl = (i + 0.5L - zr) * step, wh = (i + 0.5L + zr) * step;
-            if (!(wl > 0) || !(wh < 1))
+            // (nothing to cover left of u = 0: the table variable is never negative)
+            const long double wl = fmaxl((i + 0.5L - zr) * step, T.var_is_w ? 1e-6L * step : 0.0L), wh = (i + 0.5L + zr) * step;
+            if (T.var_is_w ? !(wh < 1) : !(wh < 2))
                 continue;
-            const long double dl = 2 * wl * wl - mc, dh = 2 * wh * wh - mc, scale = fmaxl(fabsl(dl), fabsl(dh));
+            const long double dl = m_of_u(wl) - mc, dh = m_of_u(wh) - mc, scale = fmaxl(fabsl(dl), fabsl(dh));
             long double dn[16], y[16], c[16];
             bool good = true;
             for (int k = 0; k < n && good; k++) {
                 const long double d = 0.5L * (dl + dh) + 0.5L * (dh - dl) * cheb[k];
                 dn[k] = d / scale;
-                good = G_of_u(st, 1, sqrtl((mc + d) / 2), y[k]);
+                good = G_of_u(st, 0, (long double)mc + d, y[k]);
             }
             if (!good || !solve_vandermonde(n, dn, y, c))
                 continue;
@@ -318,9 +321,9 @@ inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTab
             std::vector<long double> gt(ntest);
             std::vector<double> mt(ntest);
             for (int q = 0; q < ntest && good; q++) {
-                const long double w = (i + 0.5L - zr + 2 * zr * (q + 0.5L) / ntest) * step;
-                mt[q] = (double)(2 * w * w);  // the kernel holds m as a double
-                good = G_of_u(st, 1, sqrtl((long double)mt[q] / 2), gt[q]);
+                const long double u = wl + (wh - wl) * (q + 0.5L) / ntest;
+                mt[q] = (double)m_of_u(u);  // the kernel holds m as a double
+                good = G_of_u(st, 0, (long double)mt[q], gt[q]);
                 gmax = fmaxl(gmax, fabsl(gt[q]));
             }
             for (int q = 0; q < ntest && good; q++) {
@@ -345,7 +348,8 @@ inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTab
 // >= `lv`; n_int if there is none.
 inline int mpoly_first_ok(const MPolyTable& M, const RadialTable& T, double m_reach, int lv)
 {
-    const int last = std::min(T.n_int - 1, (int)(std::sqrt(m_reach / 2) * (1 + 1e-9) * T.inv_step) + 2);
+    const double u_reach = (T.var_is_w ? std::sqrt(m_reach / 2) : m_reach) * (1 + 1e-9);
+    const int last = std::min(T.n_int - 1, (int)(u_reach * T.inv_step) + 2);
     int first = T.n_int;
     for (int i = last; i >= 0 && M.level[i] >= lv; i--)
         first = i;

@@ -67,9 +67,9 @@ struct RayParams {
     double rx, ry, cx, cy;  // Denormalize: x = X*rx + cx, y = Y*ry + cy   (transformer.py:202-203)
     double rx32, ry32, cx32, cy32;  // the same times 32 (exact): kernels produce cv2's 32*x directly
     double n_int_f;                 // (double)n_int
-    // Second table for var_is_w plans (radial_fit.hpp: fit_mpoly_table): per w-interval a degree-6
-    // polynomial in delta = m - m_c (7 coefficients + m_c), so that tiles away from the image centre
-    // need no square root.  Null when absent.  mp_first_ok: every interval >= it (up to the plan's
+    // Second table (radial_fit.hpp: fit_mpoly_table): per interval a degree-6 polynomial in
+    // delta = m - m_c (7 coefficients + m_c), so that tiles away from the image centre need no fp64
+    // square root (w-tables) and no fp64 index arithmetic.  Null when absent.  mp_first_ok: every interval >= it (up to the plan's
     // reach) is valid at the level the lanes need; inv_step_f: (float)inv_step for the fp32 index.
     const double* radial_m;
     int mp_first_ok;
