@@ -1,6 +1,8 @@
 // kernels.hpp -- declarations shared by kernels.hip (device code) and plan.hip (host C ABI).
 #pragma once
 
+#include <vector>
+
 #include "v1c_core.hpp"
 
 namespace v1c {
@@ -34,7 +36,10 @@ size_t tile_box_bytes(const Geom& g);
 hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream);
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
-                                bool shared_entry, hipStream_t stream);
+                                bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
+                                hipStream_t stream);
+int tile_lean_half_dwords(int half_dwords);
+std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int half_dwords);
 
 // merge=True of apply_lr (remapper.py:485-497)
 hipError_t launch_anaglyph(const uint8_t* left, int64_t left_pitch, const uint8_t* right, int64_t right_pitch, int h, int w,

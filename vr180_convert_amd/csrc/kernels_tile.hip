@@ -96,7 +96,28 @@ struct TileBox {
     int magic;     // ceil(2^20 / cpr): floor(ch / cpr) == (ch * magic) >> 20 for ch < 16k, cpr <= 64 (chunk map)
 };
 
+// ceil(2^20 / cpr) for cpr = 1 .. kMaxCpr (a wave-uniform table read instead of an integer division,
+// which the compiler expands to ~25 vector instructions)
+struct ChunkMagicLut {
+    int v[kMaxCpr + 1];
+    constexpr ChunkMagicLut() : v{}
+    {
+        for (int q = 1; q <= kMaxCpr; q++)
+            v[q] = (int)(((1u << 20) + (unsigned)q - 1u) / (unsigned)q);
+    }
+};
+__device__ const ChunkMagicLut kChunkMagic{};
+
 constexpr int kTabSlice = 64;  // radial-table entries a workgroup may keep in LDS (4 KB)
+
+// Tiles the lean batch kernel takes (k_ray_lin3_batch_lean), as far as the plan can tell: interior, table
+// slice and box fit.  One definition for the kernel's own test and for the host's list of the
+// remaining tiles (tile_rest_list), which the general kernel then serves.
+__host__ __device__ inline bool lean_static_ok(int cpr, int nrows, int nidx, int interior, int half_dwords)
+{
+    return interior != 0 && nidx > 0 && nidx <= kTabSlice && cpr > 0 && cpr <= kMaxCpr && nrows * cpr <= 1024 &&
+           nrows * (cpr * 4 + 4) <= half_dwords;
+}
 constexpr int kUnitsPerBlock = V1C_UPB;  // units sharing the map that one workgroup serves (BOXES = 1)
 
 struct LaneCoords {
@@ -273,8 +294,14 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
             // cvRound by the 1.5 * 2^23 trick (two full-rate instructions instead of v_rndne_f32 +
             // v_cvt_i32_f32): the add rounds to the nearest integer, ties to even, exactly like
             // rint(); valid for |32 x| < 2^22, and interior coordinates are inside the source (< 2^20)
-            L.sx[k] = __float_as_int(fxk + 12582912.0f) - 0x4B400000;
-            L.sy[k] = __float_as_int(fyk + 12582912.0f) - 0x4B400000;
+            // INTERIOR == 2: nothing is known about the tile yet -- the coordinates are clamped into
+            // the trick's range (NaN -> lower bound), which leaves every coordinate inside a source
+            // (< 2^15 px) untouched; the caller derives "interior" from the bounding box of ALL
+            // pixels and redoes the tile with INTERIOR = 0 when it is not.
+            const float ax = INTERIOR == 2 ? __builtin_amdgcn_fmed3f(fxk, -4194303.0f, 4194303.0f) : fxk;
+            const float ay = INTERIOR == 2 ? __builtin_amdgcn_fmed3f(fyk, -4194303.0f, 4194303.0f) : fyk;
+            L.sx[k] = __float_as_int(ax + 12582912.0f) - 0x4B400000;
+            L.sy[k] = __float_as_int(ay + 12582912.0f) - 0x4B400000;
             continue;
         }
         // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
@@ -341,6 +368,55 @@ __device__ __forceinline__ bool box_fits(const TileBox& b, const uint8_t* src, u
     const int lpw = b.cpr * 4 + 4;
     return (b.cpr > 0) & (b.cpr <= kMaxCpr) & (b.nrows * b.cpr <= max_chunks) & (b.nrows * lpw <= box_dwords) &
            (((((uintptr_t)src) | spitch) & 3) == 0);
+}
+
+// ---- bounding box of ALL of the tile's pixels (no validity masks), K = 2 ----
+// Four minima (x, y, -x, -y of cv2's fixed point, shifted to pixels at the end) in 10 VALU
+// instructions per wave: v_permlane32_swap / v_permlane16_swap (gfx950) fold two registers' halves
+// into one with a single v_min each -- after them row r of 16 lanes holds quantity r's partial
+// minimum -- and four v_min_i32_dpp row_ror steps finish each row.  (The masked reduction above
+// costs 48 + 16 selects.)  xmin / xmax / ymin / ymax come back wave-uniform in SGPRs.
+struct BoxAll {
+    int xmin, xmax, ymin, ymax;  // source pixel of the top-left tap, over all 1024 pixels
+};
+
+template <int CTRL>
+__device__ __forceinline__ int row_min_step(int v)
+{
+    return min(v, __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true));
+}
+
+template <int NW>
+__device__ __forceinline__ BoxAll reduce_box_all(const LaneCoords& L, int* red, int tid)
+{
+    const int a = min(min(L.sx[0], L.sx[1]), min(L.sx[2], L.sx[3]));
+    const int b = min(min(L.sy[0], L.sy[1]), min(L.sy[2], L.sy[3]));
+    const int c = -max(max(L.sx[0], L.sx[1]), max(L.sx[2], L.sx[3]));
+    const int d = -max(max(L.sy[0], L.sy[1]), max(L.sy[2], L.sy[3]));
+    // lanes 0-31: a folded over both halves, lanes 32-63: b folded (likewise c | d)
+    const auto ab = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    const auto cd = __builtin_amdgcn_permlane32_swap((unsigned)c, (unsigned)d, false, false);
+    const int pab = min((int)ab[0], (int)ab[1]), pcd = min((int)cd[0], (int)cd[1]);
+    // rows of 16 lanes: a | c | b | d
+    const auto q = __builtin_amdgcn_permlane16_swap((unsigned)pab, (unsigned)pcd, false, false);
+    int v = min((int)q[0], (int)q[1]);
+    v = row_min_step<0x121>(v);  // row_ror:1
+    v = row_min_step<0x122>(v);  // row_ror:2
+    v = row_min_step<0x124>(v);  // row_ror:4
+    v = row_min_step<0x128>(v);  // row_ror:8: every lane of a row holds the row's minimum
+    if ((tid & 15) == 0)
+        red[(tid >> 6) * 4 + ((tid >> 4) & 3)] = v;
+    __syncthreads();
+    int m0 = red[0], m1 = red[1], m2 = red[2], m3 = red[3];
+#pragma unroll
+    for (int w = 1; w < NW; w++)
+        m0 = min(m0, red[4 * w]), m1 = min(m1, red[4 * w + 1]), m2 = min(m2, red[4 * w + 2]), m3 = min(m3, red[4 * w + 3]);
+    BoxAll r;
+    r.xmin = __builtin_amdgcn_readfirstlane(m0) >> 5;
+    r.xmax = (-__builtin_amdgcn_readfirstlane(m1)) >> 5;
+    r.ymin = __builtin_amdgcn_readfirstlane(m2) >> 5;
+    r.ymax = (-__builtin_amdgcn_readfirstlane(m3)) >> 5;
+    return r;
 }
 
 struct Staged {
@@ -838,7 +914,10 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
 
 // PAIR = 1: the launch has at most 2 units per workgroup (apply_lr's two eyes): only the
 // straight-line path is compiled, which needs ~30 fewer VGPRs (6 waves per SIMD instead of 4).
-template <int VAR_W, int ROT, int K, int OWN, int PAIR, int NT, typename WPtr>
+// LEAN = 1 (k_ray_lin3_batch_lean): only the lean batch path below is compiled and tiles that are
+// not eligible for it (lean_static_ok) exit at once; the host launches the general kernel on the list
+// of exactly those tiles (launch_tile_k).
+template <int VAR_W, int ROT, int K, int OWN, int PAIR, int NT, int LEAN, typename WPtr>
 __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitArgs& ua, const TileBox* __restrict__ boxes, int n_units,
                                                 int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw, int half_dwords,
                                                 double* tabw, WPtr wtab)
@@ -859,6 +938,12 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     const int4 b0 = bp[0], b1 = bp[1];
     b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y, b.interior = b1.z, b.magic = b1.w;
     const bool tail = box_touches_image_end(b, g);
+    // lean batch path (further down): bilinear, more than two units, an interior tile whose table slice
+    // and box fit -- the box is the same for all units, only the alignment of a source can differ
+    // (the host launches the lean kernel only when every source is dword-aligned and every group has
+    // more than two units: launch_tile_k)
+    if (LEAN && !lean_static_ok(b.cpr, b.nrows, b.nidx, b.interior, half_dwords))
+        return;
     ChunkMap M;
     make_chunk_map<NT>(b, tid, M);
 
@@ -897,8 +982,61 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     V1C_STAMP(1);  // wait for the loads + expand + LDS stores
     __syncthreads();
     V1C_STAMP(2);  // barrier
-    LaneCoords L;
     const bool interior = tab_lds & (b.interior != 0);  // wave-uniform: no validity / inside tests needed
+    // Interior tile of a bilinear batch whose every unit can be staged (the common case by far): a
+    // lean path with its own coordinate evaluation, which afterwards keeps only the per-pixel tap
+    // addresses and blend weights live (not the coordinates, masks and fit flags of the general loop
+    // further down).  Compiled into a kernel of its own (k_ray_lin3_batch_lean) so that its register
+    // count, not the general loop's, sets the occupancy of the batch workloads.
+    // Same buffer rotation as the general loop: unit v in buffer v & 1, one barrier per unit.
+    if (LEAN) {
+        {
+            const uint32_t lpw4 = (uint32_t)(b.cpr * 4 + 4) * 4u;
+            uint32_t ta[kPX];
+            BlendW W[kPX];
+            {
+                LaneCoords L;
+                if (OWN == 0 && mpoly)
+                    lane_coords<VAR_W, ROT, K, 0, 1, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+                else
+                    lane_coords<VAR_W, ROT, K, OWN, 1, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+#pragma unroll
+                for (int k = 0; k < kPX; k++) {
+                    ta[k] = __umul24((L.sy[k] >> 5) - b.y0, lpw4) + (uint32_t)((L.sx[k] >> 5) - b.x0) * 4u;  // byte offset in a box buffer
+                    W[k] = blend_weights(L.sx[k], L.sy[k]);
+                }
+            }
+            const lds_u32_ptr lbox = (lds_u32_ptr)boxw;
+            for (int u = 0; u < nu; u++) {
+                const int z = z0 + u;
+                if (u >= 1)
+                    __syncthreads();
+                if (u + 1 < nu && u + 1 >= 2)
+                    stage_store(M, S0, boxw + ((u + 1) & 1) * half_dwords);
+                if (u + 2 < nu) {
+                    const uint8_t* __restrict__ src = ua.u[z + 2].src;
+                    const uint32_t spitch = (uint32_t)ua.u[z + 2].src_pitch;
+                    if (tail)
+                        stage_load<true, false>(M, src, spitch, (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u, S0);
+                    else
+                        stage_load<false, false>(M, src, spitch, 0u, S0);
+                }
+                const uint32_t base = (uint32_t)(u & 1) * (uint32_t)half_dwords * 4u;
+                uint32_t pix[kPX];
+#pragma unroll
+                for (int k = 0; k < kPX; k++) {
+                    const lds_u32_ptr pa = (lds_u32_ptr)((const __attribute__((address_space(3))) char*)lbox + (ta[k] + base));
+                    const lds_u32_ptr pb = (lds_u32_ptr)((const __attribute__((address_space(3))) char*)pa + lpw4);
+                    pix[k] = blend3<4>(pa[0], pa[1], pb[0], pb[1], W[k]);
+                }
+                store_interior(ua, z, t, pix);
+            }
+            return;
+        }
+    }
+    if (LEAN)
+        return;
+    LaneCoords L;
     if (OWN == 0 && interior && mpoly)
         lane_coords<VAR_W, ROT, K, 0, 1, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (interior)
@@ -1010,8 +1148,11 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, int& tx, int& ty)
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
 template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR>
+// `tile_list` (BOXES = 1, may be null): blockIdx.x indexes this list of tiles (ty << 16 | tx) instead
+// of the tile grid; `tiles_x` = tile columns of the full grid then.
 __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
-                                                       int upb, int half_dwords, unsigned tiles_x_magic)
+                                                       int upb, int half_dwords, unsigned tiles_x_magic,
+                                                       const uint32_t* __restrict__ tile_list, int tiles_x)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) int red[16];
@@ -1019,11 +1160,17 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
     const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
     if (BOXES) {
         int tx, ty;
-        xcd_tile(tiles_x_magic, tx, ty);
+        if (tile_list) {
+            const uint32_t v = tile_list[blockIdx.x];
+            tx = (int)(v & 0xffffu), ty = (int)(v >> 16);
+        } else {
+            xcd_tile(tiles_x_magic, tx, ty);
+            tiles_x = gridDim.x;
+        }
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
         extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, gridDim.x, dyn_box,
-                                           half_dwords, tabw, wtab);
+        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT, 0>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, tiles_x, dyn_box,
+                                                         half_dwords, tabw, wtab);
     } else {
         __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
         const Geom& g = c.g;
@@ -1038,6 +1185,47 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
         RowCol rc;
         load_rowcol<ROT>(P, t.xc, t.jc, rc);
         LaneCoords L;
+        // Fast attempt (bilinear, OWN = 0: the host proved that no pixel of these units leaves the
+        // validated part of the radial table): coordinates without any validity logic, bounding box
+        // of all 1024 pixels, and if that box lies inside the source the tile is "interior" --
+        // unpredicated taps, unconditional stores.  Anything else (tiles cut by the destination's
+        // edge, footprints leaving the source) falls through to the general code below.
+        // PAIR doubles as "the m-polynomial table is valid for every unit of this launch" here.
+        const bool tile_full = ((int)(blockIdx.x + 1) * kTW <= g.dst_w) & ((int)(blockIdx.y + 1) * (NT / kLanesX) <= g.dst_h);
+        if (K == 2 && OWN == 0 && tile_full) {
+            if (PAIR)
+                lane_coords<VAR_W, ROT, K, 0, 2, 1>(c, ua, z, rc, kPX, P.radial_m, 0, P.n_int, L);
+            else
+                lane_coords<VAR_W, ROT, K, 0, 2, 0>(c, ua, z, rc, kPX, P.radial, 0, P.n_int, L);
+            const BoxAll ba = reduce_box_all<NT / 64>(L, red, tid);
+            if ((ba.xmin >= 0) & (ba.xmax < g.src_w - 2) & (ba.ymin >= 0) & (ba.ymax < g.src_h - 1)) {
+                TileBox fb;
+                fb.x0 = ba.xmin & ~3, fb.y0 = ba.ymin;
+                fb.cpr = (ba.xmax + 2 - fb.x0 + 3) >> 2, fb.nrows = ba.ymax - ba.ymin + 2;
+                fb.idx0 = fb.nidx = 0, fb.interior = 1;
+                fb.magic = kChunkMagic.v[min(fb.cpr, kMaxCpr)];  // (cpr > kMaxCpr: the box does not fit, magic unused)
+                if (box_fits(fb, src, spitch, 4 * NT, kBoxBytes / 4)) {
+                    ChunkMap M;
+                    make_chunk_map<NT>(fb, tid, M);
+                    Staged S;
+                    if (box_touches_image_end(fb, g))
+                        stage_load<true, false>(M, src, spitch, src_bytes, S);
+                    else
+                        stage_load<false, false>(M, src, spitch, src_bytes, S);
+                    stage_store(M, S, boxw);
+                    __syncthreads();
+                    Taps2 T;
+                    uint32_t pix[kPX];
+                    read_taps_lds<true>(L, fb, boxw, T);
+                    blend_taps(T, L, pix);
+                    store_interior(ua, z, t, pix);
+                } else {  // box too large for LDS (strong minification): gather from global memory
+                    sample_and_store<K>(c, ua, z, t, L, fb, false, boxw, wtab, src, spitch);
+                }
+                return;
+            }
+            __syncthreads();  // `red` is reused below
+        }
         lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
         const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
         const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
@@ -1053,6 +1241,21 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
             c.tile_flags[t.flag_tile] = 1;
         sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, wtab, src, spitch);
     }
+}
+
+// The lean batch path of shared_map_tile as a kernel of its own (bilinear, plan-time boxes, more than
+// two units per workgroup): launched over the whole tile grid; k_ray_lin3_tile<..., PAIR = 0> then
+// runs on the list of the tiles this one leaves out.
+template <int VAR_W, int ROT, int OWN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : 6), 8))) void k_ray_lin3_batch_lean(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
+                                                             int upb, int half_dwords, unsigned tiles_x_magic)
+{
+    __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
+    int tx, ty;
+    xcd_tile(tiles_x_magic, tx, ty);
+    shared_map_tile<VAR_W, ROT, 2, OWN, 0, 256, 1>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, gridDim.x, dyn_box, half_dwords, tabw,
+                                                   (glb_u32_ptr) nullptr);
 }
 
 static int taps_of(int interp)
@@ -1103,6 +1306,31 @@ int tile_half_dwords(const void* host_boxes, size_t n_tiles)
     return (m + 3) & ~3;
 }
 
+// Box buffer size (dwords) of the lean batch kernel: capped so that 6 workgroups -- what its 80 VGPRs
+// allow -- also fit the CU's 160 KB of LDS (2 buffers + 4 KB table slice each); tiles with larger
+// boxes go to the general kernel.
+int tile_lean_half_dwords(int half_dwords)
+{
+    return std::min(half_dwords, 2816);
+}
+
+// tiles the lean batch kernel leaves to the general one, as ty << 16 | tx (row-major order)
+std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int half_dwords)
+{
+    const TileBox* b = (const TileBox*)host_boxes;
+    const dim3 d = tile_grid(g, tile_threads(g), 1);
+    std::vector<uint32_t> out;
+    if (d.x > 0xffffu || d.y > 0xffffu)
+        return out;
+    for (unsigned ty = 0; ty < d.y; ty++)
+        for (unsigned tx = 0; tx < d.x; tx++) {
+            const TileBox& q = b[(size_t)ty * d.x + tx];
+            if (!lean_static_ok(q.cpr, q.nrows, q.nidx, q.interior, half_dwords))
+                out.push_back(ty << 16 | tx);
+        }
+    return out;
+}
+
 // plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
 template <int K, int NT>
 static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, bool shared_entry, hipStream_t stream)
@@ -1145,7 +1373,7 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry,
 
 template <int K>
 static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, int half_dwords,
-                          bool shared_entry, hipStream_t stream)
+                          bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, hipStream_t stream)
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     static const int upb_max = [] {  // V1C_UPB=<n>: A/B override of the units per workgroup
@@ -1154,18 +1382,45 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
         return v >= 1 && v <= kUnitsPerBlock ? v : kUnitsPerBlock;
     }();
     const int upb = bx ? std::min(n_units, upb_max) : 1;
-    const bool pair = bx && upb <= 2;
+    // the template's PAIR slot: with boxes "at most 2 units per workgroup", without (one unit per
+    // workgroup anyway) "the m-polynomial table serves every pixel of every unit" (bilinear, OWN = 0)
+    const bool pair = bx ? upb <= 2 : (K == 2 && shared_entry && mpoly_all && c.ray.radial_m != nullptr);
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
     const size_t lds = bx ? (size_t)half_dwords * 8 + 16 : 0;  // two box buffers
-#define V1C_TILE_P(VW, RT, BX, OW, PR) \
-    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords, \
-                       (unsigned)(0x100000000ull / grid.x) + 1u)
-#define V1C_TILE_O(VW, RT, BX, OW)          \
-    do {                                    \
-        if (BX && pair)                     \
-            V1C_TILE_P(VW, RT, BX, OW, BX); \
-        else                                \
-            V1C_TILE_P(VW, RT, BX, OW, 0);  \
+    // batches (more than two units per workgroup) of a bilinear plan: the interior tiles go to the lean
+    // kernel, everything else stays with the general one (same grid; each skips the other's tiles)
+    static const bool lean_off = [] {
+        const char* e = std::getenv("V1C_DISABLE_LEAN");
+        return e && e[0] == '1';
+    }();
+    // (every group with more than two units, every source dword-aligned, tile coordinates fit 16 bits)
+    bool lean = bx && K == 2 && upb > 2 && !lean_off && rest_list != nullptr && (n_units % upb == 0 || n_units % upb > 2);
+    for (int k = 0; k < n_units && lean; k++)
+        lean = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
+    // the few remaining tiles are served two units per workgroup (the pair instantiation): a workgroup
+    // looping over 8 units would be one long serial chain with nothing to overlap it
+    const dim3 rest_grid((unsigned)std::max(n_rest, 1), 1, (unsigned)((n_units + 1) / 2));
+    const size_t lean_lds = (size_t)lean_half * 8 + 16;
+    const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
+#define V1C_TILE_P(VW, RT, BX, OW, PR)                                                                                                \
+    do {                                                                                                                              \
+        if (lean) {                                                                                                                   \
+            hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), grid, block, lean_lds, stream, c, ua, bx, n_units, upb, lean_half, \
+                               xmagic);                                                                                               \
+            if (n_rest > 0)                                                                                                           \
+                hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, BX>), rest_grid, block, lds, stream, c, ua, bx, n_units, 2,    \
+                                   half_dwords, xmagic, rest_list, (int)grid.x);                                                      \
+        } else {                                                                                                                      \
+            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb,           \
+                               half_dwords, xmagic, (const uint32_t*)nullptr, (int)grid.x);                                           \
+        }                                                                                                                             \
+    } while (0)
+#define V1C_TILE_O(VW, RT, BX, OW)                       \
+    do {                                                 \
+        if (pair)                                        \
+            V1C_TILE_P(VW, RT, BX, OW, (BX || !OW) ? 1 : 0); \
+        else                                             \
+            V1C_TILE_P(VW, RT, BX, OW, 0);               \
     } while (0)
 #define V1C_TILE(VW, RT)                \
     do {                                \
@@ -1199,14 +1454,17 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 // 512-thread workgroup per CU it cannot hide LDS latency and its 128-byte weight rows land on 8
 // banks -- 6x slower than reading the weights through L2.  See DESIGN.md 4.5.)
 // `shared_entry`: no lane needs more than pixel 1's table entry (proved by the caller).
+// `mpoly_all` (boxes == null only): the m-polynomial table is valid on every interval these units reach.
+// `rest_list` / `n_rest` / `lean_half` (boxes != null; list may be null): device copy of tile_rest_list() and the box
+// buffer size (dwords) it was made for.
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
-                                bool shared_entry, hipStream_t stream)
+                                bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, hipStream_t stream)
 {
     const TileBox* bx = (const TileBox*)boxes;
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, stream); break;
-    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, stream); break;
-    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, stream); break;
+    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, stream); break;
+    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, stream); break;
+    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -169,11 +169,17 @@ struct v1c_plan {
     int tiles = 0;
     void* tile_boxes = nullptr;   // per-tile source boxes of the tiled kernel (plan rotation)
     int half_dwords = 256;        // LDS dwords per box buffer of the shared-map tile kernel
+    const uint32_t* rest_list = nullptr;  // tiles the lean batch kernel leaves to the general one (device)
+    int n_rest = 0;
+    int lean_half = 256;          // box buffer dwords of the lean batch kernel (<= half_dwords)
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     bool disable_shared_entry = false;  // V1C_DISABLE_SHARED_ENTRY=1: keep the per-pixel table fallback compiled in
     bool disable_mpoly = false;         // V1C_DISABLE_MPOLY=1: no m-polynomial table (every tile takes the square root)
     bool plan_shared_entry = false;     // one table entry serves a lane's 4 pixels (ray_entry_is_shared)
     double ray_step = 0;                // largest angle between horizontally adjacent output rays
+    int mp_valid_upto = -1;             // m-polynomial table (when uploaded): intervals 0 .. this are all valid at the
+                                        // level a lane needs (shared_entry_level)
+    double m_reach_norot = 0;           // largest m an unrotated ray reaches
     std::vector<void*> allocs;
 };
 
@@ -349,6 +355,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             r.rx = a.rx, r.ry = a.ry, r.cx = a.cx, r.cy = a.cy;
             r.rx32 = 32.0 * a.rx, r.ry32 = 32.0 * a.ry, r.cx32 = 32.0 * a.cx, r.cy32 = 32.0 * a.cy;
             r.n_int_f = (double)r.n_int;
+            p->m_reach_norot = ht.m_reach;
             p->ray_no_rot_safe = !a.has_rot && ray_reach_is_safe(p->table, ht.m_reach);
             p->front_hemisphere = ht.front_hemisphere;
             p->ray_plan_rot_safe = a.has_rot && ht.front_hemisphere && ray_reach_is_safe(p->table, rotated_reach(a.rot));
@@ -368,6 +375,9 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         return rc;
                     }
                     r.mp_first_ok = first;
+                    p->mp_valid_upto = -1;
+                    while (p->mp_valid_upto + 1 < r.n_int && mp.level[p->mp_valid_upto + 1] >= lv)
+                        p->mp_valid_upto++;
                 }
             }
             if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
@@ -424,6 +434,20 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     return fail(V1C_E_HIP, std::string("tile boxes readback: ") + hipGetErrorString(e));
                 }
                 p->half_dwords = tile_half_dwords(hb.data(), hb.size() / 32);
+                {
+                    p->lean_half = tile_lean_half_dwords(p->half_dwords);
+                    const std::vector<uint32_t> rest = tile_rest_list(hb.data(), g, p->lean_half);
+                    const dim3 full((unsigned)((g.dst_w + 63) / 64), (unsigned)((g.dst_h + 15) / 16));
+                    if (full.x <= 0xffffu && full.y <= 0xffffu) {
+                        if ((rc = upload(p, rest, &p->rest_list))) {
+                            v1c_plan_destroy(p);
+                            return rc;
+                        }
+                        p->n_rest = (int)rest.size();
+                    }
+                    if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+                        std::fprintf(stderr, "[v1c] lean batch kernel: %d of %zu tiles left to the general kernel\n", p->n_rest, hb.size() / 32);
+                }
                 if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1') {
                     // histogram of the LDS dwords each tile box needs
                     const int* bi = (const int*)hb.data();
@@ -528,6 +552,9 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             // `shared_entry` (one table entry per lane, no per-pixel fallback in the kernel)
             bool need_fixup = !(p->ray_no_rot_safe || p->ray_plan_rot_safe);
             bool shared_entry = p->plan_shared_entry;
+            // the m-polynomial table (no fp64 index arithmetic) serves a launch of overriding rotations
+            // when every interval up to each unit's reach is valid at the level the lanes need
+            bool mpoly_all = any_rot && p->ctx.ray.radial_m != nullptr;
             if (any_rot) {
                 need_fixup = !p->front_hemisphere;
                 shared_entry = p->front_hemisphere;
@@ -538,13 +565,20 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                     need_fixup = !covered;
                     shared_entry = shared_entry && covered &&
                                    (rotated ? ray_entry_is_shared(p->table, rotated_reach(r), p->ray_step) : p->plan_shared_entry);
+                    if (mpoly_all) {  // (same interval bound as mpoly_first_ok: reach + 2 for the fp32 index)
+                        const double mr = rotated ? rotated_reach(r) : p->m_reach_norot;
+                        const double u_reach = (p->table.var_is_w ? std::sqrt(mr / 2) : mr) * (1 + 1e-9);
+                        mpoly_all = covered && std::min(p->table.n_int - 1, (int)(u_reach * p->table.inv_step) + 2) <= p->mp_valid_upto;
+                    }
                 }
                 shared_entry = shared_entry && !need_fixup;
+                mpoly_all = mpoly_all && shared_entry;
             }
             if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
-                                             shared_entry && !p->disable_shared_entry, st));
+                                             shared_entry && !p->disable_shared_entry, mpoly_all && !p->disable_mpoly,
+                                             any_rot ? nullptr : p->rest_list, p->n_rest, p->lean_half, st));
             } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }
