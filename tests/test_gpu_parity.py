@@ -525,6 +525,70 @@ def test_shared_map_unit_loop_mixed_alignment(V, oracle_mod, dev, interp):
         assert np.array_equal(dsts[f].cpu().numpy(), want[f]), (interp, f)
 
 
+LEAN_BATCH = {
+    # name: (src (H, W), out (W, H), spec, radius): aligned sources, 11 units = groups of 8 + 3
+    "interior_mostly": ((512, 512), (512, 400), [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI], 256.0),
+    "m_table": ((384, 384), (448, 384), [("equirect_enc", True), CS.EQUI], 192.0),
+    "diagonal_big_boxes": ((700, 700), (576, 512), [("equirect_enc", True), ("rot_quat", CS.rotvec_quat([0, 0, 0.8])), CS.EQUI], 350.0),
+    "footprints_leave_source": ((300, 300), (320, 256), [("equirect_enc", True), ("zoom", 0.7), CS.EQUI], 150.0),
+    "minified_boxes_do_not_fit": ((1500, 1500), (128, 96), [("equirect_enc", True), CS.EQUI], 750.0),
+}
+
+
+@pytest.mark.parametrize("name", list(LEAN_BATCH))
+def test_lean_batch_kernel_and_rest_tiles(V, oracle_mod, dev, name):
+    """Shared-map batches of more than two units per workgroup: interior tiles run in the lean batch
+    kernel, the tiles it leaves out (edges of the destination, footprints leaving the source, boxes
+    beyond its LDS buffers) in the pair kernel on the plan's tile list -- every byte equals the oracle's."""
+    from vr180_convert_amd.synth import noise_disc
+
+    (sh, sw), out, spec, radius = LEAN_BATCH[name]
+    imgs = [noise_disc(sh, sw, 30 + f) for f in range(11)]
+    for im in imgs:
+        im[::9, ::7] = 200
+    want = oracle_mod.apply(spec, imgs, size_output=out, interpolation=1, radius=radius, border_value=(5, 6, 7))
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    dsts = [torch.full((out[1], out[0], 3), 9, dtype=torch.uint8, device=dev) for _ in imgs]
+    assert V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=radius, interpolation=1, boarder_value=(5, 6, 7)) == ["ray"]
+    torch.cuda.synchronize()
+    for f in range(11):
+        assert np.array_equal(dsts[f].cpu().numpy(), want[f]), (name, f)
+
+
+ROT_UNITS = {
+    # name: (src (H, W), out (W, H), chain before / after the rotation, radius, rotation vectors)
+    "small_calibration": ((320, 320), (320, 320), [], [CS.EQUI], 160.0, [[0.02, -0.01, 0.03], [-0.03, 0.02, 0.0], [0.0, 0.0, -0.04]]),
+    "partial_tiles": ((300, 280), (333, 217), [], [CS.EQUI], 140.0, [[0.05, 0.0, 0.0], [0.0, -0.06, 0.02]]),
+    "w_table": ((320, 320), (384, 320), [], [("poly", [0, 1, -0.1]), CS.EQUI], 160.0, [[0.03, 0.01, 0.0], [0.0, 0.02, -0.05]]),
+    "rays_leave_source": ((300, 300), (320, 256), [], [("zoom", 0.7), CS.EQUI], 150.0, [[0.1, 0.0, 0.0], [0.0, -0.2, 0.1]]),
+    "large_rotation": ((400, 400), (384, 384), [], [CS.EQUI], 200.0, [[0.0, 0.9, 0.0], [0.5, -0.4, 0.8], [0.0, 0.0, 1.5]]),
+}
+
+
+@pytest.mark.parametrize("name", list(ROT_UNITS))
+def test_per_unit_rotation_tile_paths(V, oracle_mod, dev, name):
+    """Units overriding the rotation (one unit per workgroup, box reduced in the kernel): tiles whose
+    bounding box of all pixels lies inside the source take the unpredicated path, the others the
+    general one; with and without the m-polynomial table; rotations from calibration-sized to large."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    (sh, sw), out, pre, post, radius, rvecs = ROT_UNITS[name]
+    quats = [CS.rotvec_quat(r) for r in rvecs]
+    imgs = [noise_disc(sh, sw, 50 + f) for f in range(len(quats))]
+    for im in imgs:
+        im[::6, ::11] = 180
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    dsts = [torch.full((out[1], out[0], 3), 9, dtype=torch.uint8, device=dev) for _ in imgs]
+    base = CS.to_product([("equirect_enc", True), *pre, ("rot_quat", (1.0, 0.0, 0.0, 0.0)), *post])
+    assert V.remap_tensors(base, srcs, dsts, radius=radius, interpolation=1, boarder_value=(1, 2, 3), rotations=quats) == ["ray"]
+    torch.cuda.synchronize()
+    for f, q in enumerate(quats):
+        spec = [("equirect_enc", True), *pre, ("rot_quat", q), *post]
+        want = oracle_mod.apply(spec, [imgs[f]], size_output=out, interpolation=1, radius=radius, border_value=(1, 2, 3))[0]
+        assert np.array_equal(dsts[f].cpu().numpy(), want), (name, f)
+
+
 def test_plan_run_is_graph_capturable(V, dev):
     """v1c_plan_run neither allocates nor synchronises -- a warmed-up call can be
     captured into a HIP graph on a side stream and replayed."""
@@ -550,8 +614,37 @@ def test_plan_run_is_graph_capturable(V, dev):
         assert torch.equal(out, ref)
 
 
+def test_batch_plan_run_is_graph_capturable(V, oracle_mod, dev):
+    """The same for a shared-map batch: two launches per run (the lean batch kernel and the pair kernel
+    on the plan's list of remaining tiles)."""
+    from vr180_convert_amd.synth import noise_disc
+
+    size = 320
+    spec = [("equirect_enc", True), ("zoom", 0.8), CS.EQUI]
+    t = CS.to_product(spec)
+    imgs = [noise_disc(size, size, 70 + k) for k in range(5)]
+    want = oracle_mod.apply(spec, imgs, size_output=(size, size), interpolation=1, radius=size / 2)
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    dsts = [torch.empty_like(x) for x in srcs]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        V.remap_tensors(t, srcs, dsts, radius=size / 2, interpolation=1)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        V.remap_tensors(t, srcs, dsts, radius=size / 2, interpolation=1)
+    for _ in range(2):
+        for d in dsts:
+            d.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for k in range(5):
+            assert np.array_equal(dsts[k].cpu().numpy(), want[k]), k
+
+
 @pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_DISABLE_MPOLY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"},
-                                 {"V1C_DISABLE_FAST": "1"}],
+                                 {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_LEAN": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_variants_bit_exact(env):
     """The instantiations the default configuration does not reach (per-pixel table fallback,
