@@ -47,6 +47,9 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_XCD_SWIZZLE
 #define V1C_XCD_SWIZZLE 1
 #endif
+#ifndef V1C_LEAN_WAVES
+#define V1C_LEAN_WAVES 6  // waves per SIMD the lean batch kernel is compiled for (no rotation, OWN = 0)
+#endif
 #ifndef V1C_UPB
 #define V1C_UPB 8
 #endif
@@ -1247,7 +1250,7 @@ __global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua,
 // two units per workgroup): launched over the whole tile grid; k_ray_lin3_tile<..., PAIR = 0> then
 // runs on the list of the tiles this one leaves out.
 template <int VAR_W, int ROT, int OWN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : 6), 8))) void k_ray_lin3_batch_lean(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                              int upb, int half_dwords, unsigned tiles_x_magic)
 {
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
@@ -1399,7 +1402,12 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
         return e && e[0] == '1';
     }();
     // (every group with more than two units, every source dword-aligned, tile coordinates fit 16 bits)
-    bool lean = bx && K == 2 && upb > 2 && !lean_off && rest_list != nullptr && (n_units % upb == 0 || n_units % upb > 2);
+    static const bool lean_pair = [] {  // V1C_LEAN_PAIR=1: A/B switch, pairs through the lean kernel too
+        const char* e = std::getenv("V1C_LEAN_PAIR");
+        return e && e[0] == '1';
+    }();
+    bool lean = bx && K == 2 && !lean_off && rest_list != nullptr &&
+                (lean_pair ? (upb >= 2 && n_units % upb != 1) : (upb > 2 && (n_units % upb == 0 || n_units % upb > 2)));
     for (int k = 0; k < n_units && lean; k++)
         lean = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
     // the few remaining tiles are served two units per workgroup (the pair instantiation): a workgroup

@@ -434,6 +434,8 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     return fail(V1C_E_HIP, std::string("tile boxes readback: ") + hipGetErrorString(e));
                 }
                 p->half_dwords = tile_half_dwords(hb.data(), hb.size() / 32);
+                if (const char* e = std::getenv("V1C_HALF_CAP"); e && std::atoi(e) >= 256)  // A/B: cap the LDS box buffers
+                    p->half_dwords = std::min(p->half_dwords, std::atoi(e));
                 {
                     p->lean_half = tile_lean_half_dwords(p->half_dwords);
                     const std::vector<uint32_t> rest = tile_rest_list(hb.data(), g, p->lean_half);
