@@ -47,6 +47,9 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_XCD_SWIZZLE
 #define V1C_XCD_SWIZZLE 1
 #endif
+#ifndef V1C_PAIR_WAVES
+#define V1C_PAIR_WAVES 6  // waves per SIMD the pair kernel (bilinear, no rotation, OWN = 0) is compiled for
+#endif
 #ifndef V1C_LEAN_WAVES
 #define V1C_LEAN_WAVES 6  // waves per SIMD the lean batch kernel is compiled for (no rotation, OWN = 0)
 #endif
@@ -116,10 +119,11 @@ constexpr int kTabSlice = 64;  // radial-table entries a workgroup may keep in L
 // Tiles the lean batch kernel takes (k_ray_lin3_batch_lean), as far as the plan can tell: interior, table
 // slice and box fit.  One definition for the kernel's own test and for the host's list of the
 // remaining tiles (tile_rest_list), which the general kernel then serves.
+// (a box of up to TWO buffers is served too, single-buffered: see the lean path in shared_map_tile)
 __host__ __device__ inline bool lean_static_ok(int cpr, int nrows, int nidx, int interior, int half_dwords)
 {
     return interior != 0 && nidx > 0 && nidx <= kTabSlice && cpr > 0 && cpr <= kMaxCpr && nrows * cpr <= 1024 &&
-           nrows * (cpr * 4 + 4) <= half_dwords;
+           nrows * (cpr * 4 + 4) <= 2 * half_dwords;
 }
 constexpr int kUnitsPerBlock = V1C_UPB;  // units sharing the map that one workgroup serves (BOXES = 1)
 
@@ -521,11 +525,15 @@ struct BlendW {
 __device__ __forceinline__ BlendW blend_weights(int sx, int sy)
 {
     const uint32_t fq = sx & 31, fr = sy & 31;
-    const uint32_t wxp = (32u - fq) | (fq << 16);  // u16 pair (wx0, wx1); products stay below 2^16
-    const uint32_t ra = __umul24(wxp, 32u - fr), rb = __umul24(wxp, fr);
+    // u16 pair 64 * (wx0, wx1) = (2048 - 64 fq) | (64 fq) << 16 in one multiply-add; times wy0 / wy1 with
+    // the packed 16-bit multipliers (src1's low half for both lanes).  The one product that does not
+    // fit, 64 * 32 * 32 = 65536 (both fractions zero), saturates to 65535 (clamp) -- see blend3.
+    // All 1024 fraction pairs checked against the scalar form: tools/ubench/blend_weights_pk.hip.
+    const uint32_t wx64 = __umul24(fq, 0x3FFFC0u) + 2048u;
+    const uint32_t frc = 32u - fr;
     BlendW w;
-    w.wa = (ra << 6) - ((ra >> 10) & 1u);  // low half 1024 -> 65536 would carry: 0x00010000 - 1 = 0x0000ffff
-    w.wb = rb << 6;                        // (at most 992 per half)
+    asm("v_pk_mad_u16 %0, %1, %2, 0 op_sel_hi:[1,0,0] clamp" : "=v"(w.wa) : "v"(wx64), "v"(frc));
+    asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(w.wb) : "v"(wx64), "v"(fr));
     return w;
 }
 
@@ -954,7 +962,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         const uint8_t* __restrict__ src = ua.u[z].src;
         const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
-        const bool fits = box_fits(b, src, spitch, 4 * NT, half_dwords);
+        const bool fits = box_fits(b, src, spitch, 4 * NT, LEAN ? 2 * half_dwords : half_dwords);
         if (fits) {
             if (tail)
                 stage_load<true, !PAIR>(M, src, spitch, src_bytes, S);
@@ -964,9 +972,11 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         return fits;
     };
 
+    // lean kernel: a box larger than one buffer takes both, one unit at a time
+    const bool single = LEAN && b.nrows * (b.cpr * 4 + 4) > half_dwords;
     Staged S0, S1;
     const bool fit0 = issue(z0, S0);
-    const bool fit1 = nu > 1 ? issue(z0 + 1, S1) : false;
+    const bool fit1 = nu > 1 && !single ? issue(z0 + 1, S1) : false;
     const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
     typedef double __attribute__((ext_vector_type(2))) d2;
     d2 tv = {0.0, 0.0};
@@ -1010,21 +1020,15 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                 }
             }
             const lds_u32_ptr lbox = (lds_u32_ptr)boxw;
-            for (int u = 0; u < nu; u++) {
-                const int z = z0 + u;
-                if (u >= 1)
-                    __syncthreads();
-                if (u + 1 < nu && u + 1 >= 2)
-                    stage_store(M, S0, boxw + ((u + 1) & 1) * half_dwords);
-                if (u + 2 < nu) {
-                    const uint8_t* __restrict__ src = ua.u[z + 2].src;
-                    const uint32_t spitch = (uint32_t)ua.u[z + 2].src_pitch;
-                    if (tail)
-                        stage_load<true, false>(M, src, spitch, (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u, S0);
-                    else
-                        stage_load<false, false>(M, src, spitch, 0u, S0);
-                }
-                const uint32_t base = (uint32_t)(u & 1) * (uint32_t)half_dwords * 4u;
+            auto load_unit = [&](int z) {  // box loads of unit z into S0
+                const uint8_t* __restrict__ src = ua.u[z].src;
+                const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+                if (tail)
+                    stage_load<true, false>(M, src, spitch, (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u, S0);
+                else
+                    stage_load<false, false>(M, src, spitch, 0u, S0);
+            };
+            auto sample_unit = [&](int z, uint32_t base) {  // taps from the buffer at byte offset `base`, blend, store
                 uint32_t pix[kPX];
 #pragma unroll
                 for (int k = 0; k < kPX; k++) {
@@ -1033,6 +1037,32 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                     pix[k] = blend3<4>(pa[0], pa[1], pb[0], pb[1], W[k]);
                 }
                 store_interior(ua, z, t, pix);
+            };
+            if (single) {
+                // the few tiles whose box needs both buffers (diagonal footprints): one unit at a time,
+                // two barriers per unit, the next unit's loads in flight meanwhile
+                for (int u = 0; u < nu; u++) {
+                    if (u >= 1) {
+                        __syncthreads();  // everyone is done with unit u - 1
+                        stage_store(M, S0, boxw);
+                    }
+                    if (u + 1 < nu)
+                        load_unit(z0 + u + 1);
+                    if (u >= 1)
+                        __syncthreads();
+                    sample_unit(z0 + u, 0u);
+                }
+                return;
+            }
+            for (int u = 0; u < nu; u++) {
+                const int z = z0 + u;
+                if (u >= 1)
+                    __syncthreads();
+                if (u + 1 < nu && u + 1 >= 2)
+                    stage_store(M, S0, boxw + ((u + 1) & 1) * half_dwords);
+                if (u + 2 < nu)
+                    load_unit(z + 2);
+                sample_unit(z, (uint32_t)(u & 1) * (uint32_t)half_dwords * 4u);
             }
             return;
         }
@@ -1068,8 +1098,20 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
             Taps2 T0, T1;
             uint32_t pix[kPX];
             if (interior) {  // no predication, no slow-path test, unconditional stores
-                read_taps_lds<true>(L, b, boxw, T0);
-                read_taps_lds<true>(L, b, boxw + half_dwords, T1);
+                // tap address = (iy * pitch + 4 ix) + [buffer - (y0 * pitch + 4 x0)]: the bracket is a
+                // scalar per eye, so a pixel costs shift, shift + mask, multiply-add once and two adds
+                // per eye (row a, row b) -- interior coordinates are non-negative
+                const uint32_t lpw4 = (uint32_t)(b.cpr * 4 + 4) * 4u;
+                const uint32_t org = (uint32_t)b.y0 * lpw4 + (uint32_t)b.x0 * 4u;
+                const uint32_t base0 = (uint32_t)(uintptr_t)(lds_u32_ptr)boxw - org, base1 = base0 + (uint32_t)half_dwords * 4u;
+#pragma unroll
+                for (int k = 0; k < kPX; k++) {
+                    const uint32_t rel = __umul24((uint32_t)(L.sy[k] >> 5), lpw4) + (((uint32_t)L.sx[k] >> 3) & ~3u);
+                    const lds_u32_ptr a0 = (lds_u32_ptr)(uintptr_t)(rel + base0), a1 = (lds_u32_ptr)(uintptr_t)(rel + base1);
+                    const lds_u32_ptr b0 = (lds_u32_ptr)(uintptr_t)(rel + base0 + lpw4), b1 = (lds_u32_ptr)(uintptr_t)(rel + base1 + lpw4);
+                    T0.alo[k] = a0[0], T0.ahi[k] = a0[1], T0.blo[k] = b0[0], T0.bhi[k] = b0[1];
+                    T1.alo[k] = a1[0], T1.ahi[k] = a1[1], T1.blo[k] = b1[0], T1.bhi[k] = b1[1];
+                }
                 blend_taps(T0, L, pix);
                 store_interior(ua, z0, t, pix);
                 blend_taps(T1, L, pix);
@@ -1153,7 +1195,7 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, int& tx, int& ty)
 template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR>
 // `tile_list` (BOXES = 1, may be null): blockIdx.x indexes this list of tiles (ty << 16 | tx) instead
 // of the tile grid; `tiles_x` = tile columns of the full grid then.
-__global__ __launch_bounds__(256) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && PAIR && K == 2 && !ROT && !OWN) ? V1C_PAIR_WAVES : 1, 8))) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                        int upb, int half_dwords, unsigned tiles_x_magic,
                                                        const uint32_t* __restrict__ tile_list, int tiles_x)
 {
