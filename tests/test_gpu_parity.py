@@ -268,6 +268,41 @@ def test_apply_numpy_inputs_views_and_borders(V, oracle_mod):
     assert np.array_equal(tr, ref)
 
 
+def test_apply_host_batch_is_pipelined_and_exact(V, oracle_mod, monkeypatch):
+    """apply() on a list of host arrays goes through the copy / remap / copy pipeline
+    (_hostpipe.py: groups of 4, ring of 3 slots): contiguous arrays page-locked in place, a
+    read-only one and a column-sliced view staged, results equal to the oracle and to the
+    unpipelined path; grayscale batches too."""
+    from vr180_convert_amd import _hostpipe
+    from vr180_convert_amd.synth import noise_disc
+
+    calls = []
+    orig = _hostpipe.run
+    monkeypatch.setattr(_hostpipe, "run", lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1])
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    t = CS.to_product(spec)
+    imgs = [noise_disc(200, 240, 80 + f) for f in range(14)]  # 4 groups: the ring of 3 slots is reused
+    wide = noise_disc(200, 480, 99)
+    imgs[3] = wide[:, 120:360]  # non-contiguous view
+    imgs[5] = imgs[5].copy()
+    imgs[5].setflags(write=False)
+    want = oracle_mod.apply(spec, [np.ascontiguousarray(i) for i in imgs], size_output=(224, 192), interpolation=1, radius=100.0)
+    got = V.apply(t, in_paths=imgs, size_output=(224, 192), interpolation=1, radius=100.0)
+    assert calls == [14] and len(got) == 14
+    for f in range(14):
+        assert isinstance(got[f], np.ndarray) and np.array_equal(got[f], want[f]), f
+    monkeypatch.setenv("V1C_HOST_PIPELINE", "0")
+    plain = V.apply(t, in_paths=imgs, size_output=(224, 192), interpolation=1, radius=100.0)
+    assert calls == [14] and all(np.array_equal(a, b) for a, b in zip(plain, got))
+    monkeypatch.delenv("V1C_HOST_PIPELINE")
+    gray = [np.ascontiguousarray(i[..., 1]) for i in imgs[:5]]
+    want_g = oracle_mod.apply(spec, [g[..., None] for g in gray], size_output=(96, 80), interpolation=4, radius=100.0)
+    got_g = V.apply(t, in_paths=gray, size_output=(96, 80), interpolation=4, radius=100.0)
+    assert calls == [14, 5]
+    for f in range(5):
+        assert got_g[f].shape == (80, 96) and np.array_equal(got_g[f], want_g[f][..., 0]), f
+
+
 def test_apply_lr_files_auto_radius_and_tuple(V, oracle_mod, tmp_path):
     from PIL import Image
 

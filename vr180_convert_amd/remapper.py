@@ -22,7 +22,7 @@ import numpy as np
 import torch
 from numpy.typing import NDArray
 
-from . import _abi, _io, _native
+from . import _abi, _hostpipe, _io, _native
 from .chain import NotLowerable, TransformerBase, get_radius, lower_for_get_map
 from .chain import DenormalizeTransformer, NormalizeTransformer
 
@@ -385,6 +385,25 @@ def apply(
     radius_ = get_radius_smart(radius, images)
     on_device = all(isinstance(im, torch.Tensor) and im.is_cuda for im in images)
     dev = images[0].device if on_device else _device(device)
+
+    # host-resident batch: copies in, remap and copies out of different groups overlap (_hostpipe.py)
+    host_imgs = None if on_device else [np.asarray(im) if not isinstance(im, torch.Tensor) else None for im in images]
+    if (host_imgs is not None and _hostpipe.enabled(len(images)) and all(a is not None and a.dtype == np.uint8 and a.ndim in (2, 3)
+                                                                        and a.shape == host_imgs[0].shape for a in host_imgs)
+            and boarder_mode != _abi.BORDER_TRANSPARENT):
+        imgs3 = [a[..., None] if a.ndim == 2 else a for a in host_imgs]
+        size_in = (int(imgs3[0].shape[0]), int(imgs3[0].shape[1]))
+
+        def _group(srcs_g, dsts_g):
+            remap_tensors(transformer, srcs_g, dsts_g, radius=radius_, interpolation=interpolation, boarder_mode=boarder_mode,
+                          boarder_value=boarder_value, size_input=size_in)
+
+        results = _hostpipe.run(imgs3, dev, (size_output[1], size_output[0], int(imgs3[0].shape[2])), _group)
+        results = [r[..., 0] if a.ndim == 2 else r for r, a in zip(results, host_imgs)]
+        if out_paths_ is not None:
+            for to_path, image in zip(out_paths_, results):
+                _io.imwrite(to_path, image)
+        return results
 
     srcs = [_to_device(im, dev) for im in images]
     cn = srcs[0].shape[2]
