@@ -270,9 +270,9 @@ def test_apply_numpy_inputs_views_and_borders(V, oracle_mod):
 
 def test_apply_host_batch_is_pipelined_and_exact(V, oracle_mod, monkeypatch):
     """apply() on a list of host arrays goes through the copy / remap / copy pipeline
-    (_hostpipe.py: groups of 4, ring of 3 slots): contiguous arrays page-locked in place, a
-    read-only one and a column-sliced view staged, results equal to the oracle and to the
-    unpipelined path; grayscale batches too."""
+    (_hostpipe.py: groups of 4, ring of 3 slots, staging copies on a thread pool): contiguous arrays,
+    a read-only one and a column-sliced view, results equal to the oracle and to the unpipelined
+    path; grayscale batches too."""
     from vr180_convert_amd import _hostpipe
     from vr180_convert_amd.synth import noise_disc
 

@@ -440,7 +440,7 @@ struct ChunkMap {
     unsigned valid;      // bit q: chunk q exists
 };
 
-template <int NT>
+template <int NT, int NQ = 4>
 __device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkMap& M)
 {
     const int nchunks = b.nrows * b.cpr;
@@ -448,7 +448,7 @@ __device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkM
     const uint32_t magic = (uint32_t)b.magic;  // exact floor(ch / cpr) for ch < 16k, cpr <= 64
     M.valid = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NQ; q++) {
         const uint32_t ch = tid + q * NT;
         const uint32_t r = (ch * magic) >> 20, col = ch - r * b.cpr;
         M.row[q] = b.y0 + r;
@@ -462,12 +462,12 @@ __device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkM
 // TAIL: the box may reach past the last byte of the image (decided per tile, wave-uniform)
 // ZERO: clear the slots without a chunk (the batch loop's register prefetch schedules better with
 // defined values: measured 9 % on C3; the pair path saves the 24 moves)
-template <bool TAIL, bool ZERO>
+template <bool TAIL, bool ZERO, int NQ = 4>
 __device__ __forceinline__ void stage_load(const ChunkMap& M, const uint8_t* __restrict__ src, uint32_t spitch, uint32_t src_bytes,
                                            Staged& S)
 {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NQ; q++) {
         if (ZERO)
             S.w0[q] = S.w1[q] = S.w2[q] = 0;
         if (M.valid & (1u << q)) {
@@ -492,10 +492,11 @@ __device__ __forceinline__ void stage_load(const ChunkMap& M, const uint8_t* __r
 }
 
 // ---- expand to BGRx and write the box into LDS ----
+template <int NQ = 4>
 __device__ __forceinline__ void stage_store(const ChunkMap& M, const Staged& S, uint32_t* boxw)
 {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NQ; q++) {
         if (M.valid & (1u << q)) {
             // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  BGRx x 4
             u128 o;
@@ -1251,13 +1252,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
                 fb.magic = kChunkMagic.v[min(fb.cpr, kMaxCpr)];  // (cpr > kMaxCpr: the box does not fit, magic unused)
                 if (box_fits(fb, src, spitch, 4 * NT, kBoxBytes / 4)) {
                     ChunkMap M;
-                    make_chunk_map<NT>(fb, tid, M);
                     Staged S;
-                    if (box_touches_image_end(fb, g))
-                        stage_load<true, false>(M, src, spitch, src_bytes, S);
-                    else
-                        stage_load<false, false>(M, src, spitch, src_bytes, S);
-                    stage_store(M, S, boxw);
+                    // (this kernel is VALU-bound: boxes of at most two chunks per thread -- nearly all --
+                    // skip the other two slots with a scalar branch)
+                    if (fb.nrows * fb.cpr <= 2 * NT && !box_touches_image_end(fb, g)) {
+                        make_chunk_map<NT, 2>(fb, tid, M);
+                        stage_load<false, false, 2>(M, src, spitch, src_bytes, S);
+                        stage_store<2>(M, S, boxw);
+                    } else {
+                        make_chunk_map<NT>(fb, tid, M);
+                        if (box_touches_image_end(fb, g))
+                            stage_load<true, false>(M, src, spitch, src_bytes, S);
+                        else
+                            stage_load<false, false>(M, src, spitch, src_bytes, S);
+                        stage_store(M, S, boxw);
+                    }
                     __syncthreads();
                     Taps2 T;
                     uint32_t pix[kPX];
@@ -1431,7 +1440,10 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
         const int v = e ? std::atoi(e) : 0;
         return v >= 1 && v <= kUnitsPerBlock ? v : kUnitsPerBlock;
     }();
-    const int upb = bx ? std::min(n_units, upb_max) : 1;
+    // balanced groups (10 units: 5 + 5, not 8 + 2): no short tail group, and every group of a batch
+    // has more than two units, which the lean batch kernel wants
+    const int n_groups = (n_units + upb_max - 1) / upb_max;
+    const int upb = bx ? (n_units + n_groups - 1) / n_groups : 1;
     // the template's PAIR slot: with boxes "at most 2 units per workgroup", without (one unit per
     // workgroup anyway) "the m-polynomial table serves every pixel of every unit" (bilinear, OWN = 0)
     const bool pair = bx ? upb <= 2 : (K == 2 && shared_entry && mpoly_all && c.ray.radial_m != nullptr);
