@@ -216,9 +216,38 @@ def rotation_match_golden() -> None:
     print("rotation_match.npz:", {k: v.shape for k, v in out.items()})
 
 
+def match_lr_golden() -> None:
+    """`match_lr` (remapper.py:251-321) run as the reference has it: matched pixel positions -> unit
+    rays.  The function reads its two images with `cv.imread` only for their shape (centre) -- the
+    radius is passed as a number -- so the cv2 placeholder gets an `imread` that returns an empty
+    image of the shape encoded in the file name; no arithmetic of the path is replaced."""
+    import vr180_convert.remapper as RR
+
+    RR.cv.imread = lambda name: np.zeros(tuple(int(t) for t in Path(name).stem.split("x")) + (3,), np.uint8)
+    rng = np.random.default_rng(20240620)
+    out = {}
+    cases = {
+        "equidistant": (RT.FisheyeDecoder("equidistant"), (960, 1280), 470.0),
+        "stereographic_zoom": (RT.ZoomTransformer(1.2) * RT.FisheyeDecoder("stereographic"), (777, 1033), 380.5),
+        "tuple": ((RT.FisheyeDecoder("equisolid"), RT.FisheyeDecoder("rectilinear")), (600, 600), 300.0),
+    }
+    for name, (dec, (h, w), radius) in cases.items():
+        n = 40
+        pl = np.stack([rng.uniform(0.2 * w, 0.8 * w, n), rng.uniform(0.2 * h, 0.8 * h, n)], axis=1)
+        pr = pl + rng.normal(0, 3.0, (n, 2))
+        vl, vr = RR.match_lr(dec, pl, pr, [f"{h}x{w}.png", f"{h}x{w}.png"], radius=radius)
+        out[f"{name}_pl"], out[f"{name}_pr"], out[f"{name}_vl"], out[f"{name}_vr"] = pl, pr, np.asarray(vl), np.asarray(vr)
+        out[f"{name}_geom"] = np.array([h, w, radius], dtype=float)
+    np.savez_compressed(Path(__file__).resolve().parent / "match_lr.npz", **out)
+    print("match_lr.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rotation_match":
         rotation_match_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "match_lr":
+        match_lr_golden()
     else:
         main()
         rotation_match_golden()
+        match_lr_golden()

@@ -37,3 +37,51 @@ def test_rotation_match_robust_drops_outliers():
     got, bad = rotation_match_robust(a, b)
     assert _same_rotation(got, [q.w, q.x, q.y, q.z], 1e-3)
     assert bad.shape == (300,) and bad[:20].all() and bad.sum() < 300
+
+
+def _decoders():
+    from vr180_convert_amd import transformer as T
+
+    return {
+        "equidistant": T.FisheyeDecoder("equidistant"),
+        "stereographic_zoom": T.ZoomTransformer(1.2) * T.FisheyeDecoder("stereographic"),
+        "tuple": (T.FisheyeDecoder("equisolid"), T.FisheyeDecoder("rectilinear")),
+    }
+
+
+def test_match_lr_equals_reference_vectors(golden_dir):
+    """match_lr (reference remapper.py:251-321: matched pixels -> unit rays through the decoder's
+    inverse) against rays the reference's own function produced (make_golden.py match_lr)."""
+    from vr180_convert_amd.calibration import match_lr
+
+    g = np.load(golden_dir / "match_lr.npz")
+    for name, dec in _decoders().items():
+        h, w, radius = g[f"{name}_geom"]
+        img = np.zeros((int(h), int(w), 3), np.uint8)
+        vl, vr = match_lr(dec, g[f"{name}_pl"], g[f"{name}_pr"], [img, img], radius=float(radius))
+        assert vl.shape == g[f"{name}_vl"].shape
+        np.testing.assert_allclose(vl, g[f"{name}_vl"], rtol=0, atol=1e-14, err_msg=name)
+        np.testing.assert_allclose(vr, g[f"{name}_vr"], rtol=0, atol=1e-14, err_msg=name)
+    with np.testing.assert_raises(ValueError):
+        match_lr(_decoders()["equidistant"], [(1, 2)], [(1, 2), (3, 4)], [img, img], radius=10.0)
+
+
+def test_calibration_rotators_align_the_eyes():
+    """cli.py:308-319: q rotates the left rays onto the right ones; the left eye gets conj(half_q),
+    the right eye half_q (pseudo-halves, non-unit), which together undo q:
+    R(half_q) R(half_q) == R(q) up to the pseudo-half's approximation, and R(conj) == R(half)^T."""
+    from vr180_convert_amd.calibration import calibration_rotators
+    from vr180_convert_amd.quat import as_rotation_matrix
+
+    q = from_rotation_vector([0.03, -0.02, 0.04])
+    ql, qr = calibration_rotators(q)
+    assert abs(np.sqrt(qr.w**2 + qr.x**2 + qr.y**2 + qr.z**2) - 1.0) > 1e-6  # not unit, like the reference's
+    ml, mr = as_rotation_matrix(ql), as_rotation_matrix(qr)
+    np.testing.assert_allclose(ml, mr.T, atol=1e-15)
+    np.testing.assert_allclose(mr @ mr, as_rotation_matrix(q), atol=1e-5)  # (a pseudo-half: exact to O(phi^2))
+    # same numbers as tests/chainspecs.py::half_quats, which the C5 fixtures were generated with
+    import chainspecs as CS
+
+    want_l, want_r = CS.half_quats((q.w, q.x, q.y, q.z))
+    np.testing.assert_allclose([ql.w, ql.x, ql.y, ql.z], want_l, atol=1e-16)
+    np.testing.assert_allclose([qr.w, qr.x, qr.y, qr.z], want_r, atol=1e-16)
