@@ -85,3 +85,11 @@ def test_calibration_rotators_align_the_eyes():
     want_l, want_r = CS.half_quats((q.w, q.x, q.y, q.z))
     np.testing.assert_allclose([ql.w, ql.x, ql.y, ql.z], want_l, atol=1e-16)
     np.testing.assert_allclose([qr.w, qr.x, qr.y, qr.z], want_r, atol=1e-16)
+
+
+def test_calibration_names_live_in_remapper_like_the_reference():
+    import vr180_convert_amd.remapper as R
+    from vr180_convert_amd import calibration
+
+    assert R.rotation_match is calibration.rotation_match and R.match_lr is calibration.match_lr
+    assert R.rotation_match_robust is calibration.rotation_match_robust

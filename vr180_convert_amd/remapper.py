@@ -528,3 +528,13 @@ def _radius_for_pair(radius, transformer, left, right):
             return r[0] if r[0] == r[1] else radius
         return get_radius_smart("auto", [left, right])
     return radius
+
+
+def __getattr__(name: str):
+    # rotation_match / rotation_match_robust / match_lr live in vr180_convert.remapper in the
+    # reference (remapper.py:93-321); here they are in calibration.py (which imports this module)
+    if name in ("rotation_match", "rotation_match_robust", "match_lr", "calibration_rotators"):
+        from . import calibration
+
+        return getattr(calibration, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
