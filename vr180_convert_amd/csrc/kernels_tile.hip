@@ -1113,10 +1113,13 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                     T0.alo[k] = a0[0], T0.ahi[k] = a0[1], T0.blo[k] = b0[0], T0.bhi[k] = b0[1];
                     T1.alo[k] = a1[0], T1.ahi[k] = a1[1], T1.blo[k] = b1[0], T1.bhi[k] = b1[1];
                 }
+                V1C_STAMP(4);  // tap addresses + LDS reads issued
                 blend_taps(T0, L, pix);
                 store_interior(ua, z0, t, pix);
+                V1C_STAMP(5);  // blend + store, first eye
                 blend_taps(T1, L, pix);
                 store_interior(ua, z0 + 1, t, pix);
+                V1C_STAMP(6);  // blend + store, second eye
                 return;
             }
             read_taps_lds(L, b, boxw, T0);
