@@ -193,3 +193,19 @@ def test_engine_fails_loudly_without_gpu():
         V.apply(T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant"), in_paths=img, radius="max", size_output=(16, 16))
     with pytest.raises(_native.EngineUnavailable):
         V.get_map(T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant"), radius=8.0, size_input=(16, 16), size_output=(16, 16))
+
+
+def test_io_many_round_trip(tmp_path):
+    """Image files either side of the path (reference remapper.py:373,402): batches are decoded /
+    encoded on a thread pool; PNG is lossless, arrays are BGR like cv2's."""
+    from vr180_convert_amd import _io
+
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (37, 41, 3), dtype=np.uint8) for _ in range(5)]
+    paths = [tmp_path / f"im{k}.png" for k in range(5)]
+    _io.imwrite_many(paths, imgs)
+    back = _io.imread_many([*paths[:4], imgs[4]])  # arrays pass through
+    assert all(np.array_equal(a, b) for a, b in zip(back, imgs))
+    assert _io.imread(tmp_path / "missing.png") is None  # cv2.imread's contract
+    _io.imwrite(tmp_path / "q.jpg", imgs[0])
+    assert _io.imread(tmp_path / "q.jpg").shape == (37, 41, 3)

@@ -38,8 +38,37 @@ def imwrite(path: Any, image: np.ndarray) -> bool:
     from PIL import Image
 
     arr = image if image.ndim == 2 else image[..., ::-1] if image.shape[2] == 3 else image[..., [2, 1, 0, 3]]
-    Image.fromarray(np.ascontiguousarray(arr)).save(p)
+    # cv2.imwrite's defaults: PNG compression level 1 (IMWRITE_PNG_COMPRESSION), JPEG quality 95
+    ext = Path(p).suffix.lower()
+    opts = {"compress_level": 1} if ext == ".png" else {"quality": 95} if ext in (".jpg", ".jpeg") else {}
+    Image.fromarray(np.ascontiguousarray(arr)).save(p, **opts)
     return True
+
+
+def imread_many(paths: list) -> list:
+    """``imread`` of several files on a small thread pool (the codecs release the GIL); entries that
+    are not paths are passed through."""
+    todo = [i for i, q in enumerate(paths) if isinstance(q, (str, Path))]
+    if len(todo) < 2:
+        return [imread(q) if isinstance(q, (str, Path)) else q for q in paths]
+    from concurrent.futures import ThreadPoolExecutor
+
+    out = list(paths)
+    with ThreadPoolExecutor(max_workers=min(8, len(todo))) as pool:
+        for i, img in zip(todo, pool.map(imread, [paths[i] for i in todo])):
+            out[i] = img
+    return out
+
+
+def imwrite_many(paths: list, images: list) -> None:
+    if len(paths) < 2:
+        for q, im in zip(paths, images):
+            imwrite(q, im)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(8, len(paths))) as pool:
+        list(pool.map(imwrite, paths, images))
 
 
 def draw_anaglyph_labels(combine: np.ndarray) -> np.ndarray:

@@ -381,7 +381,7 @@ def apply(
     out_paths_ = [out_paths] if isinstance(out_paths, (str, Path)) else out_paths
     del in_paths, out_paths
 
-    images = [_io.imread(p) if isinstance(p, (str, Path)) else p for p in in_paths_]
+    images = _io.imread_many(list(in_paths_))
     radius_ = get_radius_smart(radius, images)
     on_device = all(isinstance(im, torch.Tensor) and im.is_cuda for im in images)
     dev = images[0].device if on_device else _device(device)
@@ -401,8 +401,7 @@ def apply(
         results = _hostpipe.run(imgs3, dev, (size_output[1], size_output[0], int(imgs3[0].shape[2])), _group)
         results = [r[..., 0] if a.ndim == 2 else r for r, a in zip(results, host_imgs)]
         if out_paths_ is not None:
-            for to_path, image in zip(out_paths_, results):
-                _io.imwrite(to_path, image)
+            _io.imwrite_many(list(out_paths_)[: len(results)], results)
         return results
 
     srcs = [_to_device(im, dev) for im in images]
@@ -419,8 +418,8 @@ def apply(
         results = [d.cpu().numpy() for d in dsts]
         results = [r[..., 0] if np.asarray(im).ndim == 2 else r for r, im in zip(results, images)]
     if out_paths_ is not None:
-        for to_path, image in zip(out_paths_, results):
-            _io.imwrite(to_path, image.cpu().numpy() if isinstance(image, torch.Tensor) else image)
+        _io.imwrite_many(list(out_paths_)[: len(results)],
+                         [image.cpu().numpy() if isinstance(image, torch.Tensor) else image for image in results])
     return results
 
 
