@@ -509,6 +509,28 @@ __device__ __forceinline__ void stage_store(const ChunkMap& M, const Staged& S, 
     }
 }
 
+// ---- the same for the two eyes of a pair, interleaved per pixel: (A_i, B_i) as one 8-byte cell ----
+// Both eyes sample the same box positions (one map per apply() call), so with the cells interleaved
+// a tap row of BOTH eyes is one ds_read2_b64 (cells i, i + 1) instead of two ds_read2_b32: the
+// scattered gather costs about the same LDS cycles per instruction either way
+// (tools/ubench/lds_tap_mapping.hip: 18 vs 2 x 14), i.e. a third fewer for the pair.
+// `boxw` then holds nrows x (4 cpr + 4) cells = the two buffers' dwords together.
+__device__ __forceinline__ void stage_store_pair(const ChunkMap& M, const Staged& SA, const Staged& SB, uint32_t* boxw)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (M.valid & (1u << q)) {
+            const uint32_t a0 = SA.w0[q] & 0x00ffffffu, a1 = __builtin_amdgcn_perm(SA.w1[q], SA.w0[q], 0x0c050403u),
+                           a2 = __builtin_amdgcn_perm(SA.w2[q], SA.w1[q], 0x0c040302u), a3 = SA.w2[q] >> 8;
+            const uint32_t b0 = SB.w0[q] & 0x00ffffffu, b1 = __builtin_amdgcn_perm(SB.w1[q], SB.w0[q], 0x0c050403u),
+                           b2 = __builtin_amdgcn_perm(SB.w2[q], SB.w1[q], 0x0c040302u), b3 = SB.w2[q] >> 8;
+            u128* dst = (u128*)(boxw + 2 * M.lds_dw[q]);
+            dst[0] = u128{a0, b0, a1, b1};
+            dst[1] = u128{a2, b2, a3, b3};
+        }
+    }
+}
+
 // ---- bilinear blend of one pixel from its two tap pairs; SEL_HI = byte index of px1 ----
 // out = (sum_ij p_ij * wx_i * wy_j + 512) >> 10 with the four 10-bit products as two u16 pairs,
 // scaled by 64 so that the result byte is byte 2 of the accumulator:
@@ -987,10 +1009,15 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     RowCol rc;
     load_rowcol<ROT>(P, t.xc, t.jc, rc);
     V1C_STAMP(0);  // setup + issue of all loads
-    if (fit0)
-        stage_store(M, S0, boxw);
-    if (fit1)
-        stage_store(M, S1, boxw + half_dwords);
+    const bool cells = PAIR && K == 2 && nu == 2 && fit0 && fit1;  // bilinear pair: eyes interleaved per pixel
+    if (cells) {
+        stage_store_pair(M, S0, S1, boxw);
+    } else {
+        if (fit0)
+            stage_store(M, S0, boxw);
+        if (fit1)
+            stage_store(M, S1, boxw + half_dwords);
+    }
     if (tab_lds && tid < b.nidx * 4)
         ((d2*)tabw)[tid] = tv;
     V1C_STAMP(1);  // wait for the loads + expand + LDS stores
@@ -1099,19 +1126,20 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
             Taps2 T0, T1;
             uint32_t pix[kPX];
             if (interior) {  // no predication, no slow-path test, unconditional stores
-                // tap address = (iy * pitch + 4 ix) + [buffer - (y0 * pitch + 4 x0)]: the bracket is a
-                // scalar per eye, so a pixel costs shift, shift + mask, multiply-add once and two adds
-                // per eye (row a, row b) -- interior coordinates are non-negative
-                const uint32_t lpw4 = (uint32_t)(b.cpr * 4 + 4) * 4u;
-                const uint32_t org = (uint32_t)b.y0 * lpw4 + (uint32_t)b.x0 * 4u;
-                const uint32_t base0 = (uint32_t)(uintptr_t)(lds_u32_ptr)boxw - org, base1 = base0 + (uint32_t)half_dwords * 4u;
+                // cell address = (iy * pitch + ix) * 8 + [box - (y0 * pitch + x0) * 8]: the bracket is a scalar;
+                // one ds_read2_b64 per tap row fetches (A_ix, B_ix), (A_ix+1, B_ix+1) -- interior
+                // coordinates are non-negative
+                typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+                typedef const __attribute__((address_space(3))) u32x2* lds_u64_ptr;
+                const uint32_t lpw8 = (uint32_t)(b.cpr * 4 + 4) * 8u;
+                const uint32_t base0 = (uint32_t)(uintptr_t)(lds_u32_ptr)boxw - ((uint32_t)b.y0 * lpw8 + (uint32_t)b.x0 * 8u);
 #pragma unroll
                 for (int k = 0; k < kPX; k++) {
-                    const uint32_t rel = __umul24((uint32_t)(L.sy[k] >> 5), lpw4) + (((uint32_t)L.sx[k] >> 3) & ~3u);
-                    const lds_u32_ptr a0 = (lds_u32_ptr)(uintptr_t)(rel + base0), a1 = (lds_u32_ptr)(uintptr_t)(rel + base1);
-                    const lds_u32_ptr b0 = (lds_u32_ptr)(uintptr_t)(rel + base0 + lpw4), b1 = (lds_u32_ptr)(uintptr_t)(rel + base1 + lpw4);
-                    T0.alo[k] = a0[0], T0.ahi[k] = a0[1], T0.blo[k] = b0[0], T0.bhi[k] = b0[1];
-                    T1.alo[k] = a1[0], T1.ahi[k] = a1[1], T1.blo[k] = b1[0], T1.bhi[k] = b1[1];
+                    const uint32_t rel = __umul24((uint32_t)(L.sy[k] >> 5), lpw8) + (((uint32_t)L.sx[k] >> 2) & ~7u);
+                    const lds_u64_ptr ra = (lds_u64_ptr)(uintptr_t)(rel + base0), rb = (lds_u64_ptr)(uintptr_t)(rel + base0 + lpw8);
+                    const u32x2 a_lo = ra[0], a_hi = ra[1], b_lo = rb[0], b_hi = rb[1];
+                    T0.alo[k] = a_lo.x, T0.ahi[k] = a_hi.x, T0.blo[k] = b_lo.x, T0.bhi[k] = b_hi.x;
+                    T1.alo[k] = a_lo.y, T1.ahi[k] = a_hi.y, T1.blo[k] = b_lo.y, T1.bhi[k] = b_hi.y;
                 }
                 V1C_STAMP(4);  // tap addresses + LDS reads issued
                 blend_taps(T0, L, pix);
@@ -1122,8 +1150,19 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                 V1C_STAMP(6);  // blend + store, second eye
                 return;
             }
-            read_taps_lds(L, b, boxw, T0);
-            read_taps_lds(L, b, boxw + half_dwords, T1);
+            {  // (the same cells, taps predicated on `inside`)
+                const int lpw = b.cpr * 4 + 4;
+                const uint2* cellw = (const uint2*)boxw;
+#pragma unroll
+                for (int k = 0; k < kPX; k++) {
+                    const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+                    const bool in = (L.inside >> k) & 1;
+                    const uint32_t lo = in ? __umul24(iy - b.y0, lpw) + (uint32_t)(ix - b.x0) : 0u;
+                    const uint2 a_lo = cellw[lo], a_hi = cellw[lo + 1], b_lo = cellw[lo + lpw], b_hi = cellw[lo + lpw + 1];
+                    T0.alo[k] = a_lo.x, T0.ahi[k] = a_hi.x, T0.blo[k] = b_lo.x, T0.bhi[k] = b_hi.x;
+                    T1.alo[k] = a_lo.y, T1.ahi[k] = a_hi.y, T1.blo[k] = b_lo.y, T1.bhi[k] = b_hi.y;
+                }
+            }
             blend_taps(T0, L, pix);
             patch_and_store<K>(c, ua, z0, t, L, pix, L.inside, ua.u[z0].src);
             blend_taps(T1, L, pix);
