@@ -965,6 +965,13 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     const int z0 = zg * upb;
     const TileIds t = tile_ids(g, z0, tid, tx, ty, tiles_x, NT / kLanesX);
     const int nu = min(upb, n_units - z0);
+    // (the first two units' pointers are read here, next to the tile box, not behind it: every
+    // dependent scalar load of the prologue is a wait)
+    const uint8_t* __restrict__ usrc0 = ua.u[z0].src;
+    const uint32_t upitch0 = (uint32_t)ua.u[z0].src_pitch;
+    const int z1 = min(z0 + 1, kMaxUnitsPerLaunch - 1);
+    const uint8_t* __restrict__ usrc1 = ua.u[z1].src;
+    const uint32_t upitch1 = (uint32_t)ua.u[z1].src_pitch;
     // everything the tile needs from global memory is requested up front: the boxes of the first
     // two units, the radial-table slice and the row / column table entries (one exposed latency)
     TileBox b;
@@ -982,8 +989,8 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     make_chunk_map<NT>(b, tid, M);
 
     auto issue = [&](int z, Staged& S) -> bool {  // start the box loads of unit z; false: it must gather from global memory
-        const uint8_t* __restrict__ src = ua.u[z].src;
-        const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+        const uint8_t* __restrict__ src = z == z0 ? usrc0 : z == z0 + 1 ? usrc1 : ua.u[z].src;
+        const uint32_t spitch = z == z0 ? upitch0 : z == z0 + 1 ? upitch1 : (uint32_t)ua.u[z].src_pitch;
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
         const bool fits = box_fits(b, src, spitch, 4 * NT, LEAN ? 2 * half_dwords : half_dwords);
         if (fits) {
@@ -1235,9 +1242,10 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, int& tx, int& ty)
 // BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes, coordinates shared by `upb` units.
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
-template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR>
-// `tile_list` (BOXES = 1, may be null): blockIdx.x indexes this list of tiles (ty << 16 | tx) instead
-// of the tile grid; `tiles_x` = tile columns of the full grid then.
+template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR, int LIST = 0>
+// LIST = 1 (BOXES = 1): blockIdx.x indexes `tile_list` (ty << 16 | tx) instead of the tile grid;
+// `tiles_x` = tile columns of the full grid then.  (A template switch rather than a null test: the
+// test split the kernel-argument loads of the prologue over two more dependent waits.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && PAIR && K == 2 && !ROT && !OWN) ? V1C_PAIR_WAVES : 1, 8))) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                        int upb, int half_dwords, unsigned tiles_x_magic,
                                                        const uint32_t* __restrict__ tile_list, int tiles_x)
@@ -1248,7 +1256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
     const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
     if (BOXES) {
         int tx, ty;
-        if (tile_list) {
+        if (LIST) {
             const uint32_t v = tile_list[blockIdx.x];
             tx = (int)(v & 0xffffu), ty = (int)(v >> 16);
         } else {
@@ -1519,7 +1527,7 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
             hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), grid, block, lean_lds, stream, c, ua, bx, n_units, upb, lean_half, \
                                xmagic);                                                                                               \
             if (n_rest > 0)                                                                                                           \
-                hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, BX>), rest_grid, block, lds, stream, c, ua, bx, n_units, 2,    \
+                hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, BX, BX>), rest_grid, block, lds, stream, c, ua, bx, n_units, 2, \
                                    half_dwords, xmagic, rest_list, (int)grid.x);                                                      \
         } else {                                                                                                                      \
             hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb,           \
