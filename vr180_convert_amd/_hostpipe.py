@@ -33,8 +33,11 @@ COPY_THREADS = 8
 GROUP = 4  # images per group: large enough for the shared-map batch kernel, small enough to pipeline
 
 
-def enabled(n_images: int) -> bool:
-    return n_images >= 2 and os.environ.get("V1C_HOST_PIPELINE", "1") != "0"
+MAX_PINNED_BYTES = 4 << 30  # results are returned as page-locked arrays: beyond this the plain path is used
+
+
+def enabled(n_images: int, result_bytes: int = 0) -> bool:
+    return n_images >= 2 and result_bytes <= MAX_PINNED_BYTES and os.environ.get("V1C_HOST_PIPELINE", "1") != "0"
 
 
 def run(images: Sequence[Any], dev: torch.device, out_hw_c: tuple[int, int, int],

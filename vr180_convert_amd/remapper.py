@@ -388,7 +388,7 @@ def apply(
 
     # host-resident batch: copies in, remap and copies out of different groups overlap (_hostpipe.py)
     host_imgs = None if on_device else [np.asarray(im) if not isinstance(im, torch.Tensor) else None for im in images]
-    if (host_imgs is not None and _hostpipe.enabled(len(images)) and all(a is not None and a.dtype == np.uint8 and a.ndim in (2, 3)
+    if (host_imgs is not None and _hostpipe.enabled(len(images), len(images) * size_output[0] * size_output[1] * 4) and all(a is not None and a.dtype == np.uint8 and a.ndim in (2, 3)
                                                                         and a.shape == host_imgs[0].shape for a in host_imgs)
             and boarder_mode != _abi.BORDER_TRANSPARENT):
         imgs3 = [a[..., None] if a.ndim == 2 else a for a in host_imgs]
