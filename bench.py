@@ -56,7 +56,7 @@ def allreduce_max(value: float, device: torch.device) -> float:
 
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -192,14 +192,20 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
-    dev = torch.device("cuda", local_rank)
+    # V1C_BENCH_REHEARSAL=1: rehearse the multi-rank path on a box with fewer GPUs than ranks (gloo for the
+    # barrier / MAX reduction, ranks share the devices there are) -- never a measurement
+    rehearsal = os.environ.get("V1C_BENCH_REHEARSAL", "0") == "1"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if rehearsal else local_rank)
     torch.cuda.set_device(dev)
 
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import vr180_convert_amd as V
     from vr180_convert_amd import _native
@@ -297,7 +303,8 @@ def main() -> None:
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (seeded uint8 noise inside the fisheye circle, black outside), resident in HBM",
+            "data": "synthetic (seeded uint8 noise inside the fisheye circle, black outside), resident in HBM"
+                    + (" -- REHEARSAL: ranks share devices, gloo; not a measurement" if rehearsal else ""),
             "config": {"workload": f"{args.workload}: {cfg['desc']}", "units_per_step_per_gpu": units,
                        "arithmetic": "f64 coordinates (fused chain), u8 pixels with int32 fixed-point blend",
                        "sharding": "frames over ranks, no collective", "kernel_path": paths},
