@@ -236,6 +236,63 @@ def test_full_size_properties(V, dev):
     assert np.all(inner == np.array([9, 8, 7], np.uint8))
 
 
+def _lut_remap(V, src, xm, ym, out_wh, interp=1):
+    """cv.remap alone on the device (v1c_remap_lut) with maps that are already there."""
+    import ctypes as C
+
+    from vr180_convert_amd import _native
+    from vr180_convert_amd.remapper import _stream_ptr, border_scalar
+
+    dst = torch.empty((out_wh[1], out_wh[0], 3), dtype=torch.uint8, device=src.device)
+    bv = border_scalar(0)
+    rc = _native.lib().v1c_remap_lut(src.device.index, _stream_ptr(src.device), src.data_ptr(), src.shape[0], src.shape[1], src.stride(0), 3,
+                                     dst.data_ptr(), out_wh[1], out_wh[0], dst.stride(0), xm.data_ptr(), ym.data_ptr(),
+                                     xm.stride(0) * 4, interp, 0, bv.ctypes.data)
+    _native.check(rc, "v1c_remap_lut")
+    return dst
+
+
+def test_full_size_batch_and_rotation_paths_agree(V, dev):
+    """BASELINE sizes of the two batch configs, through size-independent properties:
+    C3 (16 units of 2880^2 sharing one map): the lean batch kernel + the remaining-tile launch give, unit
+    for unit, the bytes the pair kernel gives for that unit alone;
+    C5 (3840^2, a calibration rotation per unit): the in-kernel-box fast path equals cv.remap alone
+    (v1c_remap_lut) fed with the map v1c_plan_get_map produces for that rotation -- i.e. the shared
+    table entry / m-polynomial coordinates land in the same 1/32 buckets as the per-pixel evaluation
+    on all 14.7 M pixels."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.chain import lower_for_get_map
+    from vr180_convert_amd.quat import as_rotation_matrix
+    from vr180_convert_amd.remapper import _plan_for
+    from vr180_convert_amd.synth import noise_disc_torch
+
+    n = 2880
+    t = T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant")
+    frames = [noise_disc_torch(n, 2 * n, 100 + f, dev) for f in range(8)]
+    srcs = [v for fr in frames for v in (fr[:, :n], fr[:, n:])]  # pitched views, 16 units
+    dsts = [torch.empty((n, n, 3), dtype=torch.uint8, device=dev) for _ in srcs]
+    assert V.remap_tensors(t, srcs, dsts, radius=n / 2, interpolation=1) == ["ray"]
+    for k in (0, 5, 15):
+        alone = torch.empty((n, n, 3), dtype=torch.uint8, device=dev)
+        V.remap_tensors(t, [srcs[k]], [alone], radius=n / 2, interpolation=1)
+        assert torch.equal(alone, dsts[k]), k
+    del frames, srcs, dsts
+
+    n = 3840
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    quats = [CS.c5_spec(3, eye)[1][1] for eye in (0, 1)]
+    imgs = [noise_disc_torch(n, n, 200 + e, dev) for e in (0, 1)]
+    outs = [torch.empty((n, n, 3), dtype=torch.uint8, device=dev) for _ in imgs]
+    assert V.remap_tensors(base, imgs, outs, radius=n / 2, interpolation=1, rotations=quats) == ["ray"]
+    chain = lower_for_get_map(base, radius=n / 2, size_input=(n, n), size_output=(n, n))
+    plan = _plan_for(chain, src_hw=(n, n), dst_wh=(n, n), cn=3, interpolation=1, border_mode=0, border_value=0, device=dev)
+    for e in (0, 1):
+        xm, ym = plan.get_map(as_rotation_matrix(quats[e]))
+        want = _lut_remap(V, imgs[e], xm, ym, (n, n))
+        torch.cuda.synchronize()
+        assert torch.equal(want, outs[e]), e
+
+
 # ---------------------------------------------------------------------------- API behaviour
 def test_apply_numpy_inputs_views_and_borders(V, oracle_mod):
     from vr180_convert_amd.synth import noise_disc, pattern
