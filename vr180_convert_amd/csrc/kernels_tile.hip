@@ -622,16 +622,24 @@ __device__ __noinline__ uint32_t blend_table(lds_u32_ptr boxw, uint32_t lo, int 
 // The same for the two eyes of a pair: both read their taps at the same box offset with the SAME
 // weights (one map per apply() call), so the weight row -- 128 B per pixel for Lanczos4, an L2
 // read -- is fetched once for both.  Returns (pixel of box A) | (pixel of box B) << 32.
+// The boxes are interleaved per pixel ((A_i, B_i) cells, stage_store_pair): a row of K taps of BOTH eyes is
+// K / 2 ds_read2_b64 (K = 8: LDS instructions per pixel pair 64 -> 32; the Lanczos4 pair had its
+// LDS 67 % busy, 59 % of that bank conflicts).  `lo` = cell index of the top-left tap.
+typedef uint32_t __attribute__((ext_vector_type(2))) u32x2v;
+typedef const __attribute__((address_space(3))) u32x2v* lds_cell_ptr;
+
 template <int K, typename WPtr>
-__device__ __noinline__ uint64_t blend_table_pair(lds_u32_ptr boxa, lds_u32_ptr boxb, uint32_t lo, int lpw, WPtr w)
+__device__ __noinline__ uint64_t blend_table_pair(lds_cell_ptr cells, uint32_t lo, int lpw, WPtr w)
 {
     int a0 = 1 << 14, a1 = 1 << 14, a2 = 1 << 14, b0 = 1 << 14, b1 = 1 << 14, b2 = 1 << 14;
 #pragma unroll
     for (int r = 0; r < K; r++) {
         uint32_t da[K], db[K];
 #pragma unroll
-        for (int q = 0; q < K; q++)
-            da[q] = boxa[lo + r * lpw + q], db[q] = boxb[lo + r * lpw + q];
+        for (int q = 0; q < K; q++) {
+            const u32x2v cq = cells[lo + r * lpw + q];
+            da[q] = cq.x, db[q] = cq.y;
+        }
         uint32_t wr[K / 2];
 #pragma unroll
         for (int q = 0; q < K / 2; q++)
@@ -1016,7 +1024,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     RowCol rc;
     load_rowcol<ROT>(P, t.xc, t.jc, rc);
     V1C_STAMP(0);  // setup + issue of all loads
-    const bool cells = PAIR && K == 2 && nu == 2 && fit0 && fit1;  // bilinear pair: eyes interleaved per pixel
+    const bool cells = PAIR && nu == 2 && fit0 && fit1;  // a pair: the two eyes interleaved per pixel
     if (cells) {
         stage_store_pair(M, S0, S1, boxw);
     } else {
@@ -1187,7 +1195,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                 const bool in = (L.inside >> k) & 1;
                 const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
                 const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
-                const uint64_t pp = blend_table_pair<K>((lds_u32_ptr)boxw, (lds_u32_ptr)(boxw + half_dwords), lo, lpw, wtab + a * (K * K / 2));
+                const uint64_t pp = blend_table_pair<K>((lds_cell_ptr)boxw, lo, lpw, wtab + a * (K * K / 2));
                 pa[k] = (uint32_t)pp, pb[k] = (uint32_t)(pp >> 32);
             }
             patch_and_store<K>(c, ua, z0, t, L, pa, L.inside, ua.u[z0].src);
