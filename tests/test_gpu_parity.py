@@ -360,6 +360,42 @@ def test_apply_host_batch_is_pipelined_and_exact(V, oracle_mod, monkeypatch):
         assert got_g[f].shape == (80, 96) and np.array_equal(got_g[f], want_g[f][..., 0]), f
 
 
+def test_repeated_calls_take_the_memoised_path_and_stay_exact(V, oracle_mod, dev):
+    """remap_tensors remembers the plan of the previous shared-transformer call and Plan.run the
+    marshalled units of identical tensors (a steady stream of frames costs ~half the Python time):
+    new buffers, a different unit count, changed parameters and changed geometry must all still give
+    the oracle's bytes."""
+    from vr180_convert_amd.synth import noise_disc
+
+    def check(spec, imgs, out, radius):
+        srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+        dsts = [torch.empty((out[1], out[0], 3), dtype=torch.uint8, device=dev) for _ in imgs]
+        t = CS.to_product(spec)
+        for _ in range(3):  # 2nd / 3rd call: memoised plan + reused unit array
+            for d in dsts:
+                d.zero_()
+            V.remap_tensors(t, srcs, dsts, radius=radius, interpolation=1)
+        want = oracle_mod.apply(spec, imgs, size_output=out, interpolation=1, radius=radius)
+        for k in range(len(imgs)):
+            assert np.array_equal(dsts[k].cpu().numpy(), want[k]), (spec, k)
+        return t, srcs, dsts
+
+    a = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    b = [("equirect_enc", True), ("poly", [0, 1, -0.2]), CS.EQUI]
+    imgs = [noise_disc(160, 160, 90 + k) for k in range(3)]
+    t, srcs, dsts = check(a, imgs[:2], (160, 160), 80.0)
+    check(a, imgs, (160, 160), 80.0)             # same key, other buffers, 3 units
+    check(b, imgs[:2], (160, 160), 80.0)         # other parameters
+    check(a, imgs[:2], (192, 128), 80.0)         # other output geometry
+    check(a, imgs[:2], (160, 160), 70.0)         # other radius
+    # same transformer object and buffers again after all that: still its own plan
+    for d in dsts:
+        d.zero_()
+    V.remap_tensors(t, srcs, dsts, radius=80.0, interpolation=1)
+    want = oracle_mod.apply(a, imgs[:2], size_output=(160, 160), interpolation=1, radius=80.0)
+    assert all(np.array_equal(dsts[k].cpu().numpy(), want[k]) for k in range(2))
+
+
 def test_apply_lr_files_auto_radius_and_tuple(V, oracle_mod, tmp_path):
     from PIL import Image
 
