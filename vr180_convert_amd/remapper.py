@@ -198,7 +198,7 @@ def _host_map(transformer: TransformerBase, *, radius, size_input, size_output):
 
 
 _LOWERED: "OrderedDict[tuple, _abi.Chain]" = OrderedDict()
-_LAST_SHARED: list = []  # [key, Plan] of the last remap_tensors call with one shared transformer
+_LAST_SHARED: list = [None]  # [(key, Plan)] of the last remap_tensors call with one shared transformer
 
 
 def _lower_cached(t: TransformerBase, *, radius, size_input, size_output) -> _abi.Chain:
@@ -254,8 +254,9 @@ def remap_tensors(
                             None if size_input is None else tuple(size_input), srcs[0].device)
             except (TypeError, ValueError):
                 memo_key = None
-            if memo_key is not None and _LAST_SHARED and _LAST_SHARED[0] == memo_key:
-                plan = _LAST_SHARED[1]
+            last = _LAST_SHARED[0]  # (one read: another thread may replace the entry at any time)
+            if memo_key is not None and last is not None and last[0] == memo_key:
+                plan = last[1]
                 plan.run(srcs, dsts, None)
                 return [plan.path_cached]
     per_unit = list(transformer) if isinstance(transformer, (list, tuple)) else [transformer] * n
@@ -310,7 +311,7 @@ def remap_tensors(
         paths.append(plan.path)
         if memo_key is not None and len(groups) == 1 and len(paths) == 1 and uniform and len(g["srcs"]) == n:
             plan.path_cached = paths[0]
-            _LAST_SHARED[:] = [memo_key, plan]
+            _LAST_SHARED[0] = (memo_key, plan)
     return paths
 
 
