@@ -743,8 +743,7 @@ def test_plan_run_is_graph_capturable(V, dev):
 
 
 def test_batch_plan_run_is_graph_capturable(V, oracle_mod, dev):
-    """The same for a shared-map batch: two launches per run (the lean batch kernel and the pair kernel
-    on the plan's list of remaining tiles)."""
+    """The same for a shared-map batch (the lean batch kernel with the remaining tiles as its first grid slice)."""
     from vr180_convert_amd.synth import noise_disc
 
     size = 320
@@ -772,7 +771,7 @@ def test_batch_plan_run_is_graph_capturable(V, oracle_mod, dev):
 
 
 @pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_DISABLE_MPOLY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"},
-                                 {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_LEAN": "1"}],
+                                 {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_LEAN": "1"}, {"V1C_DISABLE_MERGE": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_variants_bit_exact(env):
     """The instantiations the default configuration does not reach (per-pixel table fallback,

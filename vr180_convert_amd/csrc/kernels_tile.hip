@@ -1360,13 +1360,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
 // runs on the list of the tiles this one leaves out.
 template <int VAR_W, int ROT, int OWN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
-                                                             int upb, int half_dwords, unsigned tiles_x_magic)
+                                                             int upb, int half_dwords, unsigned tiles_x_magic,
+                                                             const uint32_t* __restrict__ rest_list, int n_rest)
 {
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
     int tx, ty;
+    // `rest_list` != null: grid slice z = 0 serves the tiles the lean path leaves out, two units per
+    // workgroup through the pair code, and the lean groups are slices 1 .. n_groups: the few
+    // latency-bound workgroups are dispatched first and run alongside the lean ones instead of in a
+    // launch of their own behind them (C3 0.210 -> 0.202 ms).  LDS is sized for the lean path: a
+    // remaining tile whose box needs more gathers from global memory.
+    int zl = (int)blockIdx.z;
+    if (rest_list != nullptr) {
+        zl -= 1;
+    }
+    if (zl < 0) {
+        const unsigned pairs = (unsigned)(n_units + 1) / 2u;
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= (unsigned)n_rest * pairs)
+            return;
+        const unsigned ti = lin / pairs, zg = lin - ti * pairs;
+        const uint32_t v = rest_list[ti];
+        shared_map_tile<VAR_W, ROT, 2, OWN, 1, 256, 0>(c, ua, boxes, n_units, 2, (int)zg, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
+                                                       half_dwords, tabw, (glb_u32_ptr)c.itab);
+        return;
+    }
     xcd_tile(tiles_x_magic, tx, ty);
-    shared_map_tile<VAR_W, ROT, 2, OWN, 0, 256, 1>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, gridDim.x, dyn_box, half_dwords, tabw,
+    shared_map_tile<VAR_W, ROT, 2, OWN, 0, 256, 1>(c, ua, boxes, n_units, upb, zl, tx, ty, gridDim.x, dyn_box, half_dwords, tabw,
                                                    (glb_u32_ptr) nullptr);
 }
 
@@ -1526,15 +1547,23 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     // looping over 8 units would be one long serial chain with nothing to overlap it
     const dim3 rest_grid((unsigned)std::max(n_rest, 1), 1, (unsigned)((n_units + 1) / 2));
     const size_t lean_lds = (size_t)lean_half * 8 + 16;
+    // the remaining tiles ride in the lean launch as one more grid slice when they fit one (else, or
+    // with V1C_DISABLE_MERGE=1, in a launch of their own)
+    static const bool merge_off = [] {
+        const char* e = std::getenv("V1C_DISABLE_MERGE");
+        return e && e[0] == '1';
+    }();
+    const bool merged = !merge_off && n_rest > 0 && (size_t)n_rest * ((n_units + 1) / 2) <= (size_t)grid.x * grid.y;
+    const dim3 merged_grid(grid.x, grid.y, grid.z + 1);
     const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
 #define V1C_TILE_P(VW, RT, BX, OW, PR)                                                                                                \
     do {                                                                                                                              \
         if (lean) {                                                                                                                   \
             /* (running the remaining tiles on a side stream, forked and joined with events so that their */                          \
             /* latency-bound kernel overlaps the lean one, measured 4 % slower on C3 than back to back) */                            \
-            hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), grid, block, lean_lds, stream, c, ua, bx, n_units, upb, lean_half, \
-                               xmagic);                                                                                               \
-            if (n_rest > 0)                                                                                                           \
+            hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), merged ? merged_grid : grid, block, lean_lds, stream, c, ua, bx,   \
+                               n_units, upb, lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest);               \
+            if (n_rest > 0 && !merged)                                                                                                \
                 hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, BX, BX>), rest_grid, block, lds, stream, c, ua, bx, n_units, 2, \
                                    half_dwords, xmagic, rest_list, (int)grid.x);                                                      \
         } else {                                                                                                                      \
