@@ -37,7 +37,8 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry,
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
-                                hipStream_t stream);
+                                int strip_len, hipStream_t stream);
+int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int lean_half);
 int tile_lean_half_dwords(int half_dwords);
 std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int half_dwords);
 

@@ -1233,14 +1233,23 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
 // Give each XCD a contiguous run of tiles instead (C2: FETCH_SIZE 128 -> 61 MB per launch).
 // `magic` = floor(2^32 / gridDim.x) + 1 from the host: floor(m / gridDim.x) == mulhi(m, magic) for
 // every tile index (m * gridDim.x < 2^32).
-__device__ __forceinline__ void xcd_tile(unsigned magic, int& tx, int& ty)
+// `strip_len` > 0 (host: tile_xcd_strips): an XCD's share is not one block of the image but strips of
+// strip_len tiles spread over it (strip s of XCD x = global strip 8 s + x): tiles differ in cost (source
+// boxes that do not fit LDS gather from global memory, single-buffered boxes, tiles left to the pair
+// code) and the expensive ones cluster, so one block per XCD left some XCDs with most of them -- the
+// kernel is as slow as its slowest XCD.  `strip_magic` = floor(2^32 / strip_len) + 1.
+__device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, unsigned strip_magic, int& tx, int& ty)
 {
     tx = blockIdx.x, ty = blockIdx.y;
 #if V1C_XCD_SWIZZLE
     const unsigned ntile = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
     const unsigned per = ntile >> 3;  // tiles per XCD; the remainder keeps its natural order
     if (lin < per * 8u) {
-        const unsigned m = (lin & 7u) * per + (lin >> 3);
+        unsigned m = (lin & 7u) * per + (lin >> 3);
+        if (strip_len) {
+            const unsigned i = lin >> 3, sidx = __umulhi(i, strip_magic);  // = i / strip_len (i * strip_len < 2^32)
+            m = (sidx * 8u + (lin & 7u)) * strip_len + (i - sidx * strip_len);
+        }
         ty = gridDim.x == 1 ? (int)m : (int)__umulhi(m, magic);  // (2^32 / 1 + 1 does not fit the magic)
         tx = (int)(m - (unsigned)ty * gridDim.x);
     }
@@ -1256,7 +1265,8 @@ template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR, int LIST = 0>
 // test split the kernel-argument loads of the prologue over two more dependent waits.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && PAIR && K == 2 && !ROT && !OWN) ? V1C_PAIR_WAVES : 1, 8))) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                        int upb, int half_dwords, unsigned tiles_x_magic,
-                                                       const uint32_t* __restrict__ tile_list, int tiles_x)
+                                                       const uint32_t* __restrict__ tile_list, int tiles_x, unsigned strip_len,
+                                                       unsigned strip_magic)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) int red[16];
@@ -1268,7 +1278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
             const uint32_t v = tile_list[blockIdx.x];
             tx = (int)(v & 0xffffu), ty = (int)(v >> 16);
         } else {
-            xcd_tile(tiles_x_magic, tx, ty);
+            xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
             tiles_x = gridDim.x;
         }
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
@@ -1361,7 +1371,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
 template <int VAR_W, int ROT, int OWN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                              int upb, int half_dwords, unsigned tiles_x_magic,
-                                                             const uint32_t* __restrict__ rest_list, int n_rest)
+                                                             const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len,
+                                                             unsigned strip_magic)
 {
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
@@ -1386,7 +1397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
                                                        half_dwords, tabw, (glb_u32_ptr)c.itab);
         return;
     }
-    xcd_tile(tiles_x_magic, tx, ty);
+    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
     shared_map_tile<VAR_W, ROT, 2, OWN, 0, 256, 1>(c, ua, boxes, n_units, upb, zl, tx, ty, gridDim.x, dyn_box, half_dwords, tabw,
                                                    (glb_u32_ptr) nullptr);
 }
@@ -1452,6 +1463,65 @@ int tile_lean_half_dwords(int half_dwords)
     return std::min(half_dwords, cap);
 }
 
+// Strip length (tiles) of the XCD interleave (xcd_tile) for a plan, 0 = one block per XCD: a cost model
+// of the tiles (box beyond the LDS buffers: gathers from global memory; box needing both lean
+// buffers; not interior) is summed per XCD for 1, 2, 4, 8, 16 strips per XCD; the smallest count
+// within 3 % of the best balance wins.  Short launches keep one block (their first workgroups would
+// all start in the same corner of the image).
+int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int lean_half)
+{
+    static const int forced = [] {  // V1C_XCD_STRIPS=<n>: A/B override (1 = one block per XCD)
+        const char* e = std::getenv("V1C_XCD_STRIPS");
+        return e ? std::atoi(e) : 0;
+    }();
+    const TileBox* b = (const TileBox*)host_boxes;
+    const dim3 d = tile_grid(g, tile_threads(g), 1);
+    const unsigned ntile = d.x * d.y, per = ntile >> 3;
+    if (per < 768 && forced <= 0)
+        return 0;
+    std::vector<float> cost(ntile);
+    for (unsigned i = 0; i < ntile; i++) {
+        const int need = b[i].cpr > 0 ? b[i].nrows * (b[i].cpr * 4 + 4) : 0;
+        const bool stageable = b[i].cpr > 0 && b[i].cpr <= kMaxCpr && b[i].nrows * b[i].cpr <= 1024 && need <= half_dwords;
+        cost[i] = b[i].cpr <= 0 ? 0.5f : 1.0f + (stageable ? 0.0f : 4.0f) + (need > lean_half ? 0.5f : 0.0f) + (b[i].interior ? 0.0f : 0.5f) + (float)need / 16384.0f;
+    }
+    int cand_s[5], n_cand = 0;
+    double cand_load[5];
+    for (int S : {1, 2, 4, 8, 16}) {
+        if (forced > 0 && S != forced)
+            continue;
+        if (per % (unsigned)S != 0 || (S > 1 && per / (unsigned)S < 2 * d.x))
+            continue;
+        const unsigned L = per / (unsigned)S;
+        double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (unsigned x = 0; x < 8; x++)
+            for (unsigned i = 0; i < per; i++) {
+                const unsigned sidx = i / L;
+                load[x] += cost[(sidx * 8u + x) * L + (i - sidx * L)];
+            }
+        const double mx = *std::max_element(load, load + 8);
+        if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+            std::fprintf(stderr, "[v1c] XCD interleave model: %2d strip(s) per XCD -> max load %.0f (mean %.0f)\n", S, mx,
+                         (load[0] + load[1] + load[2] + load[3] + load[4] + load[5] + load[6] + load[7]) / 8);
+        cand_s[n_cand] = S, cand_load[n_cand++] = mx;
+    }
+    if (n_cand == 0)
+        return 0;
+    // leave one block per XCD only for a predicted gain of 3 % or more (strips cost L2 locality: C2, balanced
+    // to 2 %, measured 1.5 % slower with 4 strips); then the fewest strips within 1 % of the best balance
+    int best_s = cand_s[0];
+    if (forced <= 0) {
+        const double lo = *std::min_element(cand_load, cand_load + n_cand);
+        if (cand_s[0] == 1 && lo < 0.97 * cand_load[0])
+            for (int q = 0; q < n_cand; q++)
+                if (cand_load[q] <= 1.01 * lo) {
+                    best_s = cand_s[q];
+                    break;
+                }
+    }
+    return best_s > 1 ? (int)(per / (unsigned)best_s) : 0;
+}
+
 // tiles the lean batch kernel leaves to the general one, as ty << 16 | tx (row-major order)
 std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int half_dwords)
 {
@@ -1511,7 +1581,8 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry,
 
 template <int K>
 static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, int half_dwords,
-                          bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, hipStream_t stream)
+                          bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
+                          hipStream_t stream)
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     static const int upb_max = [] {  // V1C_UPB=<n>: A/B override of the units per workgroup
@@ -1556,19 +1627,21 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     const bool merged = !merge_off && n_rest > 0 && (size_t)n_rest * ((n_units + 1) / 2) <= (size_t)grid.x * grid.y;
     const dim3 merged_grid(grid.x, grid.y, grid.z + 1);
     const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
+    const unsigned slen = bx && strip_len > 0 && ((grid.x * grid.y) >> 3) % (unsigned)strip_len == 0 ? (unsigned)strip_len : 0u;
+    const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
 #define V1C_TILE_P(VW, RT, BX, OW, PR)                                                                                                \
     do {                                                                                                                              \
         if (lean) {                                                                                                                   \
             /* (running the remaining tiles on a side stream, forked and joined with events so that their */                          \
             /* latency-bound kernel overlaps the lean one, measured 4 % slower on C3 than back to back) */                            \
             hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), merged ? merged_grid : grid, block, lean_lds, stream, c, ua, bx,   \
-                               n_units, upb, lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest);               \
+                               n_units, upb, lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest, slen, smagic); \
             if (n_rest > 0 && !merged)                                                                                                \
                 hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, BX, BX>), rest_grid, block, lds, stream, c, ua, bx, n_units, 2, \
-                                   half_dwords, xmagic, rest_list, (int)grid.x);                                                      \
+                                   half_dwords, xmagic, rest_list, (int)grid.x, 0u, 0u);                                              \
         } else {                                                                                                                      \
             hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb,           \
-                               half_dwords, xmagic, (const uint32_t*)nullptr, (int)grid.x);                                           \
+                               half_dwords, xmagic, (const uint32_t*)nullptr, (int)grid.x, slen, smagic);                             \
         }                                                                                                                             \
     } while (0)
 #define V1C_TILE_O(VW, RT, BX, OW)                       \
@@ -1614,13 +1687,14 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 // `rest_list` / `n_rest` / `lean_half` (boxes != null; list may be null): device copy of tile_rest_list() and the box
 // buffer size (dwords) it was made for.
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
-                                bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, hipStream_t stream)
+                                bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
+                          hipStream_t stream)
 {
     const TileBox* bx = (const TileBox*)boxes;
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, stream); break;
-    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, stream); break;
-    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, stream); break;
+    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, stream); break;
+    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, stream); break;
+    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -172,6 +172,7 @@ struct v1c_plan {
     const uint32_t* rest_list = nullptr;  // tiles the lean batch kernel leaves to the general one (device)
     int n_rest = 0;
     int lean_half = 256;          // box buffer dwords of the lean batch kernel (<= half_dwords)
+    int strip_len = 0;            // XCD interleave: tiles per strip (0: one block per XCD), tile_xcd_strips()
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     bool disable_shared_entry = false;  // V1C_DISABLE_SHARED_ENTRY=1: keep the per-pixel table fallback compiled in
     bool disable_mpoly = false;         // V1C_DISABLE_MPOLY=1: no m-polynomial table (every tile takes the square root)
@@ -438,6 +439,9 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     p->half_dwords = std::min(p->half_dwords, std::atoi(e));
                 {
                     p->lean_half = tile_lean_half_dwords(p->half_dwords);
+                    p->strip_len = tile_xcd_strips(hb.data(), g, p->half_dwords, p->lean_half);
+                    if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+                        std::fprintf(stderr, "[v1c] XCD interleave: strips of %d tiles\n", p->strip_len);
                     const std::vector<uint32_t> rest = tile_rest_list(hb.data(), g, p->lean_half);
                     const dim3 full((unsigned)((g.dst_w + 63) / 64), (unsigned)((g.dst_h + 15) / 16));
                     if (full.x <= 0xffffu && full.y <= 0xffffu) {
@@ -580,7 +584,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
                                              shared_entry && !p->disable_shared_entry, mpoly_all && !p->disable_mpoly,
-                                             any_rot ? nullptr : p->rest_list, p->n_rest, p->lean_half, st));
+                                             any_rot ? nullptr : p->rest_list, p->n_rest, p->lean_half, p->strip_len, st));
             } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }
