@@ -10,18 +10,33 @@ radius "max" (BASELINE.json configs[1], "C2").  With N > 1 every rank (one proce
 launched by torch.distributed.run) remaps its own L+R pair per step: the path shards by frame
 with no data-path collective, so scaling is weak and the value is N pairs per step time.
 
+`python bench.py --gpus N` started WITHOUT torch.distributed.run starts its N ranks itself: a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` is spawned before this process has
+made any HIP call, its output is passed through and its exit code returned.
+
+The inputs / outputs of a step rotate over >= 3 buffer sets of > 640 MiB in total, so no step finds
+its source or destination lines in the 256 MiB Infinity Cache (L3-cold, like a stream of frames).
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused remap launch):
 algorithmic bytes per launch (3 B * (source + destination pixels), both eyes: SURVEY.md 8d)
 over its average duration: two events on the launch stream bracket the K timed steps.  `cpu_baseline` is the
 oracle (plain-C port of the reference path, oracle/) timed on this box's host cores on the same
-workload, rank 0 at N=1 only.
+workload, rank 0 at N=1 only.  `roofline.traffic` is measured by this very run: rank 0 at N=1 runs
+two short `rocprofv3 --pmc` child passes of itself (FETCH_SIZE, WRITE_SIZE; separate passes, gfx950
+corrections of MI355X_MICROARCH.md) after the timed region; `traffic_source` says "live" or names
+the committed file it fell back to.  `cold` is what a first call costs (plan creation + first launch).
 """
 from __future__ import annotations
 
 import argparse
+import csv
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -33,6 +48,9 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+ROTATE_MIN_BYTES = 640 << 20  # > 2x the 256 MiB Infinity Cache
+ROTATE_MIN_SETS = 3
+PMC_STEPS, PMC_WARMUP = 6, 2  # length of a rocprofv3 --pmc child pass
 
 WORKLOADS = {
     # name: (eye size, transformer spec, interpolation)
@@ -176,6 +194,98 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
     return res, parity
 
 
+def spawn_ranks(args, argv: list[str]) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process
+    (this process has made no HIP call yet and never makes one), pass its output through, return its
+    exit code.  Never exec / re-exec."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def _pmc_pass(counter: str, workload: str, timeout_s: float):
+    """One `rocprofv3 --pmc <counter>` child pass of this bench (short, nothing else profiled): mean
+    counter value of the dominant remap kernel, or None.  The child is a fresh process; this one only waits."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="v1c_pmc_")
+    env = dict(os.environ, V1C_BENCH_CHILD="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
+           str(Path(__file__).resolve()), "--workload", workload, "--steps", str(PMC_STEPS), "--warmup", str(PMC_WARMUP), "--no-cpu-baseline",
+           "--traffic", "none", "--no-cold-extra"]
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, 9)  # exactly the process group started above
+            p.wait()
+            return None
+        rows = []
+        for f in Path(tmp).rglob("*counter_collection.csv"):
+            rows += [r for r in csv.DictReader(open(f)) if r.get("Counter_Name") == counter and
+                     ("k_ray" in r.get("Kernel_Name", "") or "k_remap" in r.get("Kernel_Name", ""))]
+        if not rows:
+            return None
+        by_kernel: dict[str, list[float]] = {}
+        for r in rows:
+            by_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+        # the dominant kernel = the one with the largest counter total; per STEP = total / steps of the child
+        kern = max(by_kernel, key=lambda k: sum(by_kernel[k]))
+        return kern, sum(sum(v) for v in by_kernel.values()) / (1 + PMC_WARMUP + PMC_STEPS)  # + the cold first step
+    except Exception:  # noqa: BLE001 - traffic must never break the bench line
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_traffic(workload: str):
+    """HBM bytes per step (= per launch for the pair workloads) from the PMC counters, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate passes, both
+    in KiB; gfx950 tallies 64 B per 128-B read request, so FETCH_SIZE is doubled; WRITE_SIZE is exact."""
+    f = _pmc_pass("FETCH_SIZE", workload, 240.0)
+    if f is None:
+        return None
+    w = _pmc_pass("WRITE_SIZE", workload, 240.0)
+    if w is None:
+        return None
+    return {"hbm_bytes_per_step": int(f[1] * 1024 * 2 + w[1] * 1024), "fetch_bytes_corrected": int(f[1] * 1024 * 2),
+            "write_bytes": int(w[1] * 1024), "kernel": f[0].split("(")[0]}
+
+
+def cold_call(cfg, dev, V, transformer_builder):
+    """What the reference's own use case (one apply_lr per process, cli.py) pays on top of the kernel:
+    plan creation (host radial fit + validation, tile boxes, tables) and the first launch, on fresh
+    geometry.  Wall time, synchronised on both sides."""
+    from vr180_convert_amd import remapper as R
+    from vr180_convert_amd.synth import noise_disc_torch
+
+    size = cfg["size"]
+    left, right = noise_disc_torch(size, size, 1000, dev), noise_disc_torch(size, size, 1001, dev)
+    sbs = torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)
+    t = transformer_builder(cfg)
+    R.clear_caches()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    V.apply_lr_tensors(t, left, right, out=sbs, size_output=(size, size), interpolation=cfg["interp"], radius="max")
+    torch.cuda.synchronize(dev)
+    first = (time.perf_counter() - t0) * 1e3
+    create = sum(p.create_ms for p in R._PLANS.values())
+    t0 = time.perf_counter()
+    V.apply_lr_tensors(t, left, right, out=sbs, size_output=(size, size), interpolation=cfg["interp"], radius="max")
+    torch.cuda.synchronize(dev)
+    second = (time.perf_counter() - t0) * 1e3
+    return {"plan_create_ms": round(create, 3), "first_call_ms": round(first, 3), "second_call_ms": round(second, 3)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,18 +293,30 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
+                    help="roofline.traffic: measured by rocprofv3 --pmc child passes of this run (N=1), read from "
+                         "profiles/traffic_latest.json, or omitted")
+    ap.add_argument("--no-cold-extra", action="store_true", help="skip the 8192x8192 Lanczos4 cold-call measurement")
+    ap.add_argument("--no-rotate", action="store_true", help="A/B only: replay ONE buffer set (L3-warm for small workloads)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: start the ranks ourselves, as a child, before any HIP call
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for a different job")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     # V1C_BENCH_REHEARSAL=1: rehearse the multi-rank path on a box with fewer GPUs than ranks (gloo for the
     # barrier / MAX reduction, ranks share the devices there are) -- never a measurement
     rehearsal = os.environ.get("V1C_BENCH_REHEARSAL", "0") == "1"
+    if not rehearsal and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} HIP devices")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count() if rehearsal else local_rank)
     torch.cuda.set_device(dev)
 
@@ -209,43 +331,65 @@ def main() -> None:
 
     import vr180_convert_amd as V
     from vr180_convert_amd import _native
-    from vr180_convert_amd.synth import noise_disc
+    from vr180_convert_amd import remapper as R
+    from vr180_convert_amd.sharding import shard_range
+    from vr180_convert_amd.synth import noise_disc, noise_disc_torch
 
     _native.lib()  # fail loudly if the HIP engine is missing
     cfg = WORKLOADS[args.workload]
     size = cfg["size"]
     transformer = build_transformer(cfg)
     frames = cfg.get("frames", 0)
+    units = 2 * max(frames, 1)
+    set_bytes = units * 3 * (size * size + size * size)
+    nsets = 1 if args.no_rotate else max(ROTATE_MIN_SETS, -(-ROTATE_MIN_BYTES // set_bytes))
     left_h = right_h = None
+    sets = []
     if frames:
-        # batch of SBS frames resident in HBM; units are the column halves (pitched views), each
-        # eye is written straight into its half of the output SBS frame
-        from vr180_convert_amd.synth import noise_disc_torch
-
-        ins = [noise_disc_torch(size, 2 * size, rank * frames + f, dev) for f in range(frames)]
-        outs = [torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev) for _ in range(frames)]
-        srcs = [v for fr in ins for v in (fr[:, :size], fr[:, size:])]
-        dsts = [v for fr in outs for v in (fr[:, :size], fr[:, size:])]
+        # batch of SBS frames resident in HBM; units are the column halves (pitched views), each eye is
+        # written straight into its half of the output SBS frame.  The job's frames*world frames are
+        # dealt to the ranks by the product's partition (sharding.shard_range): this rank's block
+        mine = list(shard_range(frames * world, rank, world))
+        assert len(mine) == frames
         rots = None
         if cfg["rot"] == "calib":
-            rots = [m for f in range(frames) for m in calib_rotations(rank * frames + f)]
-        sbs = outs[0]
+            rots = [m for f in mine for m in calib_rotations(f)]
+        for k in range(nsets):
+            ins = [noise_disc_torch(size, 2 * size, f + 100003 * k, dev) for f in mine]
+            outs = [torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev) for _ in mine]
+            sets.append(dict(srcs=[v for fr in ins for v in (fr[:, :size], fr[:, size:])],
+                             dsts=[v for fr in outs for v in (fr[:, :size], fr[:, size:])], sbs=outs[0]))
 
-        def step():
-            V.remap_tensors(transformer, srcs, dsts, radius=size / 2, interpolation=cfg["interp"], rotations=rots)
+        def step(i: int):
+            b = sets[i % nsets]
+            V.remap_tensors(transformer, b["srcs"], b["dsts"], radius=size / 2, interpolation=cfg["interp"], rotations=rots)
     else:
-        # seeded noise-disc frames; frame index = rank so ranks hold different pixels
+        # seeded noise-disc frames; frame index = rank so ranks hold different pixels;
+        # set 0 is the numpy-seeded pair the CPU baseline / parity check uses, the others are generated on the device
         left_h, right_h = noise_disc(size, size, 2 * rank), noise_disc(size, size, 2 * rank + 1)
-        left, right = torch.from_numpy(left_h).to(dev), torch.from_numpy(right_h).to(dev)
-        sbs = torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)
+        for k in range(nsets):
+            if k == 0:
+                left, right = torch.from_numpy(left_h).to(dev), torch.from_numpy(right_h).to(dev)
+            else:
+                left, right = (noise_disc_torch(size, size, 2 * rank + e + 100003 * k, dev) for e in (0, 1))
+            sets.append(dict(left=left, right=right, sbs=torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)))
 
-        def step():
-            V.apply_lr_tensors(transformer, left, right, out=sbs, size_output=(size, size), interpolation=cfg["interp"],
-                               radius="max")
+        def step(i: int):
+            b = sets[i % nsets]
+            V.apply_lr_tensors(transformer, b["left"], b["right"], out=b["sbs"], size_output=(size, size),
+                               interpolation=cfg["interp"], radius="max")
 
     def barrier():
         if world > 1:
             dist.barrier()
+
+    # cold cost of THIS workload: the first step creates the plan (wall time, synchronised)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    step(0)
+    torch.cuda.synchronize(dev)
+    first_call_ms = (time.perf_counter() - t0) * 1e3
+    plan_create_ms = sum(p.create_ms for p in R._PLANS.values())
 
     # Setup, not a step: ~25 ms of device work so that the shader clock has left its idle state
     # before the W warm-up steps (a step is ~0.07 ms; the CPU-side input synthesis above leaves the
@@ -254,8 +398,8 @@ def main() -> None:
     for _ in range(40):
         spin.add_(1)
     del spin
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -265,8 +409,8 @@ def main() -> None:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     e1.record()
     torch.cuda.synchronize(dev)
     barrier()
@@ -274,49 +418,68 @@ def main() -> None:
     elapsed = allreduce_max(elapsed, dev)
     kernel_ms = e0.elapsed_time(e1) / args.steps
     kernel_ms_max = allreduce_max(kernel_ms, dev)
+    per_rank_ms = [kernel_ms]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, kernel_ms)
+        per_rank_ms = [float(v) for v in gathered]
 
-    units = 2 * max(frames, 1)
     px_per_step = units * size * size * world
     value = px_per_step * args.steps / elapsed / 1e6
     # all eyes of a step: source read once + destination written once (a batch is ceil(units/16) launches:
     # the figure is per step, i.e. per group of launches, for batch workloads)
-    alg_bytes = units * 3 * (size * size + size * size)
+    alg_bytes = set_bytes
     achieved = alg_bytes / (kernel_ms_max * 1e-3) / 1e9
 
     if rank == 0:
-        from vr180_convert_amd.remapper import _PLANS
-
-        paths = sorted({p.path for p in _PLANS.values()})
-        # HBM bytes per launch from the PMC counters: collected by tools/profile.sh in separate
-        # rocprofv3 --pmc passes of this very command (a profiler cannot run inside the timed run)
-        traffic = None
-        tfile = ROOT / "profiles" / "pmc_traffic_latest.json"
-        if tfile.exists():
-            try:
-                t = json.loads(tfile.read_text())
-                if t.get("workload") == args.workload:
-                    traffic = t.get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        paths = sorted({p.path for p in R._PLANS.values()})
         line = {
             "metric": "Mpixels/s dual-fisheye->SBS-equirect remap; achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (seeded uint8 noise inside the fisheye circle, black outside), resident in HBM"
+            "data": "synthetic (seeded uint8 noise inside the fisheye circle, black outside), resident in HBM, "
+                    f"{nsets} input/output buffer sets rotated per step ({nsets * set_bytes / 2**20:.0f} MiB: L3-cold)"
                     + (" -- REHEARSAL: ranks share devices, gloo; not a measurement" if rehearsal else ""),
             "config": {"workload": f"{args.workload}: {cfg['desc']}", "units_per_step_per_gpu": units,
                        "arithmetic": "f64 coordinates (fused chain), u8 pixels with int32 fixed-point blend",
-                       "sharding": "frames over ranks, no collective", "kernel_path": paths},
+                       "sharding": "frames over ranks (sharding.shard_range), no collective", "kernel_path": paths,
+                       "buffer_sets": nsets},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel_ms": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": alg_bytes},
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
+                         "kernel_ms": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                         "per_gpu_frac": [round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for ms in per_rank_ms]},
+            "cold": {"plan_create_ms": round(plan_create_ms, 3), "first_call_ms": round(first_call_ms, 3)},
         }
-        if world == 1 and not args.no_cpu_baseline and not frames:
-            torch.cuda.synchronize(dev)
-            cb, parity = cpu_baseline(cfg, left_h, right_h, sbs.cpu().numpy())
-            line["cpu_baseline"] = cb
-            line["parity_vs_oracle"] = parity
+        child = os.environ.get("V1C_BENCH_CHILD") == "1" or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if world == 1 and not child:
+            if not frames:
+                torch.cuda.synchronize(dev)
+                gpu_out = sets[0]["sbs"].cpu().numpy()  # set 0 = the numpy-seeded pair
+            if args.traffic == "live":
+                t = measure_traffic(args.workload)
+                if t is not None:
+                    line["roofline"]["traffic"] = t["hbm_bytes_per_step"]
+                    line["roofline"]["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run"
+                    line["roofline"]["traffic_detail"] = t
+            if line["roofline"]["traffic"] is None and args.traffic != "none":
+                tfile = ROOT / "profiles" / "traffic_latest.json"
+                try:
+                    t = json.loads(tfile.read_text()).get(args.workload)
+                    if t:
+                        line["roofline"]["traffic"] = t.get("hbm_bytes_per_step")
+                        line["roofline"]["traffic_source"] = f"file: profiles/traffic_latest.json ({t.get('tag')})"
+                except Exception:  # noqa: BLE001
+                    pass
+            if not args.no_cold_extra and args.workload != "C4":
+                try:
+                    line["cold_C4_8192_lanczos4"] = cold_call(WORKLOADS["C4"], dev, V, build_transformer)
+                except Exception as e:  # noqa: BLE001
+                    line["cold_C4_8192_lanczos4"] = {"error": repr(e)}
+            if not args.no_cpu_baseline and not frames:
+                cb, parity = cpu_baseline(cfg, left_h, right_h, gpu_out)
+                line["cpu_baseline"] = cb
+                line["parity_vs_oracle"] = parity
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

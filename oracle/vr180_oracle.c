@@ -22,7 +22,7 @@
  *       installed in the build container or on the GPU box and the reference's tests assert no
  *       pixel value, so this part is a restatement of the published algorithm:
  *       *** PARITY UNPINNED at the cv2.remap boundary *** except for the coarse known-answer
- *       test on the reference's docs/_static example pair (tests/test_oracle_kat.py).
+ *       test on the reference's docs/_static example pair (tests/test_oracle_remap.py::test_known_answer_reference_docs_pair).
  *
  *   (3) get_radius()                                  transformer.py:108-140
  *

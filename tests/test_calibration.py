@@ -93,3 +93,52 @@ def test_calibration_names_live_in_remapper_like_the_reference():
 
     assert R.rotation_match is calibration.rotation_match and R.match_lr is calibration.match_lr
     assert R.rotation_match_robust is calibration.rotation_match_robust
+
+
+def test_quaternion_convention_is_pinned_by_the_references_own_rotation_match(golden_dir):
+    """The reference's only rotation contract (tests/test_remapper.py:118-130): points rotated with
+    numpy-quaternion's ``rotate_vectors(q, a)`` are recovered by ``rotation_match(a, b) == q``, so the
+    quaternion -> rotation convention of the package IS the one rotation_match's NumPy math solves for
+    (Hamilton product, active rotation: (0, R a) = q (0, a) q^-1, docs/math.md:7-24).  ``q0`` of the
+    fixture is what the REFERENCE's rotation_match returned for the noise-free pair (a0, b0): this
+    engine's ``as_rotation_matrix`` (quat.py, used by Euclidean3DRotator and every rotated plan) must
+    carry a0 onto b0 -- a transposed (passive) or differently ordered convention fails by O(1)."""
+    from vr180_convert_amd.quat import as_rotation_matrix, quaternion, rotate_vectors as rv
+
+    g = np.load(golden_dir / "rotation_match.npz")
+    a, b, q = g["a0"], g["b0"], g["q0"]
+    m = as_rotation_matrix(quaternion(*q))
+    np.testing.assert_allclose(m @ a.T, b.T, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(rv(quaternion(*q), a), b, rtol=0, atol=1e-12)  # the rotate_vectors call shape of transformer.py:676
+    np.testing.assert_allclose(as_rotation_matrix(quaternion(*(-q))), m, rtol=0, atol=1e-15)  # q and -q: one rotation
+    # non-unit quaternions are normalised, not rejected (the CLI's pseudo-half quaternions, cli.py:308-319)
+    np.testing.assert_allclose(as_rotation_matrix(quaternion(*(1.7 * q))), m, rtol=0, atol=1e-14)
+    # the noisy pairs: the reference's q is the least-squares rotation, so it must beat small perturbations of itself
+    for k in (1, 2):
+        ak, bk, qk = g[f"a{k}"], g[f"b{k}"], g[f"q{k}"]
+        e0 = np.sum((ak @ as_rotation_matrix(quaternion(*qk)).T - bk) ** 2)
+        rng = np.random.default_rng(k)
+        for _ in range(8):
+            qp = qk + 1e-3 * rng.normal(size=4)
+            assert np.sum((ak @ as_rotation_matrix(quaternion(*qp)).T - bk) ** 2) > e0
+
+
+def test_rotation_vector_and_euler_constructors_mean_what_the_reference_tests_assume():
+    """from_rotation_vector(r): rotation by |r| about r, right-handed, active -- checked on the axes
+    against the pinned matrix convention; from_euler_angles(0, b, 0) is the same rotation as
+    from_rotation_vector([0, b, 0]) (tests/test_remapper.py:80 and tests/test_cli.py:33 use the two
+    spellings for the one "pi/4 about y" rotation of the reference's test chains)."""
+    from vr180_convert_amd.quat import as_rotation_matrix, from_euler_angles
+
+    t = 0.3
+    c, s = np.cos(t), np.sin(t)
+    np.testing.assert_allclose(as_rotation_matrix(from_rotation_vector([0, 0, t])), [[c, -s, 0], [s, c, 0], [0, 0, 1]], atol=1e-15)
+    np.testing.assert_allclose(as_rotation_matrix(from_rotation_vector([0, t, 0])), [[c, 0, s], [0, 1, 0], [-s, 0, c]], atol=1e-15)
+    np.testing.assert_allclose(as_rotation_matrix(from_rotation_vector([t, 0, 0])), [[1, 0, 0], [0, c, -s], [0, s, c]], atol=1e-15)
+    np.testing.assert_allclose(as_rotation_matrix(from_euler_angles(0.0, np.pi / 4, 0.0)),
+                               as_rotation_matrix(from_rotation_vector([0, np.pi / 4, 0])), atol=1e-15)
+    # z-y-z composition: R = Rz(alpha) Ry(beta) Rz(gamma)
+    al, be, ga = 0.4, -0.7, 1.1
+    rz = lambda x: as_rotation_matrix(from_rotation_vector([0, 0, x]))  # noqa: E731
+    ry = lambda x: as_rotation_matrix(from_rotation_vector([0, x, 0]))  # noqa: E731
+    np.testing.assert_allclose(as_rotation_matrix(from_euler_angles(al, be, ga)), rz(al) @ ry(be) @ rz(ga), atol=1e-15)

@@ -785,3 +785,260 @@ def test_kernel_variants_bit_exact(env):
     probe = Path(__file__).with_name("variant_probe.py")
     r = subprocess.run([sys.executable, str(probe)], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------- full size vs the oracle
+def _all_cores(O):
+    import os
+
+    O.set_threads(os.cpu_count() or 1)
+
+
+def test_c4_full_size_eye_vs_oracle(V, oracle_mod, dev):
+    """BASELINE config 4 at its real size and with its real chain: one 8192 x 8192 eye,
+    EquirectangularEncoder * Euclidean3DRotator(from_euler_angles(0, pi/4, 0)) * PolynomialScaler([0,1,-0.1])
+    * FisheyeDecoder("equidistant"), INTER_LANCZOS4 -- all 201 326 592 output bytes against the oracle
+    (literal fp64 chain + restated cv2.remap, every host core of the GPU box)."""
+    from vr180_convert_amd.synth import noise_disc
+
+    spec, out, inp, radius = CS.FULL_CASES["C4"]
+    O = oracle_mod
+    _all_cores(O)
+    try:
+        img = noise_disc(8192, 8192, 40)
+        want = O.apply(spec, [img], size_output=out, interpolation=4, radius="max")[0]
+        dst = torch.empty((8192, 8192, 3), dtype=torch.uint8, device=dev)
+        assert V.remap_tensors(CS.to_product(spec), [torch.from_numpy(img).to(dev)], [dst], radius=4096.0, interpolation=4) == ["ray"]
+        got = dst.cpu().numpy()
+        assert got.shape == want.shape == (8192, 8192, 3)
+        assert np.array_equal(got, want), int((got != want).sum())
+        # and the pair kernel (both eyes of the apply_lr launch) writes the same bytes for this eye
+        sbs = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(img).to(dev), torch.from_numpy(img).to(dev),
+                                 size_output=out, interpolation=4, radius="max")
+        assert torch.equal(sbs[:, :8192], dst) and torch.equal(sbs[:, 8192:], dst)
+    finally:
+        O.set_threads(min(8, __import__("os").cpu_count() or 1))
+
+
+def test_c5_full_size_units_vs_oracle(V, oracle_mod, dev):
+    """BASELINE config 5 at its real size: both eyes of a 7680 x 3840 SBS frame (2 x 3840^2), each with
+    its own calibration rotation (cli.py:308-319 pseudo-half quaternions), bilinear -- through the
+    rotations= path that shares one plan -- against the oracle evaluating each unit's own chain."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    _all_cores(O)
+    try:
+        n = 3840
+        frame = noise_disc(n, 2 * n, 50)
+        base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+        quats = [CS.c5_spec(7, eye)[1][1] for eye in (0, 1)]
+        fr = torch.from_numpy(frame).to(dev)
+        out = torch.empty((n, 2 * n, 3), dtype=torch.uint8, device=dev)
+        assert V.remap_tensors(base, [fr[:, :n], fr[:, n:]], [out[:, :n], out[:, n:]], radius=n / 2, interpolation=1,
+                               rotations=quats) == ["ray"]
+        got = out.cpu().numpy()
+        for eye in (0, 1):
+            want = O.apply(CS.c5_spec(7, eye), [frame[:, eye * n:(eye + 1) * n]], size_output=(n, n), interpolation=1, radius="max")[0]
+            assert np.array_equal(got[:, eye * n:(eye + 1) * n], want), (eye, int((got[:, eye * n:(eye + 1) * n] != want).sum()))
+    finally:
+        O.set_threads(min(8, __import__("os").cpu_count() or 1))
+
+
+def test_c3_full_size_frames_vs_oracle(V, oracle_mod, dev):
+    """BASELINE config 3 at its real size: SBS frames of 5760 x 2880 split into halves (remapper.py:448-456),
+    one shared equidistant map, bilinear, through the lean batch kernel (8 frames = 16 units in one launch);
+    three of the units against the oracle."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    _all_cores(O)
+    try:
+        n = 2880
+        t = T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant")
+        host = [noise_disc(n, 2 * n, 300 + f) for f in range(8)]
+        frames = [torch.from_numpy(h).to(dev) for h in host]
+        outs = [torch.empty((n, 2 * n, 3), dtype=torch.uint8, device=dev) for _ in frames]
+        srcs = [v for fr in frames for v in (fr[:, :n], fr[:, n:])]
+        dsts = [v for fr in outs for v in (fr[:, :n], fr[:, n:])]
+        assert V.remap_tensors(t, srcs, dsts, radius=n / 2, interpolation=1) == ["ray"]
+        spec = [("equirect_enc", True), ("fisheye_dec", "equidistant")]
+        xm, ym = O.get_map(spec, radius=n / 2, size_input=(n, n), size_output=(n, n))
+        for f, eye in ((0, 0), (3, 1), (7, 1)):
+            want = O.remap(host[f][:, eye * n:(eye + 1) * n], xm, ym, 1)
+            got = outs[f][:, eye * n:(eye + 1) * n].cpu().numpy()
+            assert np.array_equal(got, want), (f, eye)
+    finally:
+        O.set_threads(min(8, __import__("os").cpu_count() or 1))
+
+
+# ---------------------------------------------------------------------------- live third-party hooks
+@pytest.mark.parametrize("interp", [0, 1, 2, 4])
+def test_device_remap_equals_live_cv2_when_present(V, oracle_mod, dev, interp):
+    """where opencv-python is importable ON THE GPU BOX it is the live third-party oracle
+    for cv2.remap (Appendix A): the device sampler (v1c_remap_lut through the C ABI) and the C restatement
+    must both equal it bit for bit, every border mode.  Skipped (and recorded as such by smoke()) when
+    the image has no cv2."""
+    cv2 = pytest.importorskip("cv2")
+    rng = np.random.default_rng(11)
+    src = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
+    xm = rng.uniform(-12, 95, (70, 90)).astype(np.float32)
+    ym = rng.uniform(-12, 73, (70, 90)).astype(np.float32)
+    xm[3, 4] = np.nan
+    ym[5, 6] = np.inf
+    from vr180_convert_amd import _native
+    from vr180_convert_amd.remapper import _stream_ptr, border_scalar
+
+    s_d, x_d, y_d = (torch.from_numpy(a).to(dev) for a in (src, xm, ym))
+    for border in (0, 1, 2, 3, 4):
+        want = cv2.remap(src, xm, ym, interpolation=interp, borderMode=border, borderValue=(7, 0, 0))
+        dst = torch.zeros((70, 90, 3), dtype=torch.uint8, device=dev)
+        bv = border_scalar(7)
+        rc = _native.lib().v1c_remap_lut(0, _stream_ptr(dev), s_d.data_ptr(), 61, 83, s_d.stride(0), 3, dst.data_ptr(), 70, 90,
+                                         dst.stride(0), x_d.data_ptr(), y_d.data_ptr(), x_d.stride(0) * 4, interp, border, bv.ctypes.data)
+        _native.check(rc, "v1c_remap_lut")
+        got = dst.cpu().numpy()
+        assert np.array_equal(got, want), (cv2.__version__, interp, border, int((got != want).sum()))
+        assert np.array_equal(oracle_mod.remap(src, xm, ym, interp, border, 7), want), (cv2.__version__, interp, border)
+
+
+def test_quat_helpers_equal_live_numpy_quaternion_when_present():
+    """Where numpy-quaternion is importable on the GPU box: quat.py's as_rotation_matrix / rotate_vectors /
+    from_euler_angles / from_rotation_vector against the package the reference uses (transformer.py:10,676)."""
+    quaternion = pytest.importorskip("quaternion")
+    from vr180_convert_amd import quat as Q
+
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        w, x, y, z = rng.normal(size=4)
+        ref = quaternion.as_rotation_matrix(quaternion.quaternion(w, x, y, z))
+        np.testing.assert_allclose(Q.as_rotation_matrix((w, x, y, z)), ref, atol=1e-14)
+        v = rng.normal(size=(7, 3))
+        np.testing.assert_allclose(Q.rotate_vectors((w, x, y, z), v), quaternion.rotate_vectors(quaternion.quaternion(w, x, y, z), v), atol=1e-13)
+        a, b, c = rng.uniform(-3, 3, 3)
+        e = quaternion.from_euler_angles(a, b, c)
+        np.testing.assert_allclose(Q.from_euler_angles(a, b, c).components(), [e.w, e.x, e.y, e.z], atol=1e-14)
+        r = quaternion.from_rotation_vector([a, b, c])
+        np.testing.assert_allclose(Q.from_rotation_vector([a, b, c]).components(), [r.w, r.x, r.y, r.z], atol=1e-14)
+
+
+# ---------------------------------------------------------------------------- round-2 regressions
+def test_apply_lr_tuple_transformers_unequal_eye_widths(V, oracle_mod, tmp_path):
+    """An odd-width SBS file with left_path == right_path splits into W // 2 and W - W // 2 columns
+    (remapper.py:455-456); with per-eye transformers every eye is its own apply() call and takes the
+    Denormalize centre from ITS shape (remapper.py:460-473, :385) -- also when the two radii are equal."""
+    from vr180_convert_amd import _io
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    sbs_in = noise_disc(120, 241, 9)  # halves: 120 and 121 columns
+    p = tmp_path / "odd.png"
+    _io.imwrite(p, sbs_in)
+    specs = ([("equirect_enc", True), ("rot", CS.ry(0.04)), CS.EQUI], [("equirect_enc", True), ("rot", CS.ry(-0.04)), CS.EQUI])
+    out_p = tmp_path / "odd_out.png"
+    V.apply_lr(tuple(CS.to_product(s) for s in specs), left_path=p, right_path=p, out_path=out_p, size_output=(96, 96),
+               interpolation=1, radius=57.0)
+    want = O.apply_lr(specs, sbs_in[:, :120], sbs_in[:, 120:], size_output=(96, 96), interpolation=1, radius=57.0)
+    assert np.array_equal(_io.imread(out_p), want)
+
+
+def test_memo_keys_are_exact_not_printed(V, oracle_mod, dev):
+    """Two chains whose parameters differ below NumPy's print precision (and under a coarse
+    np.set_printoptions) must not share a lowered chain / plan: each call equals ITS oracle result."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    img = noise_disc(256, 256, 3)
+    src = torch.from_numpy(img).to(dev)
+    old = np.get_printoptions()
+    np.set_printoptions(precision=2)
+    try:
+        outs = []
+        for c2 in (-0.1, -0.1000000001, -0.1004):
+            t = T.EquirectangularEncoder() * T.PolynomialScaler(np.array([0, 1, c2])) * T.FisheyeDecoder("equidistant")
+            dst = torch.empty((256, 256, 3), dtype=torch.uint8, device=dev)
+            V.remap_tensors(t, [src], [dst], radius=128.0, interpolation=1)
+            want = O.apply([("equirect_enc", True), ("poly", [0, 1, c2]), CS.EQUI], [img], size_output=(256, 256), interpolation=1, radius=128.0)[0]
+            assert np.array_equal(dst.cpu().numpy(), want), c2
+            outs.append(dst.cpu().numpy())
+        assert not np.array_equal(outs[0], outs[2])
+        # rotations 2e-9 apart, given as matrices (ndarray fields)
+        for ang in (0.3, 0.3 + 2e-9, 0.31):
+            t = T.EquirectangularEncoder() * T.Euclidean3DRotator(np.array(CS.ry(ang))) * T.FisheyeDecoder("equidistant")
+            dst = torch.empty((256, 256, 3), dtype=torch.uint8, device=dev)
+            V.remap_tensors(t, [src], [dst], radius=128.0, interpolation=1)
+            want = O.apply([("equirect_enc", True), ("rot", CS.ry(ang)), CS.EQUI], [img], size_output=(256, 256), interpolation=1, radius=128.0)[0]
+            assert np.array_equal(dst.cpu().numpy(), want), ang
+    finally:
+        np.set_printoptions(**old)
+
+
+def test_one_plan_from_two_threads_and_streams(V, oracle_mod, dev):
+    """A plan is shared by every thread of the process (remapper._PLANS): two threads remap the same geometry
+    on their own streams, 24 calls each, with a chain whose radial table has flagged intervals (rectilinear
+    decoder: pole at 90 degrees) so that every call runs the ray pass AND the fix-up pass that consumes the
+    plan's tile-flag words.  Every result must equal the oracle's."""
+    import threading
+
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    spec = [("equirect_enc", True), ("zoom", 1.4), ("fisheye_dec", "rectilinear")]
+    t = CS.to_product(spec)
+    imgs = [noise_disc(300, 300, 60 + k) for k in range(2)]
+    wants = [O.apply(spec, [im], size_output=(320, 256), interpolation=1, radius=40.0)[0] for im in imgs]
+    errs = []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(dev)
+            src = torch.from_numpy(imgs[k]).to(dev)
+            with torch.cuda.stream(st):
+                for it in range(24):
+                    dst = torch.full((256, 320, 3), 77, dtype=torch.uint8, device=dev)
+                    V.remap_tensors(t, [src], [dst], radius=40.0, interpolation=1)
+                    st.synchronize()
+                    if not np.array_equal(dst.cpu().numpy(), wants[k]):
+                        errs.append((k, it))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs[:5]
+
+
+def test_remap_sharded_on_the_devices_there_are(V, oracle_mod):
+    """sharding.remap_sharded: the in-process multi-device dispatcher (worker thread + stream + staging ring
+    per device).  One GPU on the test box: devices=[0] and devices=[0, 0] (two workers sharing the card)
+    exercise the same code as 8 devices; SBS frames and (L, R) pairs, shared transformer, per-frame rotations."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    n = 96
+    frames = [noise_disc(n, 2 * n, 70 + f) for f in range(5)]
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    want = [O.apply_lr(spec, fr[:, :n], fr[:, n:], size_output=(80, 64), interpolation=1, radius="max") for fr in frames]
+    for devices in ([0], [0, 0]):
+        got = V.remap_sharded(CS.to_product(spec), frames, size_output=(80, 64), interpolation=1, radius="max", devices=devices)
+        assert len(got) == 5 and all(np.array_equal(g, w) for g, w in zip(got, want)), devices
+    # a single pair on two workers: one eye each
+    got = V.remap_sharded(CS.to_product(spec), [(frames[0][:, :n], frames[0][:, n:])], size_output=(80, 64), interpolation=1,
+                          radius="max", devices=[0, 0])
+    assert np.array_equal(got[0], want[0])
+    # per-frame, per-eye calibration rotations (BASELINE config 5)
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    rots = [tuple(CS.c5_spec(f, eye)[1][1] for eye in (0, 1)) for f in range(5)]
+    got = V.remap_sharded(base, frames, size_output=(64, 64), interpolation=1, radius=n / 2, rotations=rots, devices=[0, 0])
+    for f in range(5):
+        w = np.concatenate([O.apply(CS.c5_spec(f, eye), [frames[f][:, eye * n:(eye + 1) * n]], size_output=(64, 64), interpolation=1,
+                                    radius=n / 2)[0] for eye in (0, 1)], axis=1)
+        assert np.array_equal(got[f], w), f

@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench lines (no CPU baseline) of the workloads given as arguments: bash tools/quick_bench.sh C2 C3 C5
 for WL in "$@"; do
-  python3 bench.py --no-cpu-baseline --workload $WL 2>/dev/null | python3 -c "
+  python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --workload $WL 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -16,6 +16,7 @@ from .chain import (
     ZoomTransformer,
 )
 from .remapper import anaglyph_tensors, apply, apply_lr, apply_lr_tensors, get_map, remap_tensors
+from .sharding import remap_sharded
 
 __all__ = [
     "TransformerBase",
@@ -36,4 +37,5 @@ __all__ = [
     "apply_lr_tensors",
     "anaglyph_tensors",
     "remap_tensors",
+    "remap_sharded",
 ]

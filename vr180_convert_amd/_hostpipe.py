@@ -41,9 +41,10 @@ def enabled(n_images: int, result_bytes: int = 0) -> bool:
 
 
 def run(images: Sequence[Any], dev: torch.device, out_hw_c: tuple[int, int, int],
-        remap: Callable[[list[torch.Tensor], list[torch.Tensor]], None]) -> list[np.ndarray]:
+        remap: Callable[..., None], with_index: bool = False) -> list[np.ndarray]:
     """``images``: uint8 (H, W, C) ndarrays of one shape (host).  ``remap(srcs, dsts)`` launches the
-    remap of one group on the current stream.  Returns one page-locked-backed ndarray per image."""
+    remap of one group on the current stream (``with_index``: ``remap(srcs, dsts, idx)`` with the
+    positions of the group's images in ``images``).  Returns one page-locked-backed ndarray per image."""
     n = len(images)
     h, w, cn = out_hw_c
     in_shape = tuple(np.asarray(images[0]).shape)
@@ -86,7 +87,10 @@ def run(images: Sequence[Any], dev: torch.device, out_hw_c: tuple[int, int, int]
                 main.wait_event(ev_in[slot])
                 if g >= nslots:
                     main.wait_event(ev_out[slot])
-                remap(src_dev[slot][: len(idx)], dst_dev[slot][: len(idx)])
+                if with_index:
+                    remap(src_dev[slot][: len(idx)], dst_dev[slot][: len(idx)], idx)
+                else:
+                    remap(src_dev[slot][: len(idx)], dst_dev[slot][: len(idx)])
                 ev_done[slot].record(main)
                 with torch.cuda.stream(s_out):
                     s_out.wait_event(ev_done[slot])

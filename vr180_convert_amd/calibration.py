@@ -1,8 +1,8 @@
 """Rotation estimation of the reference's calibration path: the closed-form pieces.
 
 ``rotation_match`` / ``rotation_match_robust`` (reference remapper.py:93-191) produce the per-pair
-quaternions that ``remap_tensors(..., rotations=...)`` consumes (BASELINE config 5).  They are a few
-4x4 products on the host, exactly like the reference.  Feature detection and matching
+quaternions that ``remap_tensors(..., rotations=...)`` consumes (BASELINE config 5).  They are one
+3x3 correlation and one symmetric 4x4 eigenproblem on the host.  Feature detection and matching
 (``match_points``, remapper.py:194-248: cv2.AKAZE + BFMatcher) needs OpenCV and is not mirrored;
 everything downstream of the matched points is: ``match_lr`` (points -> unit rays through the
 decoder's inverse, remapper.py:251-321), the rotation fit, and ``calibration_rotators`` (the
@@ -28,48 +28,60 @@ def rotate_vectors(q: Any, v: np.ndarray) -> np.ndarray:
     return np.einsum("ij,...j->...i", as_rotation_matrix(q), np.asarray(v, dtype=float))
 
 
+def _horn_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Symmetric 4x4 matrix N (order w, x, y, z) with ``sum_k b_k . R(q) a_k == q^T N q`` for unit q:
+    expanding ``R(q) a = q (0, a) q^-1`` makes every entry a signed sum of entries of the 3x3
+    correlation ``M = sum_k a_k b_k^T`` (Horn 1987, closed-form absolute orientation)."""
+    m = a.T @ b
+    (sxx, sxy, sxz), (syx, syy, syz), (szx, szy, szz) = m
+    return np.array([
+        [sxx + syy + szz, syz - szy, szx - sxz, sxy - syx],
+        [syz - szy, sxx - syy - szz, sxy + syx, szx + sxz],
+        [szx - sxz, sxy + syx, syy - sxx - szz, syz + szy],
+        [sxy - syx, szx + sxz, syz + szy, szz - sxx - syy],
+    ])
+
+
 def rotation_match(points_to_be_rotated: np.ndarray, points: np.ndarray) -> quaternion:
-    """Quaternion minimising ``sum |R a_k - b_k|^2`` (reference remapper.py:93-143;
-    https://lisyarus.github.io/blog/posts/3d-shape-matching-with-quaternions.html):
-    E = sum |q a_k - b_k q|^2 = q^T B q with B = sum S_k^T S_k, S_k = Rmul(a_k) - Lmul(b_k); the
-    minimiser is the eigenvector of the smallest eigenvalue of the symmetric 4x4 matrix B."""
-    a = np.asarray(points_to_be_rotated, dtype=float)
-    b = np.asarray(points, dtype=float)
-    a = np.concatenate([a, np.zeros_like(a[..., :1])], axis=1)
-    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
-    b = np.concatenate([b, np.zeros_like(b[..., :1])], axis=1)
-    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
-    right_mult_matrix = np.array([[aw, -az, ay, -ax], [az, aw, -ax, -ay], [-ay, ax, aw, -az], [ax, ay, az, aw]])
-    left_mult_matrix = np.array([[bw, bz, -by, -bx], [-bz, bw, bx, -by], [by, -bx, bw, -bz], [bx, by, bz, bw]])
-    S = right_mult_matrix - left_mult_matrix
-    B = np.einsum("jik,jlk->il", S, S)
-    eigenvalues, eigenvectors = np.linalg.eig(B)  # (the reference's call; B is symmetric)
-    q = eigenvectors[:, np.argmin(eigenvalues)]
-    LOG.debug("Error: %s", np.sqrt(max(float(np.min(eigenvalues.real)), 0.0)) / len(points))
-    q = np.real(q)
-    return quaternion(q[3], q[0], q[1], q[2])  # eigenvector is (x, y, z, w)
+    """Quaternion q minimising ``E(q) = sum_k |R(q) a_k - b_k|^2`` (reference remapper.py:93-143, derivation
+    docs/math.md:28-59: E is the quadratic form q^T B q, minimised by the eigenvector of B's smallest
+    eigenvalue).  Since ``|R a - b|^2 = |a|^2 + |b|^2 - 2 b.(R a)``, ``B = sum_k (|a_k|^2 + |b_k|^2) I - 2 N``
+    with Horn's matrix N of the 3x3 correlation of the two point sets: the minimiser of E is the eigenvector
+    of N's LARGEST eigenvalue -- one 3x3 product and one symmetric 4x4 eigenproblem (``eigh``), whatever
+    the number of points.  The sign of the result is arbitrary (q and -q are one rotation)."""
+    a = np.asarray(points_to_be_rotated, dtype=float).reshape(-1, 3)
+    b = np.asarray(points, dtype=float).reshape(-1, 3)
+    if a.shape != b.shape:
+        raise ValueError("point sets must have the same shape")
+    lam, vec = np.linalg.eigh(_horn_matrix(a, b))  # ascending eigenvalues
+    w, x, y, z = vec[:, -1]
+    if LOG.isEnabledFor(logging.DEBUG):
+        e_min = float(np.sum(a * a) + np.sum(b * b) - 2.0 * lam[-1])  # = smallest eigenvalue of B = min E
+        LOG.debug("Error: %s", np.sqrt(max(e_min, 0.0)) / max(len(b), 1))
+    return quaternion(w, x, y, z)
 
 
 def rotation_match_robust(points_to_be_rotated: np.ndarray, points: np.ndarray, n_iter: int = 15,
                           quantile: float = 0.9) -> tuple[quaternion, np.ndarray]:
-    """``rotation_match`` repeated while dropping the worst ``1 - quantile`` of the residuals
-    (reference remapper.py:146-191).  Returns the quaternion and the mask of removed points."""
-    a = np.asarray(points_to_be_rotated, dtype=float)
-    b = np.asarray(points, dtype=float)
-    bad_idx = np.full(len(b), False)
+    """``rotation_match`` with iterated trimming (reference remapper.py:146-191): fit, measure every
+    surviving pair's residual ``|R(q) a - b|``, discard the pairs above the ``quantile`` of the residuals,
+    refit -- ``n_iter`` fits in all, the last one is not followed by a trim.  Returns the final quaternion
+    and a mask over the ORIGINAL points that is True for every discarded pair."""
+    a = np.asarray(points_to_be_rotated, dtype=float).reshape(-1, 3)
+    b = np.asarray(points, dtype=float).reshape(-1, 3)
+    alive = np.arange(len(b))  # indices (into the original arrays) of the pairs still in the fit
     q = quaternion(1, 0, 0, 0)
-    for i in range(n_iter):
-        q = rotation_match(points_to_be_rotated=a, points=b)
-        if i == n_iter - 1:
+    for it in range(n_iter):
+        q = rotation_match(a[alive], b[alive])
+        if it + 1 == n_iter:
             break
-        error = np.linalg.norm(rotate_vectors(q, a) - b, axis=-1)
-        threshold = np.quantile(error, quantile)
-        bad_idx_current = error > threshold
-        bad_idx[~bad_idx] = bad_idx_current
-        a = a[~bad_idx_current]
-        b = b[~bad_idx_current]
-        LOG.debug("Removed %d outliers, %d points left.", int(bad_idx_current.sum()), len(b))
-    return q, bad_idx
+        residual = np.linalg.norm(a[alive] @ as_rotation_matrix(q).T - b[alive], axis=-1)
+        keep = residual <= np.quantile(residual, quantile)
+        LOG.debug("Removed %d outliers, %d points left.", int((~keep).sum()), int(keep.sum()))
+        alive = alive[keep]
+    discarded = np.ones(len(b), dtype=bool)
+    discarded[alive] = False
+    return q, discarded
 
 
 def match_lr(decoder: TransformerBase | tuple[TransformerBase, TransformerBase], points_l: Sequence[tuple[float, float]],

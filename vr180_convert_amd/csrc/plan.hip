@@ -181,6 +181,14 @@ struct v1c_plan {
     int mp_valid_upto = -1;             // m-polynomial table (when uploaded): intervals 0 .. this are all valid at the
                                         // level a lane needs (shared_entry_level)
     double m_reach_norot = 0;           // largest m an unrotated ray reaches
+    // The tile-flag words are per plan: a ray pass sets them, the fix-up pass behind it consumes and clears
+    // them.  Launch sequences that use them are serialised ACROSS streams (host: flags_mu; device: the next
+    // sequence on another stream waits for flags_ev, recorded behind the previous fix-up pass), so one plan
+    // may be run from any number of threads / streams.  Plans that need no fix-up pass never touch them.
+    std::mutex flags_mu;
+    hipEvent_t flags_ev = nullptr;
+    hipStream_t flags_stream = nullptr;
+    bool flags_pending = false;
     std::vector<void*> allocs;
 };
 
@@ -255,6 +263,8 @@ extern "C" int v1c_plan_destroy(v1c_plan* p)
     DeviceGuard dg(p->device);
     for (void* d : p->allocs)
         (void)hipFree(d);
+    if (p->flags_ev)
+        (void)hipEventDestroy(p->flags_ev);
     delete p;
     return V1C_OK;
 }
@@ -403,6 +413,11 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 return fail(V1C_E_HIP, std::string("tile flags: ") + hipGetErrorString(e));
             }
             p->ctx.tile_flags = (uint32_t*)d;
+            e = hipEventCreateWithFlags(&p->flags_ev, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                v1c_plan_destroy(p);
+                return fail(V1C_E_HIP, std::string("tile flags event: ") + hipGetErrorString(e));
+            }
 #ifdef V1C_STAMPS
             {
                 void* sb = nullptr;
@@ -580,6 +595,12 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 shared_entry = shared_entry && !need_fixup;
                 mpoly_all = mpoly_all && shared_entry;
             }
+            std::unique_lock<std::mutex> flags_lk(p->flags_mu, std::defer_lock);
+            if (need_fixup) {
+                flags_lk.lock();
+                if (p->flags_pending && p->flags_stream != st)
+                    HIP_TRY(hipStreamWaitEvent(st, p->flags_ev, 0));
+            }
             if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
@@ -588,8 +609,11 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }
-            if (need_fixup)
+            if (need_fixup) {
                 HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, ua, n, st));
+                HIP_TRY(hipEventRecord(p->flags_ev, st));
+                p->flags_stream = st, p->flags_pending = true;
+            }
         } else {
             HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, ua, n, st));
         }

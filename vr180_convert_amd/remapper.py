@@ -13,6 +13,8 @@ Inputs may be paths, ``numpy`` arrays (uploaded, results come back as ``numpy``)
 from __future__ import annotations
 
 import ctypes as C
+import threading
+import time
 from collections import OrderedDict
 from logging import getLogger
 from pathlib import Path
@@ -72,6 +74,31 @@ def _check_image_tensor(t: torch.Tensor, what: str) -> None:
         raise ValueError(f"{what}: pixels must be contiguous within a row (column-sliced views are fine)")
 
 
+def marshal_units(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor], rots: Sequence[Any] | None, *,
+                  src_hw: tuple[int, int], dst_wh: tuple[int, int], cn: int, device: torch.device | None):
+    """The ``v1c_unit`` array of a launch (include/vr180_remap.h): one record per eye -- pointers and row
+    pitches of its source view and of ITS half of the side-by-side output (remapper.py:517-518 becomes a
+    pitch), optionally the 3x3 rotation replacing the chain's.  Validates shapes, layout and device;
+    ``device=None`` skips the device check (the multi-rank CPU tests marshal host tensors)."""
+    n = len(srcs)
+    units = (_abi.Unit * n)()
+    for k, (s, d) in enumerate(zip(srcs, dsts)):
+        _check_image_tensor(s, "src")
+        _check_image_tensor(d, "dst")
+        if tuple(s.shape) != (*src_hw, cn) or tuple(d.shape) != (dst_wh[1], dst_wh[0], cn):
+            raise ValueError(f"unit {k}: tensor shapes {tuple(s.shape)} -> {tuple(d.shape)} do not match the plan")
+        if device is not None and (s.device != device or d.device != device):
+            raise ValueError(f"unit {k}: tensors must live on {device}")
+        units[k].src, units[k].dst = s.data_ptr(), d.data_ptr()
+        units[k].src_pitch, units[k].dst_pitch = s.stride(0), d.stride(0)
+        if rots is not None and rots[k] is not None:
+            m = np.asarray(rots[k], dtype=np.float64).reshape(9)
+            units[k].has_rot = 1
+            for q in range(9):
+                units[k].rot[q] = m[q]
+    return units
+
+
 class Plan:
     """Owner of one ``v1c_plan`` (see include/vr180_remap.h: v1c_plan_create)."""
 
@@ -79,12 +106,15 @@ class Plan:
         self.device = _device(device)
         self.src_hw, self.dst_wh, self.cn = tuple(src_hw), tuple(dst_wh), int(cn)
         self._h = C.c_void_p()
+        self._memo: "OrderedDict[tuple, Any]" = OrderedDict()  # marshalled unit arrays of recent buffer sets
         bv = border_scalar(border_value)
+        t0 = time.perf_counter()
         rc = _native.lib().v1c_plan_create(
             C.byref(self._h), self.device.index, C.byref(chain), src_hw[0], src_hw[1], dst_wh[1], dst_wh[0],
             cn, int(interpolation), int(border_mode), bv.ctypes.data,
         )
         _native.check(rc, "v1c_plan_create")
+        self.create_ms = (time.perf_counter() - t0) * 1e3  # synchronous: host analysis + table uploads + tile boxes
 
     @property
     def path(self) -> str:
@@ -103,29 +133,28 @@ class Plan:
                 sig = tuple((s.data_ptr(), s.stride(), s.shape, s.dtype, d.data_ptr(), d.stride(), d.shape, d.dtype) for s, d in zip(srcs, dsts))
             except AttributeError:
                 sig = None
-            if sig is not None and sig == getattr(self, "_last_sig", None) and all(
-                    s.device == self.device and d.device == self.device for s, d in zip(srcs, dsts)):
-                rc = _native.lib().v1c_plan_run(self._h, _stream_ptr(self.device), self._last_units, n)
+            # (a few buffer sets are remembered: double / triple buffering rotates them; dict get / set of one key
+            # are atomic under the GIL, an entry is written once and never mutated)
+            units = self._memo.get(sig) if sig is not None else None
+            if units is not None:
+                rc = _native.lib().v1c_plan_run(self._h, _stream_ptr(self.device), units, n)
                 _native.check(rc, "v1c_plan_run")
                 return
-        units = (_abi.Unit * n)()
-        for k, (s, d) in enumerate(zip(srcs, dsts)):
-            _check_image_tensor(s, "src")
-            _check_image_tensor(d, "dst")
-            if tuple(s.shape) != (*self.src_hw, self.cn) or tuple(d.shape) != (self.dst_wh[1], self.dst_wh[0], self.cn):
-                raise ValueError(f"unit {k}: tensor shapes {tuple(s.shape)} -> {tuple(d.shape)} do not match the plan")
-            if s.device != self.device or d.device != self.device:
-                raise ValueError(f"unit {k}: tensors must live on {self.device}")
-            units[k].src, units[k].dst = s.data_ptr(), d.data_ptr()
-            units[k].src_pitch, units[k].dst_pitch = s.stride(0), d.stride(0)
-            if rots is not None and rots[k] is not None:
-                m = np.asarray(rots[k], dtype=np.float64).reshape(9)
-                units[k].has_rot = 1
-                for q in range(9):
-                    units[k].rot[q] = m[q]
+        units = marshal_units(srcs, dsts, rots, src_hw=self.src_hw, dst_wh=self.dst_wh, cn=self.cn, device=self.device)
         rc = _native.lib().v1c_plan_run(self._h, _stream_ptr(self.device), units, n)
         _native.check(rc, "v1c_plan_run")
-        self._last_sig, self._last_units = sig, units
+        if sig is not None:
+            self._memo[sig] = units
+            while len(self._memo) > 64:
+                try:
+                    self._memo.popitem(last=False)
+                except KeyError:  # another thread emptied it
+                    break
+
+    def run_units(self, units: Any, n: int) -> None:
+        """Launch an already marshalled ``v1c_unit`` array (``marshal_units``) on the current stream."""
+        rc = _native.lib().v1c_plan_run(self._h, _stream_ptr(self.device), units, int(n))
+        _native.check(rc, "v1c_plan_run")
 
     def get_map(self, rot: Any = None) -> tuple[torch.Tensor, torch.Tensor]:
         w, h = self.dst_wh
@@ -150,21 +179,34 @@ class Plan:
 
 _PLANS: "OrderedDict[tuple, Plan]" = OrderedDict()
 _PLAN_CACHE_SIZE = 32
+_PLANS_LOCK = threading.Lock()  # one worker thread per device (sharding.py) shares this cache
+
+
+def clear_caches() -> None:
+    """Forget every plan and lowered chain (cold-call measurements, tests)."""
+    with _PLANS_LOCK:
+        _PLANS.clear()
+        _LOWERED.clear()
+        _LAST_SHARED[0] = None
 
 
 def _plan_for(chain: _abi.Chain, *, src_hw, dst_wh, cn, interpolation, border_mode, border_value, device) -> Plan:
     dev = _device(device)
     key = (chain.key(), tuple(src_hw), tuple(dst_wh), cn, int(interpolation), int(border_mode),
            border_scalar(border_value).tobytes(), dev.index)
-    plan = _PLANS.get(key)
-    if plan is None:
-        plan = Plan(chain, src_hw=src_hw, dst_wh=dst_wh, cn=cn, interpolation=interpolation,
-                    border_mode=border_mode, border_value=border_value, device=dev)
-        _PLANS[key] = plan
+    with _PLANS_LOCK:
+        plan = _PLANS.get(key)
+        if plan is not None:
+            _PLANS.move_to_end(key)
+            return plan
+    # created outside the lock (tens of ms: other devices' threads keep going); a racing duplicate is dropped
+    plan = Plan(chain, src_hw=src_hw, dst_wh=dst_wh, cn=cn, interpolation=interpolation,
+                border_mode=border_mode, border_value=border_value, device=dev)
+    with _PLANS_LOCK:
+        plan = _PLANS.setdefault(key, plan)
+        _PLANS.move_to_end(key)
         while len(_PLANS) > _PLAN_CACHE_SIZE:
             _PLANS.popitem(last=False)
-    else:
-        _PLANS.move_to_end(key)
     return plan
 
 
@@ -201,14 +243,55 @@ _LOWERED: "OrderedDict[tuple, _abi.Chain]" = OrderedDict()
 _LAST_SHARED: list = [None]  # [(key, Plan)] of the last remap_tensors call with one shared transformer
 
 
+class _NoKey(Exception):
+    """The transformer holds state the memo key cannot capture exactly: lower it on every call."""
+
+
+def _param_key(obj: Any):
+    """Exact, hashable image of a built-in transformer's parameters: floats by their bits
+    (``float.hex``), arrays by dtype / shape / bytes, quaternion-likes by their four components,
+    dataclass stages field by field.  ``repr`` is NOT used: NumPy prints arrays with 8 digits and
+    honours ``np.set_printoptions``, numpy-quaternion prints ``%.15g`` -- two rotations 2e-9
+    apart would share a key and the second call would silently reuse the first one's plan."""
+    import dataclasses
+
+    if obj is None or isinstance(obj, (bool, str, bytes)):
+        return obj
+    if isinstance(obj, (int, np.integer)):
+        return ("i", int(obj))
+    if isinstance(obj, (float, np.floating)):
+        return ("f", float(obj).hex())
+    if isinstance(obj, np.ndarray):
+        if obj.dtype == object:
+            raise _NoKey
+        a = np.ascontiguousarray(obj)
+        return ("nd", a.dtype.str, a.shape, a.tobytes())
+    if isinstance(obj, (list, tuple)):
+        return (type(obj).__name__, tuple(_param_key(v) for v in obj))
+    if dataclasses.is_dataclass(obj) and not isinstance(obj, type):
+        if type(obj).__module__ != TransformerBase.__module__:
+            raise _NoKey  # a user subclass may carry state outside its fields
+        return (type(obj).__name__, tuple(_param_key(getattr(obj, f.name)) for f in dataclasses.fields(obj)))
+    if all(hasattr(obj, c) for c in "wxyz"):
+        return ("q", tuple(float(getattr(obj, c)).hex() for c in "wxyz"))
+    raise _NoKey
+
+
+def _transformer_key(t: Any):
+    try:
+        return _param_key(t)
+    except (_NoKey, TypeError, ValueError):
+        return None
+
+
 def _lower_cached(t: TransformerBase, *, radius, size_input, size_output) -> _abi.Chain:
-    """``lower_for_get_map`` memoised on the chain's dataclass repr (its full parameter set): a
-    steady stream of identical calls -- frames of a video, bench steps -- lowers once.  Reprs that
-    may be abbreviated (large arrays) or are not parameter-complete (no dataclass repr) are not cached."""
-    r = repr(t)
-    if len(r) > 4096 or "..." in r or " object at 0x" in r:
+    """``lower_for_get_map`` memoised on the chain's exact parameter set (``_param_key``): a steady
+    stream of identical calls -- frames of a video, bench steps -- lowers once.  Chains holding
+    anything the key cannot capture exactly (user subclasses, object arrays) are lowered every time."""
+    k = _transformer_key(t)
+    if k is None:
         return lower_for_get_map(t, radius=radius, size_input=size_input, size_output=size_output)
-    key = (r, float(radius), tuple(size_input), tuple(size_output))
+    key = (k, float(radius).hex(), tuple(size_input), tuple(size_output))
     ch = _LOWERED.get(key)
     if ch is None:
         ch = lower_for_get_map(t, radius=radius, size_input=size_input, size_output=size_output)
@@ -244,14 +327,14 @@ def remap_tensors(
         return _remap_with_rotations(transformer, srcs, dsts, rotations, radius=radius, interpolation=interpolation,
                                      boarder_mode=boarder_mode, boarder_value=boarder_value, size_input=size_input)
     # one shared transformer, same geometry and parameters as the previous call: straight to its plan
-    # (the repr is the chain's full parameter set, see _lower_cached)
+    # (the key is the chain's exact parameter set, see _param_key)
     memo_key = None
     if not isinstance(transformer, (list, tuple)) and len(dsts) == n and isinstance(srcs[0], torch.Tensor) and isinstance(dsts[0], torch.Tensor):
-        r = repr(transformer)
-        if len(r) <= 4096 and "..." not in r and " object at 0x" not in r and srcs[0].dim() == 3 and dsts[0].dim() == 3:
+        tk = _transformer_key(transformer)
+        if tk is not None and srcs[0].dim() == 3 and dsts[0].dim() == 3:
             try:
-                memo_key = (r, float(radius), srcs[0].shape, dsts[0].shape, int(interpolation), int(boarder_mode), repr(boarder_value),
-                            None if size_input is None else tuple(size_input), srcs[0].device)
+                memo_key = (tk, float(radius).hex(), srcs[0].shape, dsts[0].shape, int(interpolation), int(boarder_mode),
+                            border_scalar(boarder_value).tobytes(), None if size_input is None else tuple(size_input), srcs[0].device)
             except (TypeError, ValueError):
                 memo_key = None
             last = _LAST_SHARED[0]  # (one read: another thread may replace the entry at any time)
@@ -259,60 +342,98 @@ def remap_tensors(
                 plan = last[1]
                 plan.run(srcs, dsts, None)
                 return [plan.path_cached]
+    dev = srcs[0].device
+    cn = int(srcs[0].shape[2])
+    dst_wh = (int(dsts[0].shape[1]), int(dsts[0].shape[0]))
+    groups, host_mapped = group_units(transformer, srcs, dsts, radius=radius, size_input=size_input)
+    paths: list[str] = []
+    for k, t, size_in_k in host_mapped:
+        xm, ym = _host_map(t, radius=radius, size_input=size_in_k, size_output=dst_wh)
+        xm_d, ym_d = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
+        bv = border_scalar(boarder_value)
+        _check_image_tensor(srcs[k], "src")
+        _check_image_tensor(dsts[k], "dst")
+        rc = _native.lib().v1c_remap_lut(
+            dev.index, _stream_ptr(dev), srcs[k].data_ptr(), srcs[k].shape[0], srcs[k].shape[1], srcs[k].stride(0), cn,
+            dsts[k].data_ptr(), dst_wh[1], dst_wh[0], dsts[k].stride(0), xm_d.data_ptr(), ym_d.data_ptr(),
+            xm_d.stride(0) * 4, int(interpolation), int(boarder_mode), bv.ctypes.data,
+        )
+        _native.check(rc, "v1c_remap_lut")
+        paths.append("lut")
+    for g in groups:
+        plan = _plan_for(g.chain, src_hw=g.src_hw, dst_wh=dst_wh, cn=cn, interpolation=interpolation,
+                         border_mode=boarder_mode, border_value=boarder_value, device=dev)
+        plan.run(g.srcs, g.dsts, g.rots)
+        paths.append(plan.path)
+        if memo_key is not None and len(groups) == 1 and not host_mapped and g.rots is None and len(g.srcs) == n:
+            plan.path_cached = paths[-1]
+            _LAST_SHARED[0] = (memo_key, plan)
+    return paths
+
+
+class LaunchGroup:
+    """Units of one call that share a plan: ``chain`` is what the plan is created from (the group's one
+    rotation baked in, or blanked when rotations differ per unit and travel in ``rots``)."""
+
+    __slots__ = ("chain", "src_hw", "srcs", "dsts", "rots", "index")
+
+    def __init__(self, chain, src_hw, srcs, dsts, rots, index):
+        self.chain, self.src_hw, self.srcs, self.dsts, self.rots, self.index = chain, src_hw, srcs, dsts, rots, index
+
+
+def group_units(transformer, srcs, dsts, *, radius: float, size_input: tuple[int, int] | None = None):
+    """Host logic of a call, no device involved: lower the chain of every unit (one shared transformer or
+    one per unit), split units into groups that share a plan -- same chain up to the matrix of a single
+    rotate stage, same source size -- and list the units whose chain cannot be lowered.
+
+    Returns ``(groups, host_mapped)``: ``LaunchGroup`` records in first-appearance order and
+    ``(unit index, transformer, size_input)`` for units that take the map from their own ``transform()``.
+    Used by ``remap_tensors`` and by the multi-GPU dispatcher (sharding.py), whose CPU tests run it as is."""
+    n = len(srcs)
     per_unit = list(transformer) if isinstance(transformer, (list, tuple)) else [transformer] * n
     if len(per_unit) != n or len(dsts) != n:
         raise ValueError("need one transformer and one dst per src")
-    dev = srcs[0].device
     src_hw = (int(srcs[0].shape[0]), int(srcs[0].shape[1]))
-    cn = int(srcs[0].shape[2])
     dst_wh = (int(dsts[0].shape[1]), int(dsts[0].shape[0]))
-    size_input = size_input or src_hw
-
-    groups: "OrderedDict[bytes, dict]" = OrderedDict()
-    lowered: dict[int, Any] = {}
-    paths: list[str] = []
+    acc: "OrderedDict[bytes, dict]" = OrderedDict()
+    lowered: dict[Any, Any] = {}
+    host_mapped = []
     for k, t in enumerate(per_unit):
-        if id(t) not in lowered:
+        # the Denormalize centre is (W_in // 2, H_in // 2) of the image the map is FOR: with one shared
+        # transformer that is images[0] (remapper.py:385), with per-eye transformers every eye is its own
+        # apply() call and uses its own shape (remapper.py:460-473) -- odd-width SBS files split into W // 2
+        # and W - W // 2 columns
+        size_in_k = tuple(size_input) if size_input is not None else (
+            src_hw if not isinstance(transformer, (list, tuple)) else (int(srcs[k].shape[0]), int(srcs[k].shape[1])))
+        lk = (id(t), size_in_k)
+        if lk not in lowered:
             try:
-                lowered[id(t)] = _lower_cached(t, radius=radius, size_input=size_input, size_output=dst_wh)
+                lowered[lk] = _lower_cached(t, radius=radius, size_input=size_in_k, size_output=dst_wh)
             except NotLowerable as e:
                 LOG.warning("transformer chain is not lowerable (%s): map evaluated by its own NumPy transform()", e)
-                lowered[id(t)] = None
-        chain = lowered[id(t)]
+                lowered[lk] = None
+        chain = lowered[lk]
         if chain is None:
-            xm, ym = _host_map(t, radius=radius, size_input=size_input, size_output=dst_wh)
-            xm_d, ym_d = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
-            bv = border_scalar(boarder_value)
-            _check_image_tensor(srcs[k], "src")
-            _check_image_tensor(dsts[k], "dst")
-            rc = _native.lib().v1c_remap_lut(
-                dev.index, _stream_ptr(dev), srcs[k].data_ptr(), srcs[k].shape[0], srcs[k].shape[1], srcs[k].stride(0), cn,
-                dsts[k].data_ptr(), dst_wh[1], dst_wh[0], dsts[k].stride(0), xm_d.data_ptr(), ym_d.data_ptr(),
-                xm_d.stride(0) * 4, int(interpolation), int(boarder_mode), bv.ctypes.data,
-            )
-            _native.check(rc, "v1c_remap_lut")
-            paths.append("lut")
+            host_mapped.append((k, t, size_in_k))
             continue
         shared, rot = _split_single_rotation(chain)
         key = bytes(shared) + repr(tuple(srcs[k].shape)).encode()  # different source sizes: different plans
-        g = groups.setdefault(key, {"chain": shared, "full": chain, "src_hw": tuple(srcs[k].shape[:2]), "srcs": [], "dsts": [], "rots": []})
+        g = acc.setdefault(key, {"chain": shared, "full": chain, "src_hw": tuple(int(v) for v in srcs[k].shape[:2]),
+                                 "srcs": [], "dsts": [], "rots": [], "index": []})
         g["srcs"].append(srcs[k])
         g["dsts"].append(dsts[k])
         g["rots"].append(rot)
-    for g in groups.values():
+        g["index"].append(k)
+    groups = []
+    for g in acc.values():
         # one rotation for the whole group (or none): bake it into the plan, which then computes its
         # tile boxes once and shares coordinates between units; rotations that differ per unit
         # travel with the units and share the rotation-blanked plan
         r0 = g["rots"][0]
         uniform = r0 is None or all(np.array_equal(r, r0) for r in g["rots"])
-        plan = _plan_for(g["full"] if uniform else g["chain"], src_hw=g["src_hw"], dst_wh=dst_wh, cn=cn,
-                         interpolation=interpolation, border_mode=boarder_mode, border_value=boarder_value, device=dev)
-        plan.run(g["srcs"], g["dsts"], None if uniform else g["rots"])
-        paths.append(plan.path)
-        if memo_key is not None and len(groups) == 1 and len(paths) == 1 and uniform and len(g["srcs"]) == n:
-            plan.path_cached = paths[0]
-            _LAST_SHARED[0] = (memo_key, plan)
-    return paths
+        groups.append(LaunchGroup(g["full"] if uniform else g["chain"], g["src_hw"], g["srcs"], g["dsts"],
+                                  None if uniform else g["rots"], g["index"]))
+    return groups, host_mapped
 
 
 def _remap_with_rotations(transformer, srcs, dsts, rotations, *, radius, interpolation, boarder_mode, boarder_value, size_input):
