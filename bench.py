@@ -289,8 +289,8 @@ def cold_call(cfg, dev, V, transformer_builder):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
@@ -391,12 +391,16 @@ def main() -> None:
     first_call_ms = (time.perf_counter() - t0) * 1e3
     plan_create_ms = sum(p.create_ms for p in R._PLANS.values())
 
-    # Setup, not a step: ~25 ms of device work so that the shader clock has left its idle state
-    # before the W warm-up steps (a step is ~0.07 ms; the CPU-side input synthesis above leaves the
-    # GPU idle for about a second).  The timed region below is exactly K steps.
-    spin = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-    for _ in range(40):
-        spin.add_(1)
+    # Setup, not a step: the GPU comes out of its idle power state slowly on this pool (a C2 step measured 0.24-0.36 ms
+    # in a 13 ms run of 220 steps, 0.058 ms once the card had been busy for ~0.1 s; the CPU-side input synthesis above
+    # leaves it idle for about a second).  Keep it busy with memory-bound work for 0.5 s of wall time before the W
+    # warm-up steps.  The timed region below is exactly K steps.
+    spin = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.5:
+        for _ in range(20):
+            spin.add_(1)
+        torch.cuda.synchronize(dev)
     del spin
     for i in range(args.warmup):
         step(i)

@@ -702,9 +702,12 @@ __device__ __forceinline__ void store4(uint8_t* drow, const uint32_t (&pix)[kPX]
 {
     if (ok == 0xFu && aligned) {
         uint32_t* d32 = (uint32_t*)drow;
-        d32[0] = pix[0] | (pix[1] << 24);
-        d32[1] = (pix[1] >> 8) | (pix[2] << 16);
-        d32[2] = (pix[2] >> 16) | (pix[3] << 8);
+        // non-temporal: the destination is written once and never read by this launch; with the stores marked
+        // streaming the L2 / Infinity Cache keep the source halo rows instead (L3-cold bench, r02: C2 -4 %, C1 -5 %,
+        // C5 -3.5 %; no difference when the destination was L3-resident from the previous step)
+        __builtin_nontemporal_store(pix[0] | (pix[1] << 24), d32 + 0);
+        __builtin_nontemporal_store((pix[1] >> 8) | (pix[2] << 16), d32 + 1);
+        __builtin_nontemporal_store((pix[2] >> 16) | (pix[3] << 8), d32 + 2);
     } else {
 #pragma unroll
         for (int k = 0; k < kPX; k++)
@@ -1485,12 +1488,14 @@ int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int 
         const bool stageable = b[i].cpr > 0 && b[i].cpr <= kMaxCpr && b[i].nrows * b[i].cpr <= 1024 && need <= half_dwords;
         cost[i] = b[i].cpr <= 0 ? 0.5f : 1.0f + (stageable ? 0.0f : 4.0f) + (need > lean_half ? 0.5f : 0.0f) + (b[i].interior ? 0.0f : 0.5f) + (float)need / 16384.0f;
     }
-    int cand_s[5], n_cand = 0;
-    double cand_load[5];
-    for (int S : {1, 2, 4, 8, 16}) {
+    int cand_s[6], n_cand = 0;
+    double cand_load[6];
+    for (int S : {1, 2, 4, 8, 16, 32}) {
         if (forced > 0 && S != forced)
             continue;
-        if (per % (unsigned)S != 0 || (S > 1 && per / (unsigned)S < 2 * d.x))
+        // a strip is at least two tile rows (one row for a forced count): thinner strips share every halo row
+        // between two XCDs' L2s
+        if (per % (unsigned)S != 0 || (S > 1 && per / (unsigned)S < (forced > 0 ? 1u : 2u) * d.x))
             continue;
         const unsigned L = per / (unsigned)S;
         double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1507,17 +1512,22 @@ int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int 
     }
     if (n_cand == 0)
         return 0;
-    // leave one block per XCD only for a predicted gain of 3 % or more (strips cost L2 locality: C2, balanced
-    // to 2 %, measured 1.5 % slower with 4 strips); then the fewest strips within 1 % of the best balance
+    // Measured with source and destination L3-cold (r02, interleaved A/B runs): the finer the interleave the
+    // faster -- C2 1 / 2 / 4 / 8 / 16 strips 0.0570 / 0.0564 / 0.0555 / 0.0543 / 0.0532 ms, C4 8 -> 16 strips 1.363 ->
+    // 1.336 ms -- all eight XCDs then work on the same band of the image, i.e. on the same open HBM pages and
+    // Infinity-Cache sets, instead of on eight bands 1/8 of the image apart.  (Round 1 tuned this on an L3-resident
+    // buffer set, where strips only paid for balancing tile costs.)  So: the largest count of at most 16 whose strips
+    // are still two tile rows, unless the model says a coarser one balances the tile costs 3 % better.
     int best_s = cand_s[0];
     if (forced <= 0) {
-        const double lo = *std::min_element(cand_load, cand_load + n_cand);
-        if (cand_s[0] == 1 && lo < 0.97 * cand_load[0])
-            for (int q = 0; q < n_cand; q++)
-                if (cand_load[q] <= 1.01 * lo) {
-                    best_s = cand_s[q];
-                    break;
-                }
+        int q_best = 0;
+        for (int q = 0; q < n_cand; q++)
+            if (cand_s[q] <= 16)
+                q_best = q;
+        for (int q = q_best - 1; q >= 0; q--)
+            if (cand_load[q] < 0.97 * cand_load[q_best])
+                q_best = q;
+        best_s = cand_s[q_best];
     }
     return best_s > 1 ? (int)(per / (unsigned)best_s) : 0;
 }
