@@ -771,7 +771,8 @@ def test_batch_plan_run_is_graph_capturable(V, oracle_mod, dev):
 
 
 @pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_DISABLE_MPOLY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"},
-                                 {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_LEAN": "1"}, {"V1C_DISABLE_MERGE": "1"}, {"V1C_XCD_STRIPS": "2"}],
+                                 {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_LEAN": "1"}, {"V1C_DISABLE_MERGE": "1"}, {"V1C_XCD_STRIPS": "2"},
+                                 {"V1C_DISABLE_MIRROR": "1"}, {}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_variants_bit_exact(env):
     """The instantiations the default configuration does not reach (per-pixel table fallback,
@@ -782,8 +783,14 @@ def test_kernel_variants_bit_exact(env):
     import sys
     from pathlib import Path
 
+    from vr180_convert_amd import _native
+
+    # the switches exist only in the -DV1C_TUNING build of the same sources (csrc/Makefile `tuning`)
+    tuning = _native.LIB_PATH.with_name("libvr180remap_tuning.so")
+    assert tuning.exists(), "build it: make -C vr180_convert_amd/csrc tuning (or __graft_entry__.build())"
     probe = Path(__file__).with_name("variant_probe.py")
-    r = subprocess.run([sys.executable, str(probe)], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(probe)], env={**os.environ, **env, "V1C_LIB": str(tuning)}, capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -1042,3 +1049,26 @@ def test_remap_sharded_on_the_devices_there_are(V, oracle_mod):
         w = np.concatenate([O.apply(CS.c5_spec(f, eye), [frames[f][:, eye * n:(eye + 1) * n]], size_output=(64, 64), interpolation=1,
                                     radius=n / 2)[0] for eye in (0, 1)], axis=1)
         assert np.array_equal(got[f], w), f
+
+
+@pytest.mark.parametrize("src_hw,out_wh,radius", [
+    ((300, 300), (256, 96), 150.0),     # smallest mirror grid: 6 tile rows, 2 mirrored
+    ((512, 640), (320, 352), 250.0),    # non-square, source wider than high
+    ((1000, 1000), (1028, 512), 470.0), # width not a multiple of the tile (64): ragged last tile column -> rest list
+    ((700, 700), (512, 480), 350.0),    # 480 = 15 * 32: odd number of tile-row pairs
+    ((257, 263), (128, 100), 120.0),    # 100 rows: no mirror launch (not a multiple of 32), plain pair kernel
+])
+def test_mirror_pair_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radius):
+    """apply_lr pairs of unrotated bilinear chains take k_ray_lin3_pair_mirror (a tile and its mirror image about
+    the equator from one set of coordinates; tile rows 0, H/32 and the last one plus ineligible tiles through the
+    pair code in the same launch): every output byte against the oracle, m-table and w-table chains."""
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    left, right = noise_disc(*src_hw, 21), noise_disc(*src_hw, 22)
+    left[::9, ::7] = 255
+    for spec in ([("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]):
+        want = O.apply_lr(spec, left, right, size_output=out_wh, interpolation=1, radius=radius, border_value=(5, 6, 7))
+        got = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev),
+                                 size_output=out_wh, interpolation=1, radius=radius, boarder_value=(5, 6, 7)).cpu().numpy()
+        assert np.array_equal(got, want), (spec, int((got != want).sum()))

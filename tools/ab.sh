@@ -10,7 +10,8 @@ for r in $(seq $REPS); do
   for ARM in "$@"; do
     L=${ARM%%:*}; E=""; [ "$ARM" != "$L" ] && E=$(echo "${ARM#*:}" | tr ',' ' ')
     for WL in $WLS; do
-      if [ "$L" = default ]; then LIBENV=""; else LIBENV="V1C_LIB=$L"; fi
+      # (environment switches exist only in the -DV1C_TUNING build: "default" with switches -> the tuning twin)
+      if [ "$L" = default ] && [ -z "$E" ]; then LIBENV=""; elif [ "$L" = default ] || [ "$L" = tuning ]; then LIBENV="V1C_LIB=vr180_convert_amd/csrc/libvr180remap_tuning.so"; else LIBENV="V1C_LIB=$L"; fi
       env $LIBENV $E python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --workload $WL ${ARGS:-} 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:

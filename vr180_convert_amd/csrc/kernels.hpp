@@ -1,11 +1,21 @@
 // kernels.hpp -- declarations shared by kernels.hip (device code) and plan.hip (host C ABI).
 #pragma once
 
+#include <cstdlib>
 #include <vector>
 
 #include "v1c_core.hpp"
 
 namespace v1c {
+
+// A/B, coverage and diagnostic switches (environment variables, read once per process: V1C_UPB, V1C_DISABLE_*,
+// V1C_XCD_STRIPS, V1C_*_CAP, V1C_DEBUG ...; tools/README.md) exist only in the -DV1C_TUNING build
+// (libvr180remap_tuning.so, `make tuning`): the shipped library reads no environment.
+#ifdef V1C_TUNING
+inline const char* tuning_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* tuning_env(const char*) { return nullptr; }
+#endif
 
 constexpr int kPX = 4;       // output pixels per lane (12 bytes = 3 dword stores for BGR)
 constexpr int kBlockX = 64;  // lanes per row segment (= one wave)
@@ -33,7 +43,14 @@ hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float
 // hot configuration (CN = 3, INTER_LINEAR, BORDER_CONSTANT, ray mode): kernels_tile.hip
 bool tile_kernel_supports(const Geom& g);
 size_t tile_box_bytes(const Geom& g);
-hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream);
+hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream, int mirror_h = 0);
+// apply_lr pairs of unrotated chains: a tile and its mirror image about the equator from one set of coordinates
+// (k_ray_lin3_pair_mirror); `host_mboxes` = boxes of the mirrored bands (launch_tile_boxes with mirror_h).
+// tile_mirror_rest: the tiles (ty << 16 | tx) that launch leaves to the pair kernel; false: no mirror launch for this plan
+bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
+                      std::vector<uint32_t>& rest);
+hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
+                                       int mirror_h, const uint32_t* rest_list, int n_rest, hipStream_t stream);
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,

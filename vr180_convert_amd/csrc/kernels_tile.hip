@@ -130,6 +130,7 @@ constexpr int kUnitsPerBlock = V1C_UPB;  // units sharing the map that one workg
 struct LaneCoords {
     int idx_lo, idx_hi;        // range of table entries of the lane's in-table pixels (k_tile_boxes)
     int sx[kPX], sy[kPX];      // cv2's fixed point: cvRound(32 x)
+    int sy2[kPX];              // MIRROR: cvRound(32 y) of the same columns in the row mirrored about the equator
     unsigned ok;               // coordinate valid (inside the radial table's domain), bit per pixel
     unsigned inside;           // ... and the whole 2x2 cell (plus 8 readable bytes) inside the source
 };
@@ -161,7 +162,11 @@ __device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, 
 // interval index comes from fp32 arithmetic (an fp32 square root for w-tables) and
 // G = poly6(m - m_c) -- no fp64 root, no index conversion in fp64.  The
 // plan flags the tiles where every entry a lane can pick is valid at the level the lanes need.
-template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, int MPOLY, typename TabPtr>
+// MIRROR = 1 (no rotation, INTERIOR = 1): also the y coordinate of the lane's 4 columns in the output row mirrored
+// about the equator (row 2 * norm_cy - j): there sin(lat) changes sign and nothing else does (the host's row tables
+// are exactly antisymmetric / symmetric), so m, G and x are the same numbers and y32' = fma(G, -ky, cy32) -- bit for
+// bit what the mirrored row's own evaluation gives.
+template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, int MPOLY, int MIRROR = 0, typename TabPtr>
 __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, const RowCol& rc, int npx, TabPtr tab,
                                             int tab0, int tabn, LaneCoords& L)
 {
@@ -309,6 +314,8 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
             const float ay = INTERIOR == 2 ? __builtin_amdgcn_fmed3f(fyk, -4194303.0f, 4194303.0f) : fyk;
             L.sx[k] = __float_as_int(ax + 12582912.0f) - 0x4B400000;
             L.sy[k] = __float_as_int(ay + 12582912.0f) - 0x4B400000;
+            if (MIRROR && !ROT)
+                L.sy2[k] = __float_as_int((float)fma(G[k], -ky, cy32) + 12582912.0f) - 0x4B400000;
             continue;
         }
         // flagged intervals carry NaN coefficients; |32 x| < 2^30 keeps the int conversion exact
@@ -754,7 +761,9 @@ __device__ __forceinline__ bool box_touches_image_end(const TileBox& b, const Ge
 // table entry, with OWN = 1 possibly with its own -- both within tolerance, but the box must
 // bound the coordinates the consumer will actually compute.
 template <int VAR_W, int ROT, int K, int NT, int OWN>
-__global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes)
+// `mirror_h` > 0: the boxes of the MIRRORED bands instead -- entry (tx, ty) describes output rows mirror_h - j for
+// the rows j of tile (tx, ty) (k_ray_lin3_pair_mirror evaluates a tile and its mirror image from one set of coordinates).
+__global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes, int mirror_h)
 {
     constexpr int NW = NT / 64;
     __shared__ __attribute__((aligned(16))) int red[4 * NW];
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     const int tid = threadIdx.x;
     const TileIds t = tile_ids(c.g, 0, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / kLanesX);
     RowCol rc;
-    load_rowcol<ROT>(c.ray, t.xc, t.jc, rc);
+    load_rowcol<ROT>(c.ray, t.xc, mirror_h > 0 ? min(max(mirror_h - t.j, 0), c.g.dst_h - 1) : t.jc, rc);
     LaneCoords L;
     lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
     TileBox b = reduce_box<K, NW>(L, red, tid);
@@ -1251,7 +1260,10 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, uns
         unsigned m = (lin & 7u) * per + (lin >> 3);
         if (strip_len) {
             const unsigned i = lin >> 3, sidx = __umulhi(i, strip_magic);  // = i / strip_len (i * strip_len < 2^32)
-            m = (sidx * 8u + (lin & 7u)) * strip_len + (i - sidx * strip_len);
+            // full strips: 8 per round, one per XCD; the last round's strips are the (shorter) remainder of each share
+            const unsigned nfull = __umulhi(per, strip_magic), x = lin & 7u;
+            m = sidx < nfull ? (sidx * 8u + x) * strip_len + (i - sidx * strip_len)
+                             : nfull * 8u * strip_len + x * (per - nfull * strip_len) + (i - nfull * strip_len);
         }
         ty = gridDim.x == 1 ? (int)m : (int)__umulhi(m, magic);  // (2^32 / 1 + 1 does not fit the magic)
         tx = (int)(m - (unsigned)ty * gridDim.x);
@@ -1405,6 +1417,133 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
                                                    (glb_u32_ptr) nullptr);
 }
 
+// ---- a pair (apply_lr) of an unrotated chain: a tile AND its mirror image about the equator per workgroup ----
+// Rows j and mirror_h - j of an unrotated equirectangular chain differ only in the sign of sin(lat): m, the radial
+// factor G and the x coordinate are the same numbers, y mirrors about the source centre (lane_coords<..., MIRROR>).
+// One workgroup therefore serves tile (tx, ty) of the upper half and the band of 16 rows that mirrors it: one
+// prologue, one table slice, one evaluation of the coordinates (the largest block of the pair kernel's VALU work:
+// ~130 of 362 instructions per wave) for 2 x 2 x 1024 output pixels.  The LDS box is used twice: the tile's cells
+// (both eyes interleaved, as in the pair path of shared_map_tile) are sampled while the loads of the mirrored
+// band's box are in flight, then that box replaces them behind a barrier.  Interior tiles only (both boxes fit,
+// every pixel valid and inside -- mirror_static_ok, the predicate the host's rest list is built from); the rest
+// list (tile rows 0, H/32 and the last one, which the mirrored bands do not cover, plus the tiles and mirror
+// bands of ineligible workgroups) rides in grid slice z = 0 through the general pair code.
+__host__ __device__ inline bool mirror_box_ok(int x0, int y0, int cpr, int nrows, int half_dwords, int src_h, int src_w)
+{
+    return cpr > 0 && cpr <= kMaxCpr && nrows * cpr <= 1024 && nrows * (cpr * 4 + 4) <= half_dwords &&
+           !((y0 + nrows >= src_h) && (x0 + 4 * cpr > src_w));  // (boxes that reach the image's last bytes stay with the general code)
+}
+
+__host__ __device__ inline bool mirror_static_ok(const TileBox& b, const TileBox& q, int half_dwords, int src_h, int src_w)
+{
+    return b.interior != 0 && q.interior == b.interior && b.nidx > 0 && b.nidx <= kTabSlice && q.idx0 == b.idx0 && q.nidx == b.nidx &&
+           mirror_box_ok(b.x0, b.y0, b.cpr, b.nrows, half_dwords, src_h, src_w) &&
+           mirror_box_ok(q.x0, q.y0, q.cpr, q.nrows, half_dwords, src_h, src_w);
+}
+
+__device__ __forceinline__ TileBox load_tile_box(const TileBox* __restrict__ boxes, int tile)
+{
+    const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(tile));
+    const int4 b0 = bp[0], b1 = bp[1];
+    TileBox b;
+    b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y, b.interior = b1.z, b.magic = b1.w;
+    return b;
+}
+
+// taps of both eyes of a lane's 4 pixels from the interleaved cells of box `b` (fixed-point rows `sy`), blend, store
+// into output row `j`
+__device__ __forceinline__ void sample_pair_cells(const UnitArgs& ua, const TileIds& t, int j, const TileBox& b, const uint32_t* boxw,
+                                                  const int (&sx)[kPX], const int (&sy)[kPX])
+{
+    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+    typedef const __attribute__((address_space(3))) u32x2* lds_u64_ptr;
+    const uint32_t lpw8 = (uint32_t)(b.cpr * 4 + 4) * 8u;
+    const uint32_t base0 = (uint32_t)(uintptr_t)(lds_u32_ptr)boxw - ((uint32_t)b.y0 * lpw8 + (uint32_t)b.x0 * 8u);
+    Taps2 T0, T1;
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        const uint32_t rel = __umul24((uint32_t)(sy[k] >> 5), lpw8) + (((uint32_t)sx[k] >> 2) & ~7u);
+        const lds_u64_ptr ra = (lds_u64_ptr)(uintptr_t)(rel + base0), rb = (lds_u64_ptr)(uintptr_t)(rel + base0 + lpw8);
+        const u32x2 a_lo = ra[0], a_hi = ra[1], b_lo = rb[0], b_hi = rb[1];
+        T0.alo[k] = a_lo.x, T0.ahi[k] = a_hi.x, T0.blo[k] = b_lo.x, T0.bhi[k] = b_hi.x;
+        T1.alo[k] = a_lo.y, T1.ahi[k] = a_hi.y, T1.blo[k] = b_lo.y, T1.bhi[k] = b_hi.y;
+    }
+    uint32_t pix[kPX];
+    const uint32_t row_off = (uint32_t)t.x0 * 3u;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const BlendW w = blend_weights(sx[k], sy[k]);
+            pix[k] = e == 0 ? blend3<4>(T0.alo[k], T0.ahi[k], T0.blo[k], T0.bhi[k], w) : blend3<4>(T1.alo[k], T1.ahi[k], T1.blo[k], T1.bhi[k], w);
+        }
+        uint8_t* drow = ua.u[e].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[e].dst_pitch) + row_off);
+        store4(drow, pix, 0xFu, dst_rows_dword_aligned(ua, e));
+    }
+}
+
+template <int VAR_W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_ray_lin3_pair_mirror(
+    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
+    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic)
+{
+    constexpr int NT = 256;
+    __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // one pair of interleaved boxes: 2 x half_dwords
+    const int tid = threadIdx.x;
+    if (blockIdx.z == 0) {  // the tiles the mirror path leaves out, through the general pair code
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= (unsigned)n_rest)
+            return;
+        const uint32_t v = rest_list[lin];
+        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
+                                                  tabw, (glb_u32_ptr)c.itab);
+        return;
+    }
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    int tx, ty;
+    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+    ty += 1;  // tile row 0 has no mirror image (row 0 <-> row mirror_h)
+    const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
+    const uint8_t* __restrict__ src0 = ua.u[0].src;
+    const uint8_t* __restrict__ src1 = ua.u[1].src;
+    const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[1].src_pitch;
+    const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
+    if (!mirror_static_ok(b, q, half_dwords, g.src_h, g.src_w))
+        return;
+    ChunkMap M;
+    make_chunk_map<NT>(b, tid, M);
+    Staged S0, S1;
+    stage_load<false, false>(M, src0, pitch0, 0u, S0);
+    stage_load<false, false>(M, src1, pitch1, 0u, S1);
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    d2 tv = {0.0, 0.0};
+    const bool mpoly = (b.interior & 2) != 0;
+    if (tid < b.nidx * 4)
+        tv = ((const d2*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs))[tid];
+    RowCol rc;
+    load_rowcol<0>(P, t.xc, t.jc, rc);
+    stage_store_pair(M, S0, S1, dyn_box);
+    if (tid < b.nidx * 4)
+        ((d2*)tabw)[tid] = tv;
+    __syncthreads();
+    // the mirrored band's box: requested now, in flight while the tile itself is evaluated and sampled
+    make_chunk_map<NT>(q, tid, M);
+    stage_load<false, false>(M, src0, pitch0, 0u, S0);
+    stage_load<false, false>(M, src1, pitch1, 0u, S1);
+    LaneCoords L;
+    if (mpoly)
+        lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+    else
+        lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+    sample_pair_cells(ua, t, t.j, b, dyn_box, L.sx, L.sy);
+    __syncthreads();  // every wave has read its taps of the tile's box
+    stage_store_pair(M, S0, S1, dyn_box);
+    __syncthreads();
+    sample_pair_cells(ua, t, mirror_h - t.j, q, dyn_box, L.sx, L.sy2);
+}
+
 static int taps_of(int interp)
 {
     return interp == V1C_INTER_LINEAR ? 2 : interp == V1C_INTER_CUBIC ? 4 : interp == V1C_INTER_LANCZOS4 ? 8 : 0;
@@ -1435,6 +1574,57 @@ size_t tile_box_bytes(const Geom& g)
     return (size_t)d.x * d.y * sizeof(TileBox);
 }
 
+// Rest list of the mirror launch; false when the plan cannot use it (geometry, or more remaining tiles than the
+// launch's first grid slice holds).
+bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
+                      std::vector<uint32_t>& rest)
+{
+    const TileBox* b = (const TileBox*)host_boxes;
+    const TileBox* q = (const TileBox*)host_mboxes;
+    const dim3 d = tile_grid(g, tile_threads(g), 1);
+    rest.clear();
+    if (mirror_h != g.dst_h || g.dst_h % 32 != 0 || g.dst_w % 4 != 0 || d.x > 0xffffu || d.y > 0xffffu)
+        return false;
+    const unsigned TY = d.y, TYh = TY / 2;
+    if (TYh < 3)
+        return false;
+    std::vector<uint8_t> in_rest((size_t)d.x * d.y, 0);
+    auto add = [&](unsigned tx, unsigned ty) { in_rest[(size_t)ty * d.x + tx] = 1; };
+    for (unsigned tx = 0; tx < d.x; tx++)
+        add(tx, 0), add(tx, TYh), add(tx, TY - 1);
+    for (unsigned ty = 1; ty < TYh; ty++)
+        for (unsigned tx = 0; tx < d.x; tx++) {
+            const size_t i = (size_t)ty * d.x + tx;
+            if (!mirror_static_ok(b[i], q[i], half_dwords, g.src_h, g.src_w))
+                add(tx, ty), add(tx, TY - 1 - ty), add(tx, TY - ty);
+        }
+    for (unsigned ty = 0; ty < d.y; ty++)
+        for (unsigned tx = 0; tx < d.x; tx++)
+            if (in_rest[(size_t)ty * d.x + tx])
+                rest.push_back(ty << 16 | tx);
+    // worth it only while the mirror path serves most of the image, and the list must fit grid slice 0
+    return rest.size() <= (size_t)d.x * (TYh - 1) && rest.size() * 4 <= (size_t)d.x * d.y;
+}
+
+hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
+                                       int mirror_h, const uint32_t* rest_list, int n_rest, hipStream_t stream)
+{
+    const dim3 full = tile_grid(c.g, 256, 1);
+    const dim3 grid(full.x, full.y / 2 - 1, 2), block(256, 1, 1);
+    const size_t lds = (size_t)half_dwords * 8 + 16;
+    const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
+    const unsigned per = (grid.x * grid.y) >> 3;
+    const unsigned slen = 2u * grid.x < per ? 2u * grid.x : 0u;  // two tile rows per strip (tile_xcd_strips)
+    const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    if (c.ray.var_is_w)
+        hipLaunchKernelGGL((k_ray_lin3_pair_mirror<1>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                           half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic);
+    else
+        hipLaunchKernelGGL((k_ray_lin3_pair_mirror<0>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                           half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic);
+    return hipGetLastError();
+}
+
 // LDS dwords one box buffer must hold so that every stageable tile box of `host_boxes` fits
 // (capped at kMaxHalfDwords: larger boxes gather from global memory)
 constexpr int kMaxHalfDwords = 8192;  // 32 KB per buffer
@@ -1459,7 +1649,7 @@ int tile_half_dwords(const void* host_boxes, size_t n_tiles)
 int tile_lean_half_dwords(int half_dwords)
 {
     static const int cap = [] {  // V1C_LEAN_CAP=<dwords>: A/B override
-        const char* e = std::getenv("V1C_LEAN_CAP");
+        const char* e = tuning_env("V1C_LEAN_CAP");
         const int v = e ? std::atoi(e) : 0;
         return v >= 256 ? v : 2816;
     }();
@@ -1474,7 +1664,7 @@ int tile_lean_half_dwords(int half_dwords)
 int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int lean_half)
 {
     static const int forced = [] {  // V1C_XCD_STRIPS=<n>: A/B override (1 = one block per XCD)
-        const char* e = std::getenv("V1C_XCD_STRIPS");
+        const char* e = tuning_env("V1C_XCD_STRIPS");
         return e ? std::atoi(e) : 0;
     }();
     const TileBox* b = (const TileBox*)host_boxes;
@@ -1488,48 +1678,48 @@ int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int 
         const bool stageable = b[i].cpr > 0 && b[i].cpr <= kMaxCpr && b[i].nrows * b[i].cpr <= 1024 && need <= half_dwords;
         cost[i] = b[i].cpr <= 0 ? 0.5f : 1.0f + (stageable ? 0.0f : 4.0f) + (need > lean_half ? 0.5f : 0.0f) + (b[i].interior ? 0.0f : 0.5f) + (float)need / 16384.0f;
     }
-    int cand_s[6], n_cand = 0;
-    double cand_load[6];
-    for (int S : {1, 2, 4, 8, 16, 32}) {
-        if (forced > 0 && S != forced)
-            continue;
-        // a strip is at least two tile rows (one row for a forced count): thinner strips share every halo row
-        // between two XCDs' L2s
-        if (per % (unsigned)S != 0 || (S > 1 && per / (unsigned)S < (forced > 0 ? 1u : 2u) * d.x))
-            continue;
-        const unsigned L = per / (unsigned)S;
+    // candidates: one block, then strips of 16, 8, 4, 2 tile rows (forced: V1C_XCD_STRIPS = strips per XCD, rounded to
+    // whole tile rows; the last strip of a share may be shorter)
+    std::vector<unsigned> cand_len;
+    std::vector<double> cand_load;
+    auto model = [&](unsigned L) {
         double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned nfull = per / L;
         for (unsigned x = 0; x < 8; x++)
             for (unsigned i = 0; i < per; i++) {
                 const unsigned sidx = i / L;
-                load[x] += cost[(sidx * 8u + x) * L + (i - sidx * L)];
+                const unsigned m = sidx < nfull ? (sidx * 8u + x) * L + (i - sidx * L) : nfull * 8u * L + x * (per - nfull * L) + (i - nfull * L);
+                load[x] += cost[m];
             }
         const double mx = *std::max_element(load, load + 8);
-        if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
-            std::fprintf(stderr, "[v1c] XCD interleave model: %2d strip(s) per XCD -> max load %.0f (mean %.0f)\n", S, mx,
+        if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
+            std::fprintf(stderr, "[v1c] XCD interleave model: strips of %u tiles (%.1f per XCD) -> max load %.0f (mean %.0f)\n", L, (double)per / L, mx,
                          (load[0] + load[1] + load[2] + load[3] + load[4] + load[5] + load[6] + load[7]) / 8);
-        cand_s[n_cand] = S, cand_load[n_cand++] = mx;
+        return mx;
+    };
+    if (forced > 0) {
+        if (forced == 1)
+            return 0;
+        const unsigned rows = std::max(1u, (per / (unsigned)forced + d.x / 2) / d.x);
+        const unsigned L = rows * d.x;
+        return L < per ? (int)L : 0;
     }
-    if (n_cand == 0)
-        return 0;
+    cand_len.push_back(per), cand_load.push_back(model(per));
+    for (unsigned rows : {16u, 8u, 4u, 2u})
+        if (rows * d.x < per)
+            cand_len.push_back(rows * d.x), cand_load.push_back(model(rows * d.x));
     // Measured with source and destination L3-cold (r02, interleaved A/B runs): the finer the interleave the
     // faster -- C2 1 / 2 / 4 / 8 / 16 strips 0.0570 / 0.0564 / 0.0555 / 0.0543 / 0.0532 ms, C4 8 -> 16 strips 1.363 ->
     // 1.336 ms -- all eight XCDs then work on the same band of the image, i.e. on the same open HBM pages and
-    // Infinity-Cache sets, instead of on eight bands 1/8 of the image apart.  (Round 1 tuned this on an L3-resident
-    // buffer set, where strips only paid for balancing tile costs.)  So: the largest count of at most 16 whose strips
-    // are still two tile rows, unless the model says a coarser one balances the tile costs 3 % better.
-    int best_s = cand_s[0];
-    if (forced <= 0) {
-        int q_best = 0;
-        for (int q = 0; q < n_cand; q++)
-            if (cand_s[q] <= 16)
-                q_best = q;
-        for (int q = q_best - 1; q >= 0; q--)
-            if (cand_load[q] < 0.97 * cand_load[q_best])
-                q_best = q;
-        best_s = cand_s[q_best];
-    }
-    return best_s > 1 ? (int)(per / (unsigned)best_s) : 0;
+    // Infinity-Cache sets, instead of on eight bands 1/8 of the image apart; below two tile rows per strip every halo
+    // row is shared between two XCDs' L2s and it turns (C2 32 strips 0.0531 vs 0.0527).  (Round 1 tuned this on an
+    // L3-resident buffer set, where strips only paid for balancing tile costs.)  So: the finest candidate, unless the
+    // model says a coarser one balances the tile costs 3 % better.
+    size_t q_best = cand_len.size() - 1;
+    for (size_t q = q_best; q-- > 0;)
+        if (cand_load[q] < 0.97 * cand_load[q_best])
+            q_best = q;
+    return cand_len[q_best] < per ? (int)cand_len[q_best] : 0;
 }
 
 // tiles the lean batch kernel leaves to the general one, as ty << 16 | tx (row-major order)
@@ -1551,16 +1741,16 @@ std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int 
 
 // plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
 template <int K, int NT>
-static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, bool shared_entry, hipStream_t stream)
+static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, bool shared_entry, int mirror_h, hipStream_t stream)
 {
     const dim3 block(NT, 1, 1), grid = tile_grid(c.g, NT, 1);
     const bool rot = c.ray.has_rot != 0;
 #define V1C_BOXES(VW, RT)                                                                                         \
     do {                                                                                                          \
         if (shared_entry)                                                                                         \
-            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0>), grid, block, 0, stream, c, ua, boxes);           \
+            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
         else                                                                                                      \
-            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1>), grid, block, 0, stream, c, ua, boxes);           \
+            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
     } while (0)
     if (c.ray.var_is_w) {
         if (rot)
@@ -1577,13 +1767,13 @@ static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxe
 }
 
 // `shared_entry`: the value the launches consuming these boxes will pass to launch_ray_lin3_tile
-hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream)
+hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream, int mirror_h)
 {
     UnitArgs ua{};
     switch (taps_of(c.g.interp)) {
-    case 2: launch_boxes_k<2, 256>(c, ua, (TileBox*)boxes, shared_entry, stream); break;
-    case 4: launch_boxes_k<4, 256>(c, ua, (TileBox*)boxes, shared_entry, stream); break;
-    case 8: launch_boxes_k<8, 256>(c, ua, (TileBox*)boxes, shared_entry, stream); break;
+    case 2: launch_boxes_k<2, 256>(c, ua, (TileBox*)boxes, shared_entry, mirror_h, stream); break;
+    case 4: launch_boxes_k<4, 256>(c, ua, (TileBox*)boxes, shared_entry, mirror_h, stream); break;
+    case 8: launch_boxes_k<8, 256>(c, ua, (TileBox*)boxes, shared_entry, mirror_h, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1596,7 +1786,7 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     static const int upb_max = [] {  // V1C_UPB=<n>: A/B override of the units per workgroup
-        const char* e = std::getenv("V1C_UPB");
+        const char* e = tuning_env("V1C_UPB");
         const int v = e ? std::atoi(e) : 0;
         return v >= 1 && v <= kUnitsPerBlock ? v : kUnitsPerBlock;
     }();
@@ -1612,12 +1802,12 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     // batches (more than two units per workgroup) of a bilinear plan: the interior tiles go to the lean
     // kernel, everything else stays with the general one (same grid; each skips the other's tiles)
     static const bool lean_off = [] {
-        const char* e = std::getenv("V1C_DISABLE_LEAN");
+        const char* e = tuning_env("V1C_DISABLE_LEAN");
         return e && e[0] == '1';
     }();
     // (every group with more than two units, every source dword-aligned, tile coordinates fit 16 bits)
     static const bool lean_pair = [] {  // V1C_LEAN_PAIR=1: A/B switch, pairs through the lean kernel too
-        const char* e = std::getenv("V1C_LEAN_PAIR");
+        const char* e = tuning_env("V1C_LEAN_PAIR");
         return e && e[0] == '1';
     }();
     bool lean = bx && K == 2 && !lean_off && rest_list != nullptr &&
@@ -1631,28 +1821,33 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     // the remaining tiles ride in the lean launch as one more grid slice when they fit one (else, or
     // with V1C_DISABLE_MERGE=1, in a launch of their own)
     static const bool merge_off = [] {
-        const char* e = std::getenv("V1C_DISABLE_MERGE");
+        const char* e = tuning_env("V1C_DISABLE_MERGE");
         return e && e[0] == '1';
     }();
     const bool merged = !merge_off && n_rest > 0 && (size_t)n_rest * ((n_units + 1) / 2) <= (size_t)grid.x * grid.y;
     const dim3 merged_grid(grid.x, grid.y, grid.z + 1);
     const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
-    const unsigned slen = bx && strip_len > 0 && ((grid.x * grid.y) >> 3) % (unsigned)strip_len == 0 ? (unsigned)strip_len : 0u;
+    const unsigned slen = bx && strip_len > 0 && (unsigned)strip_len < ((grid.x * grid.y) >> 3) ? (unsigned)strip_len : 0u;
     const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    // Only combinations a plan can select are instantiated: the lean batch kernel and the tile-list form exist for
+    // bilinear plans with boxes; launches without boxes (units that override the rotation) always rotate.
 #define V1C_TILE_P(VW, RT, BX, OW, PR)                                                                                                \
     do {                                                                                                                              \
-        if (lean) {                                                                                                                   \
-            /* (running the remaining tiles on a side stream, forked and joined with events so that their */                          \
-            /* latency-bound kernel overlaps the lean one, measured 4 % slower on C3 than back to back) */                            \
-            hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), merged ? merged_grid : grid, block, lean_lds, stream, c, ua, bx,   \
-                               n_units, upb, lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest, slen, smagic); \
-            if (n_rest > 0 && !merged)                                                                                                \
-                hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, BX, BX>), rest_grid, block, lds, stream, c, ua, bx, n_units, 2, \
-                                   half_dwords, xmagic, rest_list, (int)grid.x, 0u, 0u);                                              \
-        } else {                                                                                                                      \
-            hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb,           \
-                               half_dwords, xmagic, (const uint32_t*)nullptr, (int)grid.x, slen, smagic);                             \
+        if constexpr (K == 2 && BX == 1) {                                                                                            \
+            if (lean) {                                                                                                               \
+                /* (running the remaining tiles on a side stream, forked and joined with events so that their */                      \
+                /* latency-bound kernel overlaps the lean one, measured 4 % slower on C3 than back to back) */                        \
+                hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), merged ? merged_grid : grid, block, lean_lds, stream, c, ua,  \
+                                   bx, n_units, upb, lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest, slen,  \
+                                   smagic);                                                                                           \
+                if (n_rest > 0 && !merged)                                                                                            \
+                    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K, OW, 1, 1>), rest_grid, block, lds, stream, c, ua, bx, n_units,  \
+                                       2, half_dwords, xmagic, rest_list, (int)grid.x, 0u, 0u);                                      \
+                break;                                                                                                                \
+            }                                                                                                                         \
         }                                                                                                                             \
+        hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords,  \
+                           xmagic, (const uint32_t*)nullptr, (int)grid.x, slen, smagic);                                             \
     } while (0)
 #define V1C_TILE_O(VW, RT, BX, OW)                       \
     do {                                                 \
@@ -1668,10 +1863,12 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
         else if (bx)                    \
             V1C_TILE_O(VW, RT, 1, 1);   \
         else if (shared_entry)          \
-            V1C_TILE_O(VW, RT, 0, 0);   \
+            V1C_TILE_O(VW, 1, 0, 0);    \
         else                            \
-            V1C_TILE_O(VW, RT, 0, 1);   \
+            V1C_TILE_O(VW, 1, 0, 1);    \
     } while (0)
+    if (!bx)
+        use_rot = true;  // (units override the rotation: plan.hip passes any_rot || has_rot)
     if (c.ray.var_is_w) {
         if (use_rot)
             V1C_TILE(1, 1);

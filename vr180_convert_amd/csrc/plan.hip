@@ -173,6 +173,12 @@ struct v1c_plan {
     int n_rest = 0;
     int lean_half = 256;          // box buffer dwords of the lean batch kernel (<= half_dwords)
     int strip_len = 0;            // XCD interleave: tiles per strip (0: one block per XCD), tile_xcd_strips()
+    // apply_lr pairs of unrotated chains: boxes of the bands that mirror the tiles about the equator and the tiles
+    // the mirror launch leaves to the pair kernel (k_ray_lin3_pair_mirror); mirror_boxes == nullptr: not used
+    void* mirror_boxes = nullptr;
+    const uint32_t* mirror_rest = nullptr;
+    int n_mirror_rest = 0;
+    int mirror_h = 0;
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     bool disable_shared_entry = false;  // V1C_DISABLE_SHARED_ENTRY=1: keep the per-pixel table fallback compiled in
     bool disable_mpoly = false;         // V1C_DISABLE_MPOLY=1: no m-polynomial table (every tile takes the square root)
@@ -309,11 +315,11 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
     v1c_plan* p = new v1c_plan();
     p->chain = *chain;
     {
-        const char* e = std::getenv("V1C_DISABLE_FAST");
+        const char* e = tuning_env("V1C_DISABLE_FAST");
         p->disable_fast = e && e[0] == '1';
-        e = std::getenv("V1C_DISABLE_SHARED_ENTRY");
+        e = tuning_env("V1C_DISABLE_SHARED_ENTRY");
         p->disable_shared_entry = e && e[0] == '1';
-        e = std::getenv("V1C_DISABLE_MPOLY");
+        e = tuning_env("V1C_DISABLE_MPOLY");
         p->disable_mpoly = e && e[0] == '1';
     }
     rc = plan_common(p, device, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, border_val);
@@ -391,10 +397,10 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         p->mp_valid_upto++;
                 }
             }
-            if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+            if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                 std::fprintf(stderr, "[v1c] m-polynomial table: %s, first usable interval %d of %d\n", r.radial_m ? "yes" : "no",
                              r.mp_first_ok, r.n_int);
-            if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+            if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                 std::fprintf(stderr,
                              "[v1c] ray plan: var=%s n_int=%d first_invalid=%d first_below_level1=%d first_below_level2=%d m_reach=%.6f "
                              "ray_step=%.3e no_rot_safe=%d plan_rot_safe=%d shared_entry=%d\n",
@@ -450,12 +456,12 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     return fail(V1C_E_HIP, std::string("tile boxes readback: ") + hipGetErrorString(e));
                 }
                 p->half_dwords = tile_half_dwords(hb.data(), hb.size() / 32);
-                if (const char* e = std::getenv("V1C_HALF_CAP"); e && std::atoi(e) >= 256)  // A/B: cap the LDS box buffers
+                if (const char* e = tuning_env("V1C_HALF_CAP"); e && std::atoi(e) >= 256)  // A/B: cap the LDS box buffers
                     p->half_dwords = std::min(p->half_dwords, std::atoi(e));
                 {
                     p->lean_half = tile_lean_half_dwords(p->half_dwords);
                     p->strip_len = tile_xcd_strips(hb.data(), g, p->half_dwords, p->lean_half);
-                    if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+                    if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                         std::fprintf(stderr, "[v1c] XCD interleave: strips of %d tiles\n", p->strip_len);
                     const std::vector<uint32_t> rest = tile_rest_list(hb.data(), g, p->lean_half);
                     const dim3 full((unsigned)((g.dst_w + 63) / 64), (unsigned)((g.dst_h + 15) / 16));
@@ -466,10 +472,43 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         }
                         p->n_rest = (int)rest.size();
                     }
-                    if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1')
+                    if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                         std::fprintf(stderr, "[v1c] lean batch kernel: %d of %zu tiles left to the general kernel\n", p->n_rest, hb.size() / 32);
                 }
-                if (const char* dbg = std::getenv("V1C_DEBUG"); dbg && dbg[0] == '1') {
+                // bilinear pairs of an unrotated chain whose rows mirror about an integer row (the default Normalize
+                // centre H / 2): boxes of the mirrored bands + the list of tiles that launch leaves to the pair kernel
+                {
+                    const char* off = tuning_env("V1C_DISABLE_MIRROR");
+                    const double two_cy = 2.0 * p->ana.norm_cy;
+                    if (!(off && off[0] == '1') && g.interp == V1C_INTER_LINEAR && !p->ana.has_rot && p->plan_shared_entry &&
+                        !p->disable_shared_entry && two_cy == (double)g.dst_h) {
+                        void* mbx = nullptr;
+                        e = hipMalloc(&mbx, tile_box_bytes(g));
+                        if (e == hipSuccess) {
+                            p->allocs.push_back(mbx);
+                            e = launch_tile_boxes(p->ctx, mbx, true, nullptr, g.dst_h);
+                        }
+                        std::vector<char> hm(tile_box_bytes(g));
+                        if (e == hipSuccess)
+                            e = hipMemcpy(hm.data(), mbx, hm.size(), hipMemcpyDeviceToHost);
+                        if (e != hipSuccess) {
+                            v1c_plan_destroy(p);
+                            return fail(V1C_E_HIP, std::string("mirror boxes: ") + hipGetErrorString(e));
+                        }
+                        std::vector<uint32_t> mrest;
+                        if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest)) {
+                            if ((rc = upload(p, mrest, &p->mirror_rest))) {
+                                v1c_plan_destroy(p);
+                                return rc;
+                            }
+                            p->mirror_boxes = mbx, p->n_mirror_rest = (int)mrest.size(), p->mirror_h = g.dst_h;
+                        }
+                        if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
+                            std::fprintf(stderr, "[v1c] mirror pair launch: %s, %zu of %zu tiles left to the pair kernel\n",
+                                         p->mirror_boxes ? "yes" : "no", mrest.size(), hb.size() / 32);
+                    }
+                }
+                if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1') {
                     // histogram of the LDS dwords each tile box needs
                     const int* bi = (const int*)hb.data();
                     const size_t nt = hb.size() / 32;
@@ -601,7 +640,14 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 if (p->flags_pending && p->flags_stream != st)
                     HIP_TRY(hipStreamWaitEvent(st, p->flags_ev, 0));
             }
-            if (fast) {
+            // a pair (apply_lr) of an unrotated chain: the tile + mirror-image launch
+            bool mirror = fast && n == 2 && !any_rot && p->mirror_boxes != nullptr && shared_entry && !p->disable_shared_entry;
+            for (int k = 0; k < n && mirror; k++)
+                mirror = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
+            if (mirror) {
+                HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h, p->mirror_rest,
+                                                    p->n_mirror_rest, st));
+            } else if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
                                              shared_entry && !p->disable_shared_entry, mpoly_all && !p->disable_mpoly,
