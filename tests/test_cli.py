@@ -1,0 +1,149 @@
+"""Command line (reference cli.py:116-559, tests/test_cli.py, tests/test_dunder_main.py): the parts that need no
+GPU -- help texts, option parsing, file-name and time-match rules, the swap command -- and, gpu-marked, ``lr`` / ``s``
+end to end against the oracle."""
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+from typer.testing import CliRunner
+
+import chainspecs as CS
+from vr180_convert_amd import _io, cli
+
+runner = CliRunner()
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_help_of_every_command():
+    assert runner.invoke(cli.app, ["--help"]).exit_code == 0
+    for cmd in ("lr", "s", "swap", "xmp"):
+        r = runner.invoke(cli.app, [cmd, "--help"])
+        assert r.exit_code == 0, r.stdout
+
+
+def test_dunder_main_prints_the_prog_name():
+    r = subprocess.run([sys.executable, "-m", "vr180_convert_amd", "--help"], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0 and "vr180-convert" in r.stdout
+
+
+def test_transformer_expressions_evaluate_in_the_cli_namespace():
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.chain import MultiTransformer
+
+    t = cli.parse_transformer("")
+    assert isinstance(t, MultiTransformer) and [type(s).__name__ for s in t.transformers] == ["EquirectangularEncoder", "InverseTransformer"]
+    # the expressions of the reference's CLI tests (tests/test_cli.py:32-34, 53-55)
+    t = cli.parse_transformer('FisheyeEncoder("equidistant") * Euclidean3DRotator(from_rotation_vector([0, np.pi / 4, 0])) * FisheyeDecoder("equidistant")')
+    assert isinstance(t.transformers[1], T.Euclidean3DRotator)
+    np.testing.assert_allclose(t.transformers[1].matrix, [[np.cos(np.pi / 4), 0, np.sin(np.pi / 4)], [0, 1, 0], [-np.sin(np.pi / 4), 0, np.cos(np.pi / 4)]], atol=1e-15)
+    t = cli.parse_transformer("EquirectangularEncoder() * PolynomialScaler([0, 1, -0.1]) * FisheyeDecoder('equidistant')")
+    assert list(t.transformers[1].coefs_reverse) == [0, 1, -0.1]
+
+
+def test_option_parsing():
+    assert cli.parse_size("4096x2048") == (4096, 2048)
+    assert cli.parse_radius("auto") == "auto" and cli.parse_radius("max") == "max" and cli.parse_radius("512.5") == 512.5
+    for spelling in ("INTER_LANCZOS4", "inter_lanczos4", "lanczos4"):
+        assert cli._flag(spelling, cli._INTERPOLATIONS, "inter_", "interpolation") == 4
+    assert cli._flag("border_reflect_101", cli._BORDERS, "border_", "border mode") == 4
+    with pytest.raises(Exception):
+        cli._flag("inter_bogus", cli._INTERPOLATIONS, "inter_", "interpolation")
+
+
+def test_output_names(tmp_path):
+    left, right = tmp_path / "a" / "L001.jpg", tmp_path / "b" / "R001.jpg"
+    assert cli.output_path(Path(""), left, right, "") == tmp_path / "a" / "L001-R001.png"
+    (tmp_path / "out").mkdir()
+    assert cli.output_path(tmp_path / "out", left, right, "-12345678") == tmp_path / "out" / "L001-R001-12345678.png"
+    assert cli.output_path(tmp_path / "x.jpg", left, right, "") == tmp_path / "x.jpg"
+    tag = cli.unique_suffix("T", "4096x4096", "inter_lanczos4", "border_constant", 0, "auto", False, 0.0, False)
+    assert len(tag) == 9 and tag[0] == "-" and tag != cli.unique_suffix("T", "2048x2048", "inter_lanczos4", "border_constant", 0, "auto", False, 0.0, False)
+
+
+def test_time_matched_search(tmp_path):
+    """One argument may be a directory: the image whose mtime is closest to the other eye's, after the clock
+    offset, is taken (cli.py:178-216)."""
+    d = tmp_path / "right_cam"
+    d.mkdir()
+    left = tmp_path / "left.jpg"
+    left.write_bytes(b"x")
+    now = time.time()
+    os.utime(left, (now, now))
+    for name, dt in (("r0.jpg", -30.0), ("r1.jpg", 2.0), ("r2.jpg", 11.0), ("r1.png", 0.0)):
+        (d / name).write_bytes(b"x")
+        os.utime(d / name, (now + dt, now + dt))
+    assert cli.resolve_pair(left, d, 0.0) == (left, d / "r1.jpg")        # same suffix only
+    assert cli.resolve_pair(left, d, 10.0) == (left, d / "r2.jpg")       # right clock 10 s ahead
+    assert cli.resolve_pair(d, left, 0.0) == (d / "r1.jpg", left)
+    with pytest.raises(ValueError):
+        cli.resolve_pair(d, d, 0.0)
+    with pytest.raises(ValueError):
+        cli.closest_in_time(tmp_path / "right_cam", tmp_path / "left.tif" if (tmp_path / "left.tif").write_bytes(b"x") else left, 0.0)
+
+
+def test_swap_command(tmp_path):
+    img = np.arange(6 * 8 * 3, dtype=np.uint8).reshape(6, 8, 3)
+    p = tmp_path / "sbs.png"
+    _io.imwrite(p, img)
+    r = runner.invoke(cli.app, ["swap", str(p), "--no-overwrite"])
+    assert r.exit_code == 0, r.stdout
+    assert np.array_equal(_io.imread(tmp_path / "sbs.swap.png"), np.hstack([img[:, 4:], img[:, :4]]))
+    assert np.array_equal(_io.imread(p), img)
+    assert runner.invoke(cli.app, ["swap", str(p)]).exit_code == 0
+    assert np.array_equal(_io.imread(p), np.hstack([img[:, 4:], img[:, :4]]))
+
+
+def test_automatch_split_and_missing_cv2():
+    from vr180_convert_amd import transformer as T
+
+    t = T.EquirectangularEncoder() * T.PolynomialScaler([0, 1, -0.1]) * T.FisheyeDecoder("equidistant")
+    head, tail = cli.split_at_first_encoder(t)
+    assert [type(s).__name__ for s in head.transformers] == ["EquirectangularEncoder"]
+    assert [type(s).__name__ for s in tail.transformers] == ["PolynomialScaler", "InverseTransformer"]
+    with pytest.raises(ValueError):
+        cli.split_at_first_encoder(T.ZoomTransformer(2.0))
+    try:
+        import cv2  # noqa: F401
+    except Exception:  # noqa: BLE001
+        with pytest.raises(Exception, match="OpenCV"):
+            cli._points_from_option("fm0.5", Path("a"), Path("b"))
+
+
+@pytest.mark.gpu
+def test_lr_and_s_commands_match_the_oracle(tmp_path, oracle_mod):
+    """The reference's CLI tests (tests/test_cli.py:24-64) with assertions: outputs equal the oracle's."""
+    from vr180_convert_amd.synth import pattern
+
+    O = oracle_mod
+    img = pattern(256, 256)
+    p = tmp_path / "test.png"
+    _io.imwrite(p, img)
+    out = tmp_path / "test.cli.lr.png"
+    expr = 'FisheyeEncoder("equidistant") * Euclidean3DRotator(from_rotation_vector([0, np.pi / 4, 0])) * FisheyeDecoder("equidistant")'
+    r = runner.invoke(cli.app, ["lr", str(p), str(p), "--transformer", expr, "--radius", "max", "--out-path", str(out), "--size", "256x256"])
+    assert r.exit_code == 0, (r.stdout, r.exception)
+    spec = [("fisheye_enc", "equidistant"), ("rot", CS.ry(np.pi / 4)), ("fisheye_dec", "equidistant")]
+    # same path for both eyes: the file is split into halves (remapper.py:448-456)
+    want = O.apply_lr(spec, img[:, :128], img[:, 128:], size_output=(256, 256), interpolation=4, radius="max")
+    assert np.array_equal(_io.imread(out), want)
+    out_s = tmp_path / "test.cli.s.png"
+    expr = 'FisheyeEncoder("equidistant") * Euclidean3DRotator(from_rotation_vector([np.pi / 4, 0, 0])) * FisheyeDecoder("equidistant")'
+    r = runner.invoke(cli.app, ["s", str(p), "--transformer", expr, "--radius", "max", "--out-path", str(out_s), "--size", "256x256",
+                                "--interpolation", "inter_linear"])
+    assert r.exit_code == 0, (r.stdout, r.exception)
+    c, s_ = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    spec = [("fisheye_enc", "equidistant"), ("rot", [[1, 0, 0], [0, c, -s_], [0, s_, c]]), ("fisheye_dec", "equidistant")]
+    assert np.array_equal(_io.imread(out_s), O.apply(spec, [img], size_output=(256, 256), interpolation=1, radius="max")[0])
+    # explicit calibration points, default output name next to the left image, unique suffix
+    l, r_ = tmp_path / "L.png", tmp_path / "R.png"
+    _io.imwrite(l, img)
+    _io.imwrite(r_, img)
+    r = runner.invoke(cli.app, ["lr", str(l), str(r_), "--radius", "max", "--size", "128x128", "--interpolation", "inter_linear",
+                                "--automatch", "100,100;104,101;160,90;163,92;80,170;82,173", "--name-unique"])
+    assert r.exit_code == 0, (r.stdout, r.exception)
+    made = list(tmp_path.glob("L-R-*.png"))
+    assert len(made) == 1 and _io.imread(made[0]).shape == (128, 256, 3)

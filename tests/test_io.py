@@ -1,0 +1,51 @@
+"""Image I/O either side of the path: the multi-threaded PNG writer decodes to the same pixels
+with an independent reader (Pillow), .npy round trips, cv2's imread contract (None for unreadable files)."""
+import numpy as np
+import pytest
+
+from vr180_convert_amd import _io, _png
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 3), (37, 53, 3), (64, 48), (200, 300, 4), (1030, 517, 3)])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_parallel_png_decodes_with_pillow(tmp_path, shape, threads):
+    from PIL import Image
+
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    if img.ndim == 3:
+        img[: shape[0] // 2] = img[0, 0]  # a compressible half
+    p = tmp_path / "x.png"
+    _png.write(p, img, threads=threads, band_rows=16)
+    with Image.open(p) as im:
+        im.load()
+        got = np.asarray(im)
+    want = img if img.ndim == 2 else img[..., ::-1] if shape[2] == 3 else img[..., [2, 1, 0, 3]]
+    assert got.shape == want.shape and np.array_equal(got, want)
+    back = _io.imread(p)  # cv2.imread's default: always 3 channels, BGR
+    assert np.array_equal(back, np.repeat(img[..., None], 3, axis=2) if img.ndim == 2 else img[..., :3])
+
+
+def test_imwrite_uses_the_parallel_encoder_for_large_pngs_and_round_trips(tmp_path):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (700, 900, 3), dtype=np.uint8)  # 1.9 MB > PARALLEL_PNG_MIN_BYTES
+    p = tmp_path / "big.png"
+    assert _io.imwrite(p, img)
+    assert np.array_equal(_io.imread(p), img)
+    small = img[:20, :30]
+    assert _io.imwrite(tmp_path / "small.png", small) and np.array_equal(_io.imread(tmp_path / "small.png"), small)
+    # float input is saturated like cv2.imwrite does
+    f = np.array([[[-5.0, 100.4, 300.0]]])
+    _io.imwrite(tmp_path / "f.png", f)
+    assert np.array_equal(_io.imread(tmp_path / "f.png"), [[[0, 100, 255]]])
+
+
+def test_npy_round_trip_and_unreadable_files(tmp_path):
+    img = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    p = tmp_path / "frame.npy"
+    assert _io.imwrite(p, img[:, ::-1])  # a non-contiguous view
+    got = _io.imread(p)
+    assert np.array_equal(got, img[:, ::-1])
+    assert _io.imread(tmp_path / "missing.png") is None and _io.imread(tmp_path / "missing.npy") is None
+    np.save(tmp_path / "float.npy", np.zeros((4, 4), np.float32))
+    assert _io.imread(tmp_path / "float.npy") is None  # images are uint8

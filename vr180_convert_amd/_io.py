@@ -1,12 +1,19 @@
 """Image file I/O either side of the hot path (reference remapper.py:373,402,453,519 use
 ``cv.imread`` / ``cv.imwrite``).  cv2 is used when it is importable, Pillow otherwise; arrays are
-BGR like cv2's.  Codec work is outside the measured path."""
+BGR like cv2's.  Codec work is outside the measured path.
+
+Two additions for batch work, where codecs -- not the remap -- set the end-to-end time:
+* ``.npy`` files are read (memory-mapped) and written as raw uint8 arrays in cv2 channel order: the codec-free
+  format for frame sequences (the GPU image ships no device-side JPEG / PNG codec: no rocJPEG, no torchvision);
+* large PNGs are written by the multi-threaded encoder of ``_png.py`` when cv2 is absent."""
 from __future__ import annotations
 
 from pathlib import Path
 from typing import Any
 
 import numpy as np
+
+PARALLEL_PNG_MIN_BYTES = 1 << 20  # below this a single zlib stream is as fast
 
 try:  # pragma: no cover - not installed in the build / GPU image
     import cv2 as _cv
@@ -17,6 +24,12 @@ except Exception:  # noqa: BLE001
 def imread(path: Any):
     """BGR uint8 (H, W, 3) array, or ``None`` when the file cannot be read (cv2.imread's contract)."""
     p = Path(path).as_posix()
+    if p.lower().endswith(".npy"):
+        try:
+            a = np.load(p, mmap_mode="r")
+        except (OSError, ValueError):
+            return None
+        return a if a.dtype == np.uint8 and a.ndim in (2, 3) else None
     if _cv is not None:
         return _cv.imread(p)
     from PIL import Image
@@ -33,8 +46,16 @@ def imwrite(path: Any, image: np.ndarray) -> bool:
     p = Path(path).as_posix()
     if image.dtype != np.uint8:
         image = np.clip(np.rint(image), 0, 255).astype(np.uint8)  # cv2.imwrite converts with saturation
+    if p.lower().endswith(".npy"):
+        np.save(p, np.ascontiguousarray(image))
+        return True
     if _cv is not None:
         return bool(_cv.imwrite(p, image))
+    if p.lower().endswith(".png") and image.size >= PARALLEL_PNG_MIN_BYTES and image.ndim in (2, 3):
+        from . import _png
+
+        _png.write(p, image, level=1)  # cv2.imwrite's default compression level
+        return True
     from PIL import Image
 
     arr = image if image.ndim == 2 else image[..., ::-1] if image.shape[2] == 3 else image[..., [2, 1, 0, 3]]

@@ -511,8 +511,10 @@ def _to_device(img: Any, dev: torch.device) -> torch.Tensor:
         raise TypeError("images must be uint8")  # cv2.remap's fixed-point path is the uint8 one
     if a.ndim == 2:
         a = a[..., None]
-    # column-sliced views (remapper.py:455-456) are made contiguous on the host before upload
-    return torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=False)
+    # column-sliced views (remapper.py:455-456) are made contiguous on the host before upload; read-only arrays
+    # (memory-mapped .npy frames, Pillow buffers) are copied: torch refuses to alias them silently
+    a = np.ascontiguousarray(a) if a.flags.writeable else np.array(a, order="C")
+    return torch.from_numpy(a).to(dev, non_blocking=False)
 
 
 def apply(
