@@ -26,8 +26,10 @@ def _chunk(kind: bytes, data: bytes) -> bytes:
     return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
 
 
-def encode(image: np.ndarray, *, level: int = 1, threads: int | None = None, band_rows: int | None = None) -> bytes:
-    """PNG bytes of a uint8 image in cv2 channel order: (H, W) gray, (H, W, 3) BGR or (H, W, 4) BGRA."""
+def encode(image: np.ndarray, *, level: int = 1, threads: int | None = None, band_rows: int | None = None, up_filter: bool = True) -> bytes:
+    """PNG bytes of a uint8 image in cv2 channel order: (H, W) gray, (H, W, 3) BGR or (H, W, 4) BGRA.
+    ``up_filter``: scanline filter 2 ("Up": each byte minus the one above it, one vectorised subtraction) instead
+    of 0 ("None") -- photographs deflate about a third smaller and faster."""
     if image.dtype != np.uint8 or image.ndim not in (2, 3):
         raise TypeError("PNG encoder takes uint8 (H, W[, C]) arrays")
     a = image if image.ndim == 3 else image[..., None]
@@ -35,9 +37,9 @@ def encode(image: np.ndarray, *, level: int = 1, threads: int | None = None, ban
     if cn not in (1, 3, 4) or h == 0 or w == 0:
         raise ValueError("1, 3 or 4 channels and a non-empty image")
     color_type = {1: 0, 3: 2, 4: 6}[cn]
-    # scanlines: filter byte 0 ("None") + pixels in RGB(A) order
+    # scanlines: filter byte + pixels in RGB(A) order
     lines = np.empty((h, 1 + w * cn), np.uint8)
-    lines[:, 0] = 0
+    lines[:, 0] = 2 if up_filter else 0
     body = lines[:, 1:].reshape(h, w, cn)
     if cn == 1:
         body[...] = a
@@ -45,6 +47,9 @@ def encode(image: np.ndarray, *, level: int = 1, threads: int | None = None, ban
         body[..., 0], body[..., 1], body[..., 2] = a[..., 2], a[..., 1], a[..., 0]
         if cn == 4:
             body[..., 3] = a[..., 3]
+    if up_filter and h > 1:
+        flat = lines[:, 1:]
+        flat[1:] -= flat[:-1].copy()  # uint8 wrap-around = the filter's modulo-256 difference (row 0: the row above is zero)
     nthreads = threads or min(32, os.cpu_count() or 1)
     rows = band_rows or max(16, -(-h // (4 * nthreads)))
     bands = [(r, min(r + rows, h)) for r in range(0, h, rows)]
