@@ -16,6 +16,8 @@ made any HIP call, its output is passed through and its exit code returned.
 
 The inputs / outputs of a step rotate over >= 3 buffer sets of > 640 MiB in total, so no step finds
 its source or destination lines in the 256 MiB Infinity Cache (L3-cold, like a stream of frames).
+Before the W warm-up steps the workload's own launch is replayed untimed for 0.5 s: clocks and the HIP
+launch queue are then in the state of a running stream, whatever K and W are (see main()).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused remap launch):
 algorithmic bytes per launch (3 B * (source + destination pixels), both eyes: SURVEY.md 8d)
@@ -391,17 +393,24 @@ def main() -> None:
     first_call_ms = (time.perf_counter() - t0) * 1e3
     plan_create_ms = sum(p.create_ms for p in R._PLANS.values())
 
-    # Setup, not a step: the GPU comes out of its idle power state slowly on this pool (a C2 step measured 0.24-0.36 ms
-    # in a 13 ms run of 220 steps, 0.058 ms once the card had been busy for ~0.1 s; the CPU-side input synthesis above
-    # leaves it idle for about a second).  Keep it busy with memory-bound work for 0.5 s of wall time before the W
-    # warm-up steps.  The timed region below is exactly K steps.
-    spin = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.5:
-        for _ in range(20):
-            spin.add_(1)
+    # Setup, not steps: condition the GPU before the W warm-up steps.  On this pool the card comes out of its idle
+    # power state slowly (the CPU-side input synthesis above leaves it idle for about a second) and its clocks follow
+    # the KIND of work: after 0.5 s of a memory-bound filler kernel 20 timed C2 steps still ran at half speed
+    # (0.105 ms against 0.053 ms after ~5 ms of the remap itself), and the HIP runtime stalls once for ~35 ms when
+    # its launch queue first gets ~60 packets deep.  So the workload's own launch is replayed, untimed, for 0.5 s
+    # (first one burst of 256 launches, then bursts of 64) -- the state a stream of frames runs in.  Nothing of it is
+    # measured; the timed region below is exactly K steps after the W warm-up steps.
+    torch.cuda.synchronize(dev)
+    t_cond = time.perf_counter()
+    n_cond, burst = 0, 256
+    while True:
+        for _ in range(burst):
+            step(n_cond)
+            n_cond += 1
         torch.cuda.synchronize(dev)
-    del spin
+        burst = 64
+        if time.perf_counter() - t_cond >= 0.5:
+            break
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
