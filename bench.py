@@ -81,6 +81,19 @@ def allreduce_max(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def allgather_scalar(value: float, device: torch.device, world: int) -> list[float]:
+    """One host scalar per rank, on every rank (tensor all_gather: RCCL on the device, gloo on the host)."""
+    import torch.distributed as dist
+
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    where = device if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([value], dtype=torch.float64, device=where)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def build_transformer(cfg):
     import math
 
@@ -431,11 +444,7 @@ def main() -> None:
     elapsed = allreduce_max(elapsed, dev)
     kernel_ms = e0.elapsed_time(e1) / args.steps
     kernel_ms_max = allreduce_max(kernel_ms, dev)
-    per_rank_ms = [kernel_ms]
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, kernel_ms)
-        per_rank_ms = [float(v) for v in gathered]
+    per_rank_ms = allgather_scalar(kernel_ms, dev, world)
 
     px_per_step = units * size * size * world
     value = px_per_step * args.steps / elapsed / 1e6

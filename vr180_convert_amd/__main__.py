@@ -1,4 +1,7 @@
-"""``python -m vr180_convert_amd`` (reference __main__.py:3-5)."""
-from .cli import app
+"""Entry point of ``python -m vr180_convert_amd``: the command line of cli.py under the reference's program name."""
+import sys
 
-app(prog_name="vr180-convert")
+from . import cli
+
+if __name__ == "__main__":
+    cli.main(sys.argv[1:])

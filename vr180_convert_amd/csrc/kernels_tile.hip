@@ -1583,7 +1583,8 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
     const TileBox* q = (const TileBox*)host_mboxes;
     const dim3 d = tile_grid(g, tile_threads(g), 1);
     rest.clear();
-    if (mirror_h != g.dst_h || g.dst_h % 32 != 0 || g.dst_w % 4 != 0 || d.x > 0xffffu || d.y > 0xffffu)
+    const int th = tile_threads(g) / kLanesX;  // tile height
+    if (mirror_h != g.dst_h || g.dst_h % (2 * th) != 0 || g.dst_w % 4 != 0 || d.x > 0xffffu || d.y > 0xffffu)
         return false;
     const unsigned TY = d.y, TYh = TY / 2;
     if (TYh < 3)
