@@ -1072,3 +1072,17 @@ def test_mirror_pair_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radiu
         got = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev),
                                  size_output=out_wh, interpolation=1, radius=radius, boarder_value=(5, 6, 7)).cpu().numpy()
         assert np.array_equal(got, want), (spec, int((got != want).sum()))
+
+
+def test_remap_sharded_splits_rows_when_devices_outnumber_eyes(V, oracle_mod):
+    """a single pair on 4 / 8 GPUs = bands of output rows per GPU (each needs the whole source eye, no
+    exchange).  Eight workers on the one card of the test box: 2 eyes x 4 bands, assembled rows equal the oracle's."""
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    left, right = noise_disc(300, 300, 31), noise_disc(300, 300, 32)
+    spec = [("equirect_enc", True), ("rot", CS.ry(0.2)), ("poly", [0, 1, -0.1]), CS.EQUI]
+    want = O.apply_lr(spec, left, right, size_output=(256, 208), interpolation=4, radius="max")
+    for ndev in (4, 8):
+        got = V.remap_sharded(CS.to_product(spec), [(left, right)], size_output=(256, 208), interpolation=4, radius="max", devices=[0] * ndev)
+        assert np.array_equal(got[0], want), ndev

@@ -181,3 +181,44 @@ def test_plan_shards_partition_exactly(n_frames, world):
         assert max(sizes) - min(sizes) <= 2
     else:
         assert max(sizes) <= 2 and sizes == sorted(sizes, reverse=True)
+
+
+@pytest.mark.parametrize("height,n", [(4096, 4), (100, 3), (30, 8), (16, 4), (2880, 7)])
+def test_row_bands_cover_the_rows(height, n):
+    sys.path.insert(0, str(ROOT))
+    from vr180_convert_amd.sharding import plan_band_shards, row_bands
+
+    bands = row_bands(height, n)
+    assert bands[0][0] == 0 and bands[-1][1] == height and len(bands) <= n
+    assert all(a[1] == b[0] for a, b in zip(bands, bands[1:])) and all(r1 > r0 for r0, r1 in bands)
+    assert all(r0 % 16 == 0 for r0, _ in bands)
+    work = plan_band_shards(1, 2 * n, height)
+    flat = sorted(u for rank in work for u in rank)
+    assert flat == [(0, e, r0, r1) for e in (0, 1) for (r0, r1) in bands]
+    assert max(len(r) for r in work) == 1  # one band per rank
+
+
+def test_row_band_chain_reproduces_the_rows_of_the_full_map(emul_lib, oracle_mod):
+    """One eye's output rows split over GPUs: the chain of a band -- the same Normalize with its
+    centre moved up by r0 rows -- gives rows r0 .. r1 - 1 of the full map bit for bit (product lowering + the
+    product's per-pixel code compiled for the host; literal interpreter and fused ray path)."""
+    sys.path.insert(0, str(ROOT))
+    import ctypes as C
+
+    import chainspecs as CS
+    from test_host_emul import emul_map
+    from vr180_convert_amd.chain import lower_for_get_map
+
+    O = oracle_mod
+    spec = [("equirect_enc", True), ("rot", CS.ry(0.3)), ("poly", [0, 1, -0.1]), CS.EQUI]
+    t = CS.to_product(spec)
+    W, H, r0, r1 = 96, 80, 32, 64
+    full = O.Chain.from_buffer_copy(bytes(lower_for_get_map(t, radius=41.5, size_input=(90, 100), size_output=(W, H))))
+    band = O.Chain.from_buffer_copy(bytes(lower_for_get_map(t, radius=41.5, size_input=(90, 100), size_output=(W, H), row_band=(r0, r1))))
+    for mode in (0, 1):
+        rc, fx, fy, _ = emul_map(emul_lib, full, W, H, mode)
+        rc2, bx, by, _ = emul_map(emul_lib, band, W, r1 - r0, mode)
+        assert rc == 0 and rc2 == 0
+        assert np.array_equal(bx.view(np.uint32), fx[r0:r1].view(np.uint32)) and np.array_equal(by.view(np.uint32), fy[r0:r1].view(np.uint32))
+    with pytest.raises(ValueError):
+        lower_for_get_map(t, radius=41.5, size_input=(90, 100), size_output=(W, H), row_band=(64, 96))

@@ -491,14 +491,25 @@ class Euclidean3DRotator(Euclidean3DTransformer):
 
 
 def lower_for_get_map(transformer: TransformerBase, *, radius: float, size_input: tuple[int, int],
-                      size_output: tuple[int, int]) -> _abi.Chain:
+                      size_output: tuple[int, int], row_band: tuple[int, int] | None = None) -> _abi.Chain:
     """The chain get_map() evaluates (remapper.py:50-57):
     ``NormalizeTransformer() * transformer * DenormalizeTransformer((r, r), (W_in // 2, H_in // 2))``
     lowered for an output grid of ``size_output`` = (W, H); ``size_input`` = (H_in, W_in).
+    ``row_band`` = (r0, r1): the chain of output rows r0 .. r1 - 1 only, as a grid of its own (one eye's rows split
+    over several GPUs): the same Normalize with its centre moved up by r0 rows -- row j' of the band
+    gets ((j' + r0) - H / 2) / s * 2 from the exactly representable difference (j' - (H / 2 - r0)), i.e. the very
+    numbers of row j' + r0 of the full grid.
     Raises :class:`NotLowerable` when a stage has no op form or the chain is too long."""
-    out_shape = (size_output[1], size_output[0])
+    w, h = size_output
+    if row_band is None:
+        norm, out_shape = NormalizeTransformer(), (h, w)
+    else:
+        r0, r1 = row_band
+        if not 0 <= r0 < r1 <= h:
+            raise ValueError("row_band outside the output grid")
+        norm, out_shape = NormalizeTransformer(center=(w / 2, h / 2 - r0), scale=min(w, h)), (r1 - r0, w)
     full = (
-        NormalizeTransformer()
+        norm
         * transformer
         * DenormalizeTransformer(scale=(radius, radius), center=(size_input[1] // 2, size_input[0] // 2))
     )

@@ -7,7 +7,9 @@ Every (frame, eye) is an independent unit; the reference loops over them seriall
 * ``shard_range`` / ``plan_shards`` -- the partition.  With at least as many frames as ranks every
   rank takes a contiguous, balanced block of FRAMES (both eyes of a frame end up in one side-by-side
   buffer, so they stay together); with fewer frames than ranks -- a single L+R pair on 2 GPUs -- the
-  EYES are dealt, one eye per GPU.  The partition needs no communication: every rank computes it.
+  EYES are dealt, one eye per GPU; with more ranks than eyes (a single pair on 4 / 8 GPUs) ``plan_band_shards``
+  cuts every eye's output rows into bands (a band = an ordinary plan of a chain whose Normalize centre is moved,
+  ``chain.lower_for_get_map(row_band=...)``).  The partition needs no communication: every rank computes it.
 * ``build_rank_job`` -- host logic of one rank's share: lowered chains, plan groups and the marshalled
   ``v1c_unit`` records (pointers / pitches into the rank's source views and SBS halves).  No device
   is involved, so the multi-rank CPU tests (gloo, tests/test_sharding_gloo.py) run exactly this code.
@@ -69,6 +71,32 @@ def plan_shards(n_frames: int, world: int) -> list[Shard]:
             units = tuple(flat[i] for i in shard_range(len(flat), r, min(world, max(len(flat), 1)))) if r < len(flat) else ()
         shards.append(Shard(r, world, units))
     return shards
+
+
+def row_bands(height: int, n: int, align: int = 16) -> list[tuple[int, int]]:
+    """``n`` bands of output rows covering ``range(height)``, balanced, cut on multiples of ``align`` (the kernels'
+    tile height) where the height allows; fewer than ``n`` when there are not enough rows."""
+    if height <= 0 or n < 1:
+        raise ValueError("bad band arguments")
+    blocks = -(-height // align)
+    n = min(n, blocks)
+    cuts = [min(height, align * (blocks * k // n)) for k in range(n + 1)]
+    return [(cuts[k], cuts[k + 1]) for k in range(n) if cuts[k + 1] > cuts[k]]
+
+
+def plan_band_shards(n_frames: int, world: int, out_height: int) -> list[list[tuple[int, int, int, int]]]:
+    """More ranks than eyes (a single pair on 4 or 8 GPUs): every eye's output ROWS are split into
+    ``world // (2 * n_frames)`` bands and rank r gets the r-th ``(frame, eye, row0, row1)`` of the list ordered by
+    frame, eye, band; surplus ranks get nothing.  Each rank needs the whole source eye of its band; nothing is
+    exchanged between GPUs."""
+    if n_frames < 1 or world < 1:
+        raise ValueError("bad shard arguments")
+    per_eye = max(1, world // (2 * n_frames))
+    units = [(f, e, r0, r1) for f in range(n_frames) for e in (0, 1) for (r0, r1) in row_bands(out_height, per_eye)]
+    out: list[list[tuple[int, int, int, int]]] = [[] for _ in range(world)]
+    for k, u in enumerate(units):
+        out[k % world].append(u)
+    return out
 
 
 def split_sbs(frame: Any):
@@ -200,8 +228,12 @@ def remap_sharded(transformer: Any, frames: Sequence[Any], *, size_output: tuple
     cn = eyes[0][0].shape[2]
     radii = [R.get_radius_smart(radius, list(e)) if not isinstance(transformer, tuple) else None for e in eyes]
     outs = [np.empty((h, 2 * w, cn), np.uint8) for _ in range(n)]
-    shards = [s for s in plan_shards(n, len(devs)) if s.units]
     errors: list[BaseException] = []
+    if len(devs) >= 4 * n and not isinstance(transformer, tuple) and rotations is None:
+        # more devices than eyes: split every eye's output rows into bands (plan_band_shards)
+        return _remap_banded(transformer, eyes, radii, outs, devs, size_output=size_output, interpolation=interpolation,
+                             boarder_mode=boarder_mode, boarder_value=boarder_value)
+    shards = [s for s in plan_shards(n, len(devs)) if s.units]
 
     def worker(shard: Shard, dev_index: int) -> None:
         try:
@@ -232,6 +264,51 @@ def remap_sharded(transformer: Any, frames: Sequence[Any], *, size_output: tuple
             errors.append(ex)
 
     threads = [threading.Thread(target=worker, args=(s, devs[s.rank]), name=f"v1c-dev{devs[s.rank]}") for s in shards]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return outs
+
+
+def _remap_banded(transformer, eyes, radii, outs, devs, *, size_output, interpolation, boarder_mode, boarder_value):
+    """Worker per device, each remapping bands of output rows of whole source eyes it uploads itself."""
+    import torch
+
+    from . import remapper as R
+    from .chain import lower_for_get_map
+
+    w, h = size_output
+    cn = eyes[0][0].shape[2]
+    work = plan_band_shards(len(eyes), len(devs), h)
+    errors: list[BaseException] = []
+
+    def worker(units, dev_index):
+        try:
+            dev = torch.device("cuda", dev_index)
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                uploaded: dict = {}
+                for f, e, r0, r1 in units:
+                    im = eyes[f][e]
+                    if (f, e) not in uploaded:
+                        uploaded[(f, e)] = R._to_device(im, dev)
+                    src = uploaded[(f, e)]
+                    chain = lower_for_get_map(transformer, radius=radii[f], size_input=(int(eyes[f][0].shape[0]), int(eyes[f][0].shape[1])),
+                                              size_output=size_output, row_band=(r0, r1))
+                    plan = R._plan_for(chain, src_hw=(int(im.shape[0]), int(im.shape[1])), dst_wh=(w, r1 - r0), cn=cn,
+                                       interpolation=interpolation, border_mode=boarder_mode, border_value=boarder_value, device=dev)
+                    dst = torch.empty((r1 - r0, w, cn), dtype=torch.uint8, device=dev)
+                    if boarder_mode == 5:  # BORDER_TRANSPARENT: skipped pixels must be deterministic
+                        dst.zero_()
+                    plan.run([src], [dst])
+                    np.copyto(outs[f][r0:r1, e * w:(e + 1) * w], dst.cpu().numpy())
+        except BaseException as ex:  # noqa: BLE001 - re-raised in the calling thread
+            errors.append(ex)
+
+    threads = [threading.Thread(target=worker, args=(u, devs[k]), name=f"v1c-band-dev{devs[k]}") for k, u in enumerate(work) if u]
     for t in threads:
         t.start()
     for t in threads:
