@@ -235,7 +235,7 @@ def _pmc_pass(counter: str, workload: str, timeout_s: float):
         env.pop(k, None)
     cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
            str(Path(__file__).resolve()), "--workload", workload, "--steps", str(PMC_STEPS), "--warmup", str(PMC_WARMUP), "--no-cpu-baseline",
-           "--traffic", "none", "--no-cold-extra"]
+           "--traffic", "none", "--no-cold-extra", "--no-condition"]
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
         try:
@@ -313,6 +313,8 @@ def main() -> None:
                          "profiles/traffic_latest.json, or omitted")
     ap.add_argument("--no-cold-extra", action="store_true", help="skip the 8192x8192 Lanczos4 cold-call measurement")
     ap.add_argument("--no-rotate", action="store_true", help="A/B only: replay ONE buffer set (L3-warm for small workloads)")
+    ap.add_argument("--no-condition", action="store_true",
+                    help="skip the 0.5 s clock / launch-queue conditioning (the --pmc child passes: counters do not depend on clocks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -416,7 +418,7 @@ def main() -> None:
     torch.cuda.synchronize(dev)
     t_cond = time.perf_counter()
     n_cond, burst = 0, 256
-    while True:
+    while not args.no_condition:
         for _ in range(burst):
             step(n_cond)
             n_cond += 1

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 WL=$1; L=$2; shift 2
 D=$(mktemp -d /tmp/pmc.XXXX)
-V1C_LIB=$L rocprofv3 --pmc "$@" --output-format csv -d $D -o p -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --steps 3 --warmup 1 --workload $WL > /dev/null 2>&1
+V1C_LIB=$L rocprofv3 --pmc "$@" --output-format csv -d $D -o p -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --steps 3 --warmup 1 --no-condition --workload $WL > /dev/null 2>&1
 f=$(find $D -name '*counter_collection.csv' | head -1)
 python3 - "$f" "$L" <<'PY'
 import csv, sys, collections

@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 find $OUT/trace -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 find $OUT/trace -name '*kernel_trace.csv' | head -1 | xargs -I{} sh -c 'head -1 {} > '$OUT'/kernel_trace_head.csv; grep -E "k_ray|k_remap|k_tile" {} | head -100 >> '$OUT'/kernel_trace_head.csv'
 for k in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $k --output-format csv -d $OUT/pmc_$k -o pmc -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --steps 5 --warmup 2 "$@" > $OUT/bench_pmc_$k.log 2>&1
+  rocprofv3 --pmc $k --output-format csv -d $OUT/pmc_$k -o pmc -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --no-condition --steps 5 --warmup 2 "$@" > $OUT/bench_pmc_$k.log 2>&1
   f=$(find $OUT/pmc_$k -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && { head -1 "$f" > $OUT/pmc_$k.csv; grep -E "k_ray|k_remap" "$f" | head -40 >> $OUT/pmc_$k.csv; }
   rm -rf $OUT/pmc_$k
