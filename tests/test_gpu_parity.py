@@ -787,7 +787,8 @@ def test_kernel_variants_bit_exact(env):
 
     # the switches exist only in the -DV1C_TUNING build of the same sources (csrc/Makefile `tuning`)
     tuning = _native.LIB_PATH.with_name("libvr180remap_tuning.so")
-    assert tuning.exists(), "build it: make -C vr180_convert_amd/csrc tuning (or __graft_entry__.build())"
+    if not tuning.exists():  # normally built by __graft_entry__.build() and shipped with the snapshot
+        subprocess.run(["make", "-C", str(tuning.parent), "-j4", "tuning"], check=True, capture_output=True, timeout=900)
     probe = Path(__file__).with_name("variant_probe.py")
     r = subprocess.run([sys.executable, str(probe)], env={**os.environ, **env, "V1C_LIB": str(tuning)}, capture_output=True, text=True,
                        timeout=600)
