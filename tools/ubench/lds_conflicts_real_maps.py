@@ -1,10 +1,13 @@
 """CPU model of the LDS bank conflicts of the bilinear pair tap gather (ds_read2_b64 on 8-byte cells) on the real C2 / C1 maps:
 lane -> pixel mapping A (kernel: 16 lanes x 4 rows per wave) vs G (16-lane groups of 4 lane columns x 4 rows) and the box pitch."""
 import sys
+from pathlib import Path
+
 import numpy as np
-sys.path.insert(0, '.')
-from oracle import oracle as O
-O.set_threads(8)
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import vr180_convert_amd as V  # noqa: E402  (the maps come from the engine's own get_map: run on the GPU box)
+from vr180_convert_amd import transformer as T  # noqa: E402
 
 def conflicts(ix, iy, x0, y0, pitch, mapping):
     """ix, iy: (16 rows, 64 px) source integer coords of one tile; returns LDS cycles for all ds_read2_b64 of the tile (ideal: 8 per instr)"""
@@ -29,8 +32,8 @@ def conflicts(ix, iy, x0, y0, pitch, mapping):
                 n += 2
     return total, n
 
-def run(name, spec, size, radius):
-    xm, ym = O.get_map(spec, radius=radius, size_input=(size, size), size_output=(size, size))
+def run(name, chain, size, radius):
+    xm, ym = V.get_map(chain, radius=radius, size_input=(size, size), size_output=(size, size))
     sx = np.rint(xm.astype(np.float64) * 32).astype(np.int64); sy = np.rint(ym.astype(np.float64) * 32).astype(np.int64)
     ix, iy = sx >> 5, sy >> 5
     res = {}
@@ -47,6 +50,6 @@ def run(name, spec, size, radius):
             t, n = conflicts(bx, by, x0, y0, pitch, mapping)
             tot += t; cnt += n
         res[(mapping, podd)] = tot / cnt
-        print(f'{name}: mapping {mapping} pitch 4cpr+{4+podd}: {tot / cnt:.2f} LDS cycles per ds_read2_b64 (conflict-free: 8)')
-run('C2', [("equirect_enc", True), ("poly", [0, 1, -0.1]), ("fisheye_dec", "equidistant")], 4096, 2048.0)
-run('C1', [("equirect_enc", True), ("fisheye_dec", "equidistant")], 2048, 1024.0)
+        print(f'{name}: mapping {mapping} pitch 4cpr+{4+podd}: {2 * tot / cnt:.2f} LDS cycles per ds_read2_b64 (conflict-free: 8)')
+run('C2', T.EquirectangularEncoder() * T.PolynomialScaler([0, 1, -0.1]) * T.FisheyeDecoder("equidistant"), 4096, 2048.0)
+run('C1', T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant"), 2048, 1024.0)
