@@ -24,7 +24,7 @@ from . import _abi, _io
 from . import quat as _quat
 from . import transformer as _T
 from .calibration import calibration_rotators, match_lr, rotation_match, rotation_match_robust
-from .chain import MultiTransformer, TransformerBase
+from .chain import MultiTransformer
 
 LOG = logging.getLogger(__name__)
 DEFAULT_EXTENSION = "png"  # cli.py:39
