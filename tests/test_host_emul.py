@@ -66,6 +66,26 @@ def test_ray_path_full_size_sha(emul_lib, oracle_mod, golden_dir, name):
     assert hashlib.sha256(CS.buckets(ym).tobytes()).digest() == g[f"{name}__sha_by"].tobytes()
 
 
+@pytest.mark.parametrize("name,mode", [("C1", 1), ("C2", 1), ("C2", 0)])
+def test_rows_mirror_about_the_equator(emul_lib, oracle_mod, name, mode):
+    """The premise of k_ray_lin3_pair_mirror (kernels_tile.hip): for an unrotated equirectangular chain output rows j and
+    H - j differ only in the sign of sin(lat) -- the x coordinates are the SAME float32 bits and y mirrors about the source
+    centre (y' - c_y == -(y - c_y) up to the rounding of one fma).  Checked on the product's per-pixel code compiled for
+    the host, at the full BASELINE sizes, fused ray path (and the literal interpreter for C2)."""
+    spec, out, inp, radius = CS.FULL_CASES[name]
+    ch = oracle_mod.chain_from_spec(spec, radius=radius, size_input=inp, size_output=out)
+    W, H = out
+    rc, xm, ym, _ = emul_map(emul_lib, ch, W, H, mode)
+    assert rc == 0
+    top, bottom = slice(1, H // 2), slice(H - 1, H // 2, -1)  # rows 1 .. H/2 - 1 and their mirror images H - 1 .. H/2 + 1
+    if mode == 1:
+        assert np.array_equal(xm[top].view(np.uint32), xm[bottom].view(np.uint32))
+    else:  # the literal chain goes through sqrt / atan2 / cos / sin per stage: equal to the last float32 bit or two
+        assert np.max(np.abs(xm[top] - xm[bottom])) <= 2 * np.spacing(np.float32(W))
+    cy = inp[0] // 2
+    assert np.max(np.abs((ym[bottom].astype(np.float64) - cy) + (ym[top].astype(np.float64) - cy))) <= np.spacing(np.float32(H))
+
+
 def test_per_unit_rotation_override(emul_lib, oracle_mod, golden_dir):
     """BASELINE config 5: one plan, the rotation arrives per unit."""
     g = np.load(golden_dir / "maps_c5.npz")
