@@ -415,7 +415,10 @@ def main() -> None:
     # its launch queue first gets ~60 packets deep.  So the workload's own launch is replayed, untimed, for 0.5 s
     # (first one burst of 256 launches, then bursts of 64) -- the state a stream of frames runs in.  Nothing of it is
     # measured; the timed region below is exactly K steps after the W warm-up steps.
+    # (ranks are aligned first: input synthesis and plan creation take different times on different ranks, and a rank
+    # that waited idle at the barrier in front of the timed region would enter it with its clocks down again)
     torch.cuda.synchronize(dev)
+    barrier()
     t_cond = time.perf_counter()
     n_cond, burst = 0, 256
     while not args.no_condition:
