@@ -114,6 +114,10 @@ struct ChunkMagicLut {
 };
 __device__ const ChunkMagicLut kChunkMagic{};
 
+#ifndef V1C_KXK_OWN_LANES
+#define V1C_KXK_OWN_LANES 0  // 1: bicubic / Lanczos4 pairs gather in the coordinates' lane -> pixel mapping (A/B builds)
+#endif
+constexpr int kKxkExchangeBytes = 4096;  // K x K pair path: 4 waves x (4 rows x 64 columns) dwords behind the box buffers
 constexpr int kTabSlice = 64;  // radial-table entries a workgroup may keep in LDS (4 KB)
 
 // Tiles the lean batch kernel takes (k_ray_lin3_batch_lean), as far as the plan can tell: interior, table
@@ -1196,23 +1200,75 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
             patch_and_store<K>(c, ua, z0 + 1, t, L, pix, L.inside, ua.u[z0 + 1].src);
             return;
         }
-        if (K != 2 && nu == 2 && fit0 && fit1) {
+        if constexpr (K != 2) {
+        if (nu == 2 && fit0 && fit1) {
             // K x K taps of both eyes against one fetch of the weight row
             constexpr int off = K / 2 - 1;
             const int lpw = b.cpr * 4 + 4;
             uint32_t pa[kPX], pb[kPX];
+            if (kLanesX == 16 && !V1C_KXK_OWN_LANES) {
+                // The gather runs in ANOTHER lane -> pixel mapping than the coordinates and the stores: slot k of lane l
+                // samples column 16 k + (l & 15) of the lane's tile row, so that the 16 lanes LDS serves together read
+                // ADJACENT cells (with 4 adjacent pixels per lane they read every 4th cell: 4-way bank conflicts at best;
+                // the Lanczos4 pair had its LDS 67 % busy, 59 % of that conflicts -- tools/ubench/lanczos_pair_forms.hip:
+                // sampler alone 1.29 - 1.93 -> 0.96 - 1.29 ms at C4's size).  Tap origin and weight entry travel as one
+                // dword through a wave-private KB of LDS behind the boxes, the two result pixels come back the same way
+                // (a wave's LDS operations execute in order: no barrier, only compiler fences).
+                const int lane = tid & 63;
+                uint32_t* xw = boxw + 2 * half_dwords + (tid >> 6) * 256;  // [row of the wave][column of the tile]
+                u128 own;
+                uint32_t pk[kPX];
 #pragma unroll
-            for (int k = 0; k < kPX; k++) {
-                const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-                const bool in = (L.inside >> k) & 1;
-                const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
-                const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
-                const uint64_t pp = blend_table_pair<K>((lds_cell_ptr)boxw, lo, lpw, wtab + a * (K * K / 2));
-                pa[k] = (uint32_t)pp, pb[k] = (uint32_t)(pp >> 32);
+                for (int k = 0; k < kPX; k++) {
+                    const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+                    const bool in = (L.inside >> k) & 1;
+                    const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;  // < 2^14 cells
+                    pk[k] = (lo << 10) | (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
+                }
+                own.x = pk[0], own.y = pk[1], own.z = pk[2], own.w = pk[3];
+                ((u128*)xw)[lane] = own;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint32_t* col = xw + (lane >> 4) * 64 + (lane & 15);
+                uint32_t gk[kPX];
+#pragma unroll
+                for (int k = 0; k < kPX; k++)
+                    gk[k] = col[16 * k];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // (requesting the weight row of slot k + 1 before slot k is blended -- 32 more VGPRs, the blend inlined in a
+                // rolled loop -- measured 5 % SLOWER on C4 than these four calls)
+#pragma unroll
+                for (int k = 0; k < kPX; k++) {
+                    const uint64_t pp = blend_table_pair<K>((lds_cell_ptr)boxw, gk[k] >> 10, lpw, wtab + (gk[k] & 1023u) * (K * K / 2));
+                    pa[k] = (uint32_t)pp, gk[k] = (uint32_t)(pp >> 32);
+                }
+#pragma unroll
+                for (int k = 0; k < kPX; k++)
+                    col[16 * k] = pa[k];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                own = ((const u128*)xw)[lane];
+                pa[0] = own.x, pa[1] = own.y, pa[2] = own.z, pa[3] = own.w;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int k = 0; k < kPX; k++)
+                    col[16 * k] = gk[k];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                own = ((const u128*)xw)[lane];
+                pb[0] = own.x, pb[1] = own.y, pb[2] = own.z, pb[3] = own.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < kPX; k++) {
+                    const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+                    const bool in = (L.inside >> k) & 1;
+                    const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
+                    const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
+                    const uint64_t pp = blend_table_pair<K>((lds_cell_ptr)boxw, lo, lpw, wtab + a * (K * K / 2));
+                    pa[k] = (uint32_t)pp, pb[k] = (uint32_t)(pp >> 32);
+                }
             }
             patch_and_store<K>(c, ua, z0, t, L, pa, L.inside, ua.u[z0].src);
             patch_and_store<K>(c, ua, z0 + 1, t, L, pb, L.inside, ua.u[z0 + 1].src);
             return;
+        }
         }
         sample_and_store<K>(c, ua, z0, t, L, b, fit0, boxw, wtab, ua.u[z0].src, (uint32_t)ua.u[z0].src_pitch);
         if (nu == 2)
@@ -1799,7 +1855,12 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     // workgroup anyway) "the m-polynomial table serves every pixel of every unit" (bilinear, OWN = 0)
     const bool pair = bx ? upb <= 2 : (K == 2 && shared_entry && mpoly_all && c.ray.radial_m != nullptr);
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
-    const size_t lds = bx ? (size_t)half_dwords * 8 + 16 : 0;  // two box buffers
+    static const size_t lds_pad = [] {  // V1C_LDS_PAD=<bytes>: occupancy experiments (fewer workgroups per CU)
+        const char* e = tuning_env("V1C_LDS_PAD");
+        return e ? (size_t)std::atoi(e) : (size_t)0;
+    }();
+    // two box buffers (+ the K x K pair path's exchange buffer: 1 KB per wave, see shared_map_tile)
+    const size_t lds = bx ? (size_t)half_dwords * 8 + 16 + (K != 2 && pair ? kKxkExchangeBytes : 0) + lds_pad : 0;
     // batches (more than two units per workgroup) of a bilinear plan: the interior tiles go to the lean
     // kernel, everything else stays with the general one (same grid; each skips the other's tiles)
     static const bool lean_off = [] {
