@@ -50,6 +50,9 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_PAIR_WAVES
 #define V1C_PAIR_WAVES 6  // waves per SIMD the pair kernel (bilinear, no rotation, OWN = 0) is compiled for
 #endif
+#ifndef V1C_NOBOX_WAVES
+#define V1C_NOBOX_WAVES 1  // waves per SIMD the bilinear kernel without plan-time boxes (per-unit rotations) is compiled for
+#endif
 #ifndef V1C_LEAN_WAVES
 #define V1C_LEAN_WAVES 6  // waves per SIMD the lean batch kernel is compiled for (no rotation, OWN = 0)
 #endif
@@ -1334,7 +1337,7 @@ template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR, int LIST = 0>
 // LIST = 1 (BOXES = 1): blockIdx.x indexes `tile_list` (ty << 16 | tx) instead of the tile grid;
 // `tiles_x` = tile columns of the full grid then.  (A template switch rather than a null test: the
 // test split the kernel-argument loads of the prologue over two more dependent waits.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && PAIR && K == 2 && !ROT && !OWN) ? V1C_PAIR_WAVES : 1, 8))) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && PAIR && K == 2 && !ROT && !OWN) ? V1C_PAIR_WAVES : (!BOXES && K == 2) ? V1C_NOBOX_WAVES : 1, 8))) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
                                                        int upb, int half_dwords, unsigned tiles_x_magic,
                                                        const uint32_t* __restrict__ tile_list, int tiles_x, unsigned strip_len,
                                                        unsigned strip_magic)
