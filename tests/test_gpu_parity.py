@@ -772,7 +772,7 @@ def test_batch_plan_run_is_graph_capturable(V, oracle_mod, dev):
 
 @pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_DISABLE_MPOLY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"},
                                  {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_LEAN": "1"}, {"V1C_DISABLE_MERGE": "1"}, {"V1C_XCD_STRIPS": "2"},
-                                 {"V1C_DISABLE_MIRROR": "1"}, {}],
+                                 {"V1C_DISABLE_MIRROR": "1"}, {"V1C_MIRROR_RAW": "0"}, {"V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_RAW": "7"}, {}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_variants_bit_exact(env):
     """The instantiations the default configuration does not reach (per-pixel table fallback,
@@ -1060,9 +1060,10 @@ def test_remap_sharded_on_the_devices_there_are(V, oracle_mod):
     ((257, 263), (128, 100), 120.0),    # 100 rows: no mirror launch (not a multiple of 32), plain pair kernel
 ])
 def test_mirror_pair_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radius):
-    """apply_lr pairs of unrotated bilinear chains take k_ray_lin3_pair_mirror (a tile and its mirror image about
-    the equator from one set of coordinates; tile rows 0, H/32 and the last one plus ineligible tiles through the
-    pair code in the same launch): every output byte against the oracle, m-table and w-table chains."""
+    """apply_lr pairs of unrotated bilinear chains take k_ray_lin3_pair_mirror_raw (a tile and its mirror image about
+    the equator from one set of coordinates, boxes by LDS-DMA; tile rows 0, H/32 and the last one plus ineligible tiles
+    through the pair code in the same launch): every output byte against the oracle, m-table and w-table chains.
+    (The register-staged k_ray_lin3_pair_mirror and other box-buffer sizes: test_kernel_variants_bit_exact.)"""
     from vr180_convert_amd.synth import noise_disc
 
     O = oracle_mod

@@ -47,10 +47,13 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry,
 // apply_lr pairs of unrotated chains: a tile and its mirror image about the equator from one set of coordinates
 // (k_ray_lin3_pair_mirror); `host_mboxes` = boxes of the mirrored bands (launch_tile_boxes with mirror_h).
 // tile_mirror_rest: the tiles (ty << 16 | tx) that launch leaves to the pair kernel; false: no mirror launch for this plan
+// `raw_nwp` > 0: for k_ray_lin3_pair_mirror_raw (boxes by LDS-DMA, packed BGR in LDS, box buffers of raw_nwp KB:
+// tile_mirror_raw_passes) instead of k_ray_lin3_pair_mirror
 bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
-                      std::vector<uint32_t>& rest);
+                      std::vector<uint32_t>& rest, int raw_nwp);
+int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, const Geom& g);
 hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
-                                       int mirror_h, const uint32_t* rest_list, int n_rest, hipStream_t stream);
+                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, hipStream_t stream);
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,

@@ -53,6 +53,9 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_NOBOX_WAVES
 #define V1C_NOBOX_WAVES 1  // waves per SIMD the bilinear kernel without plan-time boxes (per-unit rotations) is compiled for
 #endif
+#ifndef V1C_RAW_WAVES
+#define V1C_RAW_WAVES 5  // waves per SIMD k_ray_lin3_pair_mirror_raw is compiled for
+#endif
 #ifndef V1C_LEAN_WAVES
 #define V1C_LEAN_WAVES 6  // waves per SIMD the lean batch kernel is compiled for (no rotation, OWN = 0)
 #endif
@@ -1500,6 +1503,25 @@ __host__ __device__ inline bool mirror_static_ok(const TileBox& b, const TileBox
            mirror_box_ok(q.x0, q.y0, q.cpr, q.nrows, half_dwords, src_h, src_w);
 }
 
+// ... and for k_ray_lin3_pair_mirror_raw: the box as it is in memory, rows of `upr` 16-byte units (LDS-DMA, 16 B per lane);
+// a box buffer holds `nwp` wave-passes of 64 units (the plan sizes it: tile_mirror_raw_passes); the last unit of a row
+// reads up to 12 bytes past the box (never past the image)
+constexpr int kRawMaxWavePasses = 16;  // 16 KB per box and eye
+__host__ __device__ inline int raw_units_per_row(int cpr)
+{
+    return (3 * cpr + 3) >> 2;
+}
+__host__ __device__ inline bool raw_box_ok(int x0, int y0, int cpr, int nrows, int nwp, int src_h, int src_w)
+{
+    const int upr = raw_units_per_row(cpr);
+    return cpr > 0 && cpr <= kMaxCpr && nrows * upr <= nwp * 64 && !((y0 + nrows >= src_h) && (x0 * 3 + upr * 16 > src_w * 3));
+}
+__host__ __device__ inline bool mirror_raw_static_ok(const TileBox& b, const TileBox& q, int nwp, int src_h, int src_w)
+{
+    return b.interior != 0 && q.interior == b.interior && b.nidx > 0 && b.nidx <= kTabSlice && q.idx0 == b.idx0 && q.nidx == b.nidx &&
+           raw_box_ok(b.x0, b.y0, b.cpr, b.nrows, nwp, src_h, src_w) && raw_box_ok(q.x0, q.y0, q.cpr, q.nrows, nwp, src_h, src_w);
+}
+
 __device__ __forceinline__ TileBox load_tile_box(const TileBox* __restrict__ boxes, int tile)
 {
     const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(tile));
@@ -1603,6 +1625,160 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     sample_pair_cells(ua, t, mirror_h - t.j, q, dyn_box, L.sx, L.sy2);
 }
 
+// ---- the same workgroup with the boxes brought in by LDS-DMA, as they are in memory ----
+// global_load_lds_dwordx4 copies 16 bytes per lane from any dword-aligned address straight into LDS (lane-linear: unit
+// u = pass * 256 + tid at byte 16 u), so nothing of a box ever sits in a VGPR: all four boxes of the workgroup (two
+// eyes x tile and mirrored band) and the table slice are requested in the prologue and the coordinates are evaluated
+// WHILE they are in flight (with register staging that overlap costs the staging registers' occupancy: DESIGN 4.4).
+// The box stays packed BGR (row pitch upr x 16 bytes); a tap pair (6 bytes at byte 3 ix) is cut out of three dwords
+// read at the dword below it (ds_read2_b32 + ds_read_b32: b64 / b96 reads that are not naturally aligned are
+// microcoded, 64 cycles) with two v_alignbyte_b32, then blended as the global-memory fallback does (blend3<3>).
+// vmcnt counts loads in issue order, so the waits below are exact: every lane issues every pass (units past the box are
+// clamped to its last unit and land in the unused tail of the box's kRawBoxBytes).
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+// `lds_box`: LDS byte address of the box (wave-uniform); wave w runs pass q iff 4 q + w < nwp (all its lanes: units past the
+// box are clamped to the last one and land in the unused tail of the buffer) -- `my_passes` of them
+__device__ __forceinline__ void raw_box_dma(const TileBox& b, const uint8_t* __restrict__ src, uint32_t spitch, int tid, uint32_t lds_box,
+                                            int my_passes)
+{
+    const int upr = raw_units_per_row(b.cpr);
+    // floor(u / upr) for u < 16 K, upr <= 48 without a division: (u + 0.5) / upr stays 0.5 / 48 away from every integer, fp32's
+    // error here is < 1e-4 (the integer form needs a dependent table read or quarter-rate multiplies)
+    const float rupr = __builtin_amdgcn_rcpf((float)upr);
+    const uint32_t last = (uint32_t)(b.nrows * upr - 1);
+    const uint32_t org = __umul24((uint32_t)b.y0, spitch) + (uint32_t)b.x0 * 3u;
+    const uint32_t wave_off = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
+#pragma unroll
+    for (int q = 0; q < kRawMaxWavePasses / 4; q++) {
+        if (q < my_passes) {  // wave-uniform
+            const uint32_t u = min((uint32_t)(tid + q * 256), last);
+            const uint32_t r = (uint32_t)(((float)u + 0.5f) * rupr), col = u - r * (uint32_t)upr;
+            const uint8_t* gp = src + (org + __umul24(r, spitch) + col * 16u);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_box + (uint32_t)q * 4096u + wave_off), 16, 0, 0);
+        }
+    }
+}
+
+// s_waitcnt vmcnt(n) + s_barrier for a wave-uniform n = 0, 2, 4 ... 16 (the count is an immediate); no fence: see the kernel
+__device__ __forceinline__ void wait_vm_barrier(int n)
+{
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); break;
+    }
+}
+
+// taps of both eyes of a lane's 4 pixels from the raw boxes at LDS byte addresses `raw` (eye 0) and `raw + eye_off` (eye 1)
+__device__ __forceinline__ void gather_pair_raw(const TileBox& b, uint32_t raw, uint32_t eye_off, const int (&sx)[kPX], const int (&sy)[kPX],
+                                                uint32_t (&pix0)[kPX], uint32_t (&pix1)[kPX])
+{
+    const uint32_t pitch = (uint32_t)raw_units_per_row(b.cpr) * 16u;
+    const uint32_t base0 = raw - ((uint32_t)b.y0 * pitch + (uint32_t)b.x0 * 3u);
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        const uint32_t ix = (uint32_t)sx[k] >> 5;
+        const uint32_t a = __umul24((uint32_t)(sy[k] >> 5), pitch) + (ix * 2u + ix) + base0;  // LDS byte address of the pixel
+        const uint32_t d = a & ~3u;
+        const lds_u32_ptr r0 = (lds_u32_ptr)(uintptr_t)d, r1 = (lds_u32_ptr)(uintptr_t)(d + pitch);
+        const lds_u32_ptr s0 = (lds_u32_ptr)(uintptr_t)(d + eye_off), s1 = (lds_u32_ptr)(uintptr_t)(d + pitch + eye_off);
+        const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+        const uint32_t c0 = s0[0], c1 = s0[1], c2 = s0[2], e0 = s1[0], e1 = s1[1], e2 = s1[2];
+        const BlendW w = blend_weights(sx[k], sy[k]);
+        pix0[k] = blend3<3>(__builtin_amdgcn_alignbyte(a1, a0, a), __builtin_amdgcn_alignbyte(a2, a1, a), __builtin_amdgcn_alignbyte(b1, b0, a),
+                            __builtin_amdgcn_alignbyte(b2, b1, a), w);
+        pix1[k] = blend3<3>(__builtin_amdgcn_alignbyte(c1, c0, a), __builtin_amdgcn_alignbyte(c2, c1, a), __builtin_amdgcn_alignbyte(e1, e0, a),
+                            __builtin_amdgcn_alignbyte(e2, e1, a), w);
+    }
+}
+
+__device__ __forceinline__ void store_pair_row(const UnitArgs& ua, const TileIds& t, int j, const uint32_t (&pix0)[kPX], const uint32_t (&pix1)[kPX])
+{
+    const uint32_t row_off = (uint32_t)t.x0 * 3u;
+    store4(ua.u[0].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[0].dst_pitch) + row_off), pix0, 0xFu, dst_rows_dword_aligned(ua, 0));
+    store4(ua.u[1].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix1, 0xFu, dst_rows_dword_aligned(ua, 1));
+}
+
+template <int VAR_W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAVES, 8))) void k_ray_lin3_pair_mirror_raw(
+    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
+    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp)
+{
+    constexpr int NT = 256;
+    __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 4 raw boxes (or the general code's cell buffers)
+    const int tid = threadIdx.x;
+    if (blockIdx.z == 0) {  // the tiles this path leaves out, through the general pair code
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= (unsigned)n_rest)
+            return;
+        const uint32_t v = rest_list[lin];
+        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
+                                                  tabw, (glb_u32_ptr)c.itab);
+        return;
+    }
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    int tx, ty;
+    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+    ty += 1;
+    const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
+    // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
+    RowCol rc;
+    load_rowcol<0>(P, t.xc, t.jc, rc);
+    const uint8_t* __restrict__ src0 = ua.u[0].src;
+    const uint8_t* __restrict__ src1 = ua.u[1].src;
+    const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[1].src_pitch;
+    const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
+    if (!mirror_raw_static_ok(b, q, nwp, g.src_h, g.src_w))
+        return;
+    const bool mpoly = (b.interior & 2) != 0;
+    // (the row / column values are consumed here: the compiler's own wait for them then sits in front of the DMA requests,
+    // not -- as vmcnt(0), it does not count LDS-DMA -- in front of the coordinates)
+#pragma unroll
+    for (int k = 0; k < kPX; k++)
+        asm volatile("" ::"v"(rc.slon[k]), "v"(rc.qlon[k]));
+    asm volatile("" ::"v"(rc.sl), "v"(rc.cl), "v"(rc.hl));
+    const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
+    const uint32_t box_bytes = (uint32_t)nwp * 1024u;
+    const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + 2u * box_bytes;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np = (nwp - wave + 3) >> 2;  // this wave's passes per box
+    {  // table slice: nidx * 4 units of 16 bytes, one pass (clamped like the boxes)
+        const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
+        const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
+    }
+    raw_box_dma(b, src0, pitch0, tid, raw_b, np);
+    raw_box_dma(b, src1, pitch1, tid, raw_b + box_bytes, np);
+    raw_box_dma(q, src0, pitch0, tid, raw_q, np);
+    raw_box_dma(q, src1, pitch1, tid, raw_q + box_bytes, np);
+    // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
+    // what the barrier publishes -- vmcnt counts in issue order -- then joins.
+    wait_vm_barrier(4 * np);  // table slice landed (this wave's 4 x np box loads may still be in flight)
+    LaneCoords L;
+    if (mpoly)
+        lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+    else
+        lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+    wait_vm_barrier(2 * np);  // the tile's two boxes
+    uint32_t p0[kPX], p1[kPX];
+    gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
+    // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
+    wait_vm_barrier(0);
+    store_pair_row(ua, t, t.j, p0, p1);
+    gather_pair_raw(q, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
+    store_pair_row(ua, t, mirror_h - t.j, p0, p1);
+}
+
 static int taps_of(int interp)
 {
     return interp == V1C_INTER_LINEAR ? 2 : interp == V1C_INTER_CUBIC ? 4 : interp == V1C_INTER_LANCZOS4 ? 8 : 0;
@@ -1635,8 +1811,35 @@ size_t tile_box_bytes(const Geom& g)
 
 // Rest list of the mirror launch; false when the plan cannot use it (geometry, or more remaining tiles than the
 // launch's first grid slice holds).
+// Box buffer size (wave-passes of 64 sixteen-byte units) of k_ray_lin3_pair_mirror_raw for a plan: the smallest that holds the
+// boxes of 98 % of the tile pairs (the others go to the general code with the rest list); 4 boxes of nwp KB each set the
+// workgroups per CU.
+int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, const Geom& g)
+{
+    const TileBox* b = (const TileBox*)host_boxes;
+    const TileBox* q = (const TileBox*)host_mboxes;
+    const dim3 d = tile_grid(g, tile_threads(g), 1);
+    std::vector<int> hist(kRawMaxWavePasses + 2, 0);
+    size_t n = 0;
+    for (unsigned ty = 1; ty < d.y / 2; ty++)
+        for (unsigned tx = 0; tx < d.x; tx++) {
+            const size_t i = (size_t)ty * d.x + tx;
+            if (b[i].cpr <= 0 || q[i].cpr <= 0 || b[i].cpr > kMaxCpr || q[i].cpr > kMaxCpr)
+                continue;
+            const int u = std::max(b[i].nrows * raw_units_per_row(b[i].cpr), q[i].nrows * raw_units_per_row(q[i].cpr));
+            hist[std::min((u + 63) / 64, kRawMaxWavePasses + 1)]++, n++;
+        }
+    size_t acc = 0;
+    for (int k = 0; k <= kRawMaxWavePasses; k++) {
+        acc += hist[k];
+        if (acc * 100 >= n * 98)
+            return std::max(k, 4);
+    }
+    return kRawMaxWavePasses;
+}
+
 bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
-                      std::vector<uint32_t>& rest)
+                      std::vector<uint32_t>& rest, int raw_nwp)
 {
     const TileBox* b = (const TileBox*)host_boxes;
     const TileBox* q = (const TileBox*)host_mboxes;
@@ -1655,7 +1858,7 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
     for (unsigned ty = 1; ty < TYh; ty++)
         for (unsigned tx = 0; tx < d.x; tx++) {
             const size_t i = (size_t)ty * d.x + tx;
-            if (!mirror_static_ok(b[i], q[i], half_dwords, g.src_h, g.src_w))
+            if (raw_nwp > 0 ? !mirror_raw_static_ok(b[i], q[i], raw_nwp, g.src_h, g.src_w) : !mirror_static_ok(b[i], q[i], half_dwords, g.src_h, g.src_w))
                 add(tx, ty), add(tx, TY - 1 - ty), add(tx, TY - ty);
         }
     for (unsigned ty = 0; ty < d.y; ty++)
@@ -1667,15 +1870,24 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
 }
 
 hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
-                                       int mirror_h, const uint32_t* rest_list, int n_rest, hipStream_t stream)
+                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, hipStream_t stream)
 {
     const dim3 full = tile_grid(c.g, 256, 1);
     const dim3 grid(full.x, full.y / 2 - 1, 2), block(256, 1, 1);
-    const size_t lds = (size_t)half_dwords * 8 + 16;
+    const size_t lds = std::max((size_t)half_dwords * 8 + 16, (size_t)4 * 1024 * (size_t)std::max(raw_nwp, 0));
     const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
     const unsigned per = (grid.x * grid.y) >> 3;
     const unsigned slen = 2u * grid.x < per ? 2u * grid.x : 0u;  // two tile rows per strip (tile_xcd_strips)
     const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    if (raw_nwp > 0) {
+        if (c.ray.var_is_w)
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp);
+        else
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp);
+        return hipGetLastError();
+    }
     if (c.ray.var_is_w)
         hipLaunchKernelGGL((k_ray_lin3_pair_mirror<1>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
                            half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic);

@@ -178,6 +178,7 @@ struct v1c_plan {
     void* mirror_boxes = nullptr;
     const uint32_t* mirror_rest = nullptr;
     int n_mirror_rest = 0;
+    int mirror_raw_nwp = 0;  // > 0: the mirror launch brings its boxes in by LDS-DMA (k_ray_lin3_pair_mirror_raw), buffers of so many KB
     int mirror_h = 0;
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     bool disable_shared_entry = false;  // V1C_DISABLE_SHARED_ENTRY=1: keep the per-pixel table fallback compiled in
@@ -496,7 +497,11 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                             return fail(V1C_E_HIP, std::string("mirror boxes: ") + hipGetErrorString(e));
                         }
                         std::vector<uint32_t> mrest;
-                        if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest)) {
+                        // boxes by LDS-DMA (k_ray_lin3_pair_mirror_raw); V1C_MIRROR_RAW=0: the register-staged form, <n> > 1: n KB per box
+                        const char* rawsw = tuning_env("V1C_MIRROR_RAW");
+                        const int rawv = rawsw ? std::atoi(rawsw) : 1;
+                        p->mirror_raw_nwp = rawv == 1 ? tile_mirror_raw_passes(hb.data(), hm.data(), g) : rawv > 1 ? std::min(rawv, 16) : 0;
+                        if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest, p->mirror_raw_nwp)) {
                             if ((rc = upload(p, mrest, &p->mirror_rest))) {
                                 v1c_plan_destroy(p);
                                 return rc;
@@ -504,8 +509,8 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                             p->mirror_boxes = mbx, p->n_mirror_rest = (int)mrest.size(), p->mirror_h = g.dst_h;
                         }
                         if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
-                            std::fprintf(stderr, "[v1c] mirror pair launch: %s, %zu of %zu tiles left to the pair kernel\n",
-                                         p->mirror_boxes ? "yes" : "no", mrest.size(), hb.size() / 32);
+                            std::fprintf(stderr, "[v1c] mirror pair launch: %s, %zu of %zu tiles left to the pair kernel (raw wave-passes %d)\n",
+                                         p->mirror_boxes ? "yes" : "no", mrest.size(), hb.size() / 32, p->mirror_raw_nwp);
                     }
                 }
                 if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1') {
@@ -646,7 +651,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 mirror = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
             if (mirror) {
                 HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h, p->mirror_rest,
-                                                    p->n_mirror_rest, st));
+                                                    p->n_mirror_rest, p->mirror_raw_nwp, st));
             } else if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
