@@ -1312,11 +1312,14 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
 // boxes that do not fit LDS gather from global memory, single-buffered boxes, tiles left to the pair
 // code) and the expensive ones cluster, so one block per XCD left some XCDs with most of them -- the
 // kernel is as slow as its slowest XCD.  `strip_magic` = floor(2^32 / strip_len) + 1.
-__device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, unsigned strip_magic, int& tx, int& ty)
+// `rows`, `row0`: the swizzled part of the grid is rows row0 .. row0 + rows - 1 of workgroups (0: all of gridDim.y); row0 *
+// gridDim.x must be a multiple of 8 (the XCD of a workgroup is its linear id modulo 8)
+__device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, unsigned strip_magic, int& tx, int& ty, unsigned rows = 0,
+                                         unsigned row0 = 0)
 {
-    tx = blockIdx.x, ty = blockIdx.y;
+    tx = blockIdx.x, ty = blockIdx.y - row0;
 #if V1C_XCD_SWIZZLE
-    const unsigned ntile = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned ntile = gridDim.x * (rows ? rows : gridDim.y), lin = (blockIdx.y - row0) * gridDim.x + blockIdx.x;
     const unsigned per = ntile >> 3;  // tiles per XCD; the remainder keeps its natural order
     if (lin < per * 8u) {
         unsigned m = (lin & 7u) * per + (lin >> 3);
@@ -1710,13 +1713,16 @@ __device__ __forceinline__ void store_pair_row(const UnitArgs& ua, const TileIds
 template <int VAR_W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAVES, 8))) void k_ray_lin3_pair_mirror_raw(
     KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
-    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp)
+    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp,
+    unsigned rest_rows)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 4 raw boxes (or the general code's cell buffers)
     const int tid = threadIdx.x;
-    if (blockIdx.z == 0) {  // the tiles this path leaves out, through the general pair code
+    // grid: first `rest_rows` rows of workgroups for the tiles this path leaves out (general pair code: they take longest, so
+    // they are dispatched first -- dispatched last they were a tail: C1 0.0188 -> 0.0245 ms), then the rows of tile pairs
+    if (blockIdx.y < rest_rows) {
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
         if (lin >= (unsigned)n_rest)
             return;
@@ -1728,7 +1734,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const Geom& g = c.g;
     const RayParams& P = c.ray;
     int tx, ty;
-    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
     ty += 1;
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
     // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
@@ -1880,12 +1886,15 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     const unsigned slen = 2u * grid.x < per ? 2u * grid.x : 0u;  // two tile rows per strip (tile_xcd_strips)
     const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
     if (raw_nwp > 0) {
+        // (whole rows, a multiple of 8 of them: the pair rows keep their XCDs)
+        const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
+        const dim3 rgrid(full.x, grid.y + rest_rows, 1);
         if (c.ray.var_is_w)
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp);
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);
         else
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp);
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);
         return hipGetLastError();
     }
     if (c.ray.var_is_w)
