@@ -53,6 +53,9 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_NOBOX_WAVES
 #define V1C_NOBOX_WAVES 1  // waves per SIMD the bilinear kernel without plan-time boxes (per-unit rotations) is compiled for
 #endif
+#ifndef V1C_CHUNK_MAP_FP32
+#define V1C_CHUNK_MAP_FP32 1  // chunk -> (row, column) of the staging map by an fp32 reciprocal (0: integer magic multiply)
+#endif
 #ifndef V1C_RAW_WAVES
 #define V1C_RAW_WAVES 5  // waves per SIMD k_ray_lin3_pair_mirror_raw is compiled for
 #endif
@@ -462,15 +465,25 @@ __device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkM
 {
     const int nchunks = b.nrows * b.cpr;
     const int lpw = b.cpr * 4 + 4;  // LDS row pitch in dwords (+4: rotate the banks from row to row)
+#if V1C_CHUNK_MAP_FP32
+    // floor(ch / cpr) for ch < 16 K, cpr <= 64 in fp32: (ch + 0.5) / cpr stays 0.5 / 64 away from every integer and the
+    // rounding errors are below 1e-3 -- full-rate instructions instead of quarter-rate v_mul_lo_u32
+    const float rcpr = __builtin_amdgcn_rcpf((float)b.cpr);
+#else
     const uint32_t magic = (uint32_t)b.magic;  // exact floor(ch / cpr) for ch < 16k, cpr <= 64
+#endif
     M.valid = 0;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         const uint32_t ch = tid + q * NT;
+#if V1C_CHUNK_MAP_FP32
+        const uint32_t r = (uint32_t)(((float)ch + 0.5f) * rcpr), col = ch - __umul24(r, (uint32_t)b.cpr);
+#else
         const uint32_t r = (ch * magic) >> 20, col = ch - r * b.cpr;
+#endif
         M.row[q] = b.y0 + r;
         M.xbyte[q] = (uint32_t)(b.x0 + 4 * col) * 3u;
-        M.lds_dw[q] = r * lpw + col * 4;
+        M.lds_dw[q] = __umul24(r, (uint32_t)lpw) + col * 4;
         M.valid |= ch < (uint32_t)nchunks ? 1u << q : 0u;
     }
 }
