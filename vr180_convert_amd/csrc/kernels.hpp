@@ -57,10 +57,12 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
-                                int strip_len, hipStream_t stream);
+                                int strip_len, int lean_raw_nwp, hipStream_t stream);
 int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int lean_half);
 int tile_lean_half_dwords(int half_dwords);
-std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int half_dwords);
+// `raw_nwp` > 0: batches through k_ray_lin3_batch_lean_raw (boxes by LDS-DMA, buffers of raw_nwp KB: tile_lean_raw_passes)
+std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int half_dwords, int raw_nwp);
+int tile_lean_raw_passes(const void* host_boxes, const Geom& g);
 
 // merge=True of apply_lr (remapper.py:485-497)
 hipError_t launch_anaglyph(const uint8_t* left, int64_t left_pitch, const uint8_t* right, int64_t right_pitch, int h, int w,

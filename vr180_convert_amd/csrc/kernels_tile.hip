@@ -56,6 +56,10 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_CHUNK_MAP_FP32
 #define V1C_CHUNK_MAP_FP32 1  // chunk -> (row, column) of the staging map by an fp32 reciprocal (0: integer magic multiply)
 #endif
+#ifndef V1C_LEAN_RING
+#define V1C_LEAN_RING 2  // box buffers of k_ray_lin3_batch_lean_raw (2 or 3: the boxes of 1 or 2 units in flight; C3: 0.1807 / 0.1852 ms,
+                         // 7 / 5 workgroups per CU)
+#endif
 #ifndef V1C_RAW_WAVES
 #define V1C_RAW_WAVES 5  // waves per SIMD k_ray_lin3_pair_mirror_raw is compiled for
 #endif
@@ -1677,19 +1681,31 @@ __device__ __forceinline__ void raw_box_dma(const TileBox& b, const uint8_t* __r
     }
 }
 
-// s_waitcnt vmcnt(n) + s_barrier for a wave-uniform n = 0, 2, 4 ... 16 (the count is an immediate); no fence: see the kernel
+// s_waitcnt vmcnt(n) + s_barrier for a wave-uniform n (the count is an immediate); no fence: see the kernels
 __device__ __forceinline__ void wait_vm_barrier(int n)
 {
     switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory"); break;
     case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)\n\ts_barrier" ::: "memory"); break;
     case 14: asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)\n\ts_barrier" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)\n\ts_barrier" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory"); break;
     }
 }
 
@@ -1796,6 +1812,111 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     store_pair_row(ua, t, t.j, p0, p1);
     gather_pair_raw(q, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
     store_pair_row(ua, t, mirror_h - t.j, p0, p1);
+}
+
+// ---- batches (units sharing one map) with the boxes by LDS-DMA: k_ray_lin3_batch_lean's loop on raw boxes ----
+// V1C_LEAN_RING box buffers of nwp KB in a ring: unit u is sampled from its buffer while the boxes of the next ring - 1 units
+// are in flight (requested behind the barrier that tells everyone is done with the unit whose buffer they take): the
+// register-staged loop without its 12 staging registers (74 instead of 80 VGPRs, rotated batches 77 instead of 106), expansion
+// VALU and ds_write_b128; a tap row is 3 dwords at a lane stride of 12 bytes instead of 2 at 16 (9 instead of 14 LDS cycles
+// per wave: tools/ubench/dma_raw_forms.hip, lds_tap_mapping.hip).
+__host__ __device__ inline bool lean_raw_static_ok(const TileBox& b, int nwp, int src_h, int src_w)
+{
+    return b.interior != 0 && b.nidx > 0 && b.nidx <= kTabSlice && raw_box_ok(b.x0, b.y0, b.cpr, b.nrows, nwp, src_h, src_w);
+}
+
+template <int VAR_W, int ROT, int OWN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean_raw(
+    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units, int upb, int half_dwords, unsigned tiles_x_magic,
+    const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp)
+{
+    constexpr int NT = 256;
+    __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
+    const int tid = threadIdx.x;
+    int zl = (int)blockIdx.z;
+    if (rest_list != nullptr)
+        zl -= 1;  // slice 0: the tiles this path leaves out (as in k_ray_lin3_batch_lean)
+    if (zl < 0) {
+        const unsigned pairs = (unsigned)(n_units + 1) / 2u;
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= (unsigned)n_rest * pairs)
+            return;
+        const unsigned ti = lin / pairs, zg = lin - ti * pairs;
+        const uint32_t v = rest_list[ti];
+        shared_map_tile<VAR_W, ROT, 2, OWN, 1, NT, 0>(c, ua, boxes, n_units, 2, (int)zg, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
+                                                      half_dwords, tabw, (glb_u32_ptr)c.itab);
+        return;
+    }
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    int tx, ty;
+    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+    const int z0 = zl * upb;
+    const TileIds t = tile_ids(g, z0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
+    const int nu = min(upb, n_units - z0);
+    RowCol rc;
+    load_rowcol<ROT>(P, t.xc, t.jc, rc);
+    const TileBox b = load_tile_box(boxes, t.box_tile);
+    if (!lean_raw_static_ok(b, nwp, g.src_h, g.src_w))
+        return;
+    const bool mpoly = OWN == 0 && (b.interior & 2) != 0;
+#pragma unroll
+    for (int k = 0; k < kPX; k++)
+        asm volatile("" ::"v"(rc.slon[k]), "v"(rc.qlon[k]));
+    asm volatile("" ::"v"(rc.sl), "v"(rc.cl), "v"(rc.hl));
+    const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
+    const uint32_t box_bytes = (uint32_t)nwp * 1024u;
+    const uint32_t raw0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np = (nwp - wave + 3) >> 2;  // this wave's passes per box
+    {
+        const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
+        const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
+    }
+    constexpr int D = V1C_LEAN_RING - 1;  // prefetch distance (units)
+    raw_box_dma(b, ua.u[z0].src, (uint32_t)ua.u[z0].src_pitch, tid, raw0, np);
+    if (D > 1 && nu > 1)
+        raw_box_dma(b, ua.u[z0 + 1].src, (uint32_t)ua.u[z0 + 1].src_pitch, tid, raw0 + box_bytes, np);
+    wait_vm_barrier(D > 1 && nu > 1 ? 2 * np : np);  // table slice landed
+    const uint32_t pitch = (uint32_t)raw_units_per_row(b.cpr) * 16u;
+    uint32_t ta[kPX];
+    BlendW W[kPX];
+    {
+        LaneCoords L;
+        if (OWN == 0 && mpoly)
+            lane_coords<VAR_W, ROT, 2, 0, 1, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        else
+            lane_coords<VAR_W, ROT, 2, OWN, 1, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const uint32_t ix = (uint32_t)((L.sx[k] >> 5) - b.x0);
+            ta[k] = __umul24((uint32_t)((L.sy[k] >> 5) - b.y0), pitch) + (ix * 2u + ix) + raw0;  // LDS byte address in buffer 0
+            W[k] = blend_weights(L.sx[k], L.sy[k]);
+        }
+    }
+    uint32_t cur = 0, nxt = (uint32_t)D * box_bytes;  // byte offsets of the buffers of unit u and unit u + D
+    for (int u = 0; u < nu; u++) {
+        // unit u's box: everything older has landed once at most the requests younger than it are outstanding -- the passes of
+        // the units between u and u + D and the stores of the last min(u, D) units (at least one instruction each)
+        wait_vm_barrier((D > 1 && u + 1 < nu ? np : 0) + min(u, D));
+        if (u + D < nu)
+            raw_box_dma(b, ua.u[z0 + u + D].src, (uint32_t)ua.u[z0 + u + D].src_pitch, tid, raw0 + nxt, np);
+        asm volatile("" ::: "memory");  // (the counts above rely on the program order request -> taps -> store)
+        uint32_t pix[kPX];
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const uint32_t a = ta[k] + cur, d = a & ~3u;
+            const lds_u32_ptr r0 = (lds_u32_ptr)(uintptr_t)d, r1 = (lds_u32_ptr)(uintptr_t)(d + pitch);
+            const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+            pix[k] = blend3<3>(__builtin_amdgcn_alignbyte(a1, a0, a), __builtin_amdgcn_alignbyte(a2, a1, a), __builtin_amdgcn_alignbyte(b1, b0, a),
+                               __builtin_amdgcn_alignbyte(b2, b1, a), W[k]);
+        }
+        store_interior(ua, z0 + u, t, pix);
+        cur = cur == (uint32_t)D * box_bytes ? 0u : cur + box_bytes;
+        nxt = nxt == (uint32_t)D * box_bytes ? 0u : nxt + box_bytes;
+    }
 }
 
 static int taps_of(int interp)
@@ -2017,7 +2138,29 @@ int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int 
 }
 
 // tiles the lean batch kernel leaves to the general one, as ty << 16 | tx (row-major order)
-std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int half_dwords)
+// Box buffer size (KB = wave-passes of 64 units) of k_ray_lin3_batch_lean_raw: holds the boxes of 98 % of the interior tiles
+int tile_lean_raw_passes(const void* host_boxes, const Geom& g)
+{
+    const TileBox* b = (const TileBox*)host_boxes;
+    const dim3 d = tile_grid(g, tile_threads(g), 1);
+    std::vector<int> hist(kRawMaxWavePasses + 2, 0);
+    size_t n = 0;
+    for (size_t i = 0; i < (size_t)d.x * d.y; i++) {
+        if (b[i].interior == 0 || b[i].cpr <= 0 || b[i].cpr > kMaxCpr)
+            continue;
+        hist[std::min((b[i].nrows * raw_units_per_row(b[i].cpr) + 63) / 64, kRawMaxWavePasses + 1)]++, n++;
+    }
+    size_t acc = 0;
+    for (int k = 0; k <= kRawMaxWavePasses; k++) {
+        acc += hist[k];
+        if (acc * 100 >= n * 98)
+            return std::max(k, 4);
+    }
+    return kRawMaxWavePasses;
+}
+
+// `raw_nwp` > 0: the list for k_ray_lin3_batch_lean_raw with box buffers of raw_nwp KB instead
+std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int half_dwords, int raw_nwp)
 {
     const TileBox* b = (const TileBox*)host_boxes;
     const dim3 d = tile_grid(g, tile_threads(g), 1);
@@ -2027,7 +2170,7 @@ std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int 
     for (unsigned ty = 0; ty < d.y; ty++)
         for (unsigned tx = 0; tx < d.x; tx++) {
             const TileBox& q = b[(size_t)ty * d.x + tx];
-            if (!lean_static_ok(q.cpr, q.nrows, q.nidx, q.interior, half_dwords))
+            if (raw_nwp > 0 ? !lean_raw_static_ok(q, raw_nwp, g.src_h, g.src_w) : !lean_static_ok(q.cpr, q.nrows, q.nidx, q.interior, half_dwords))
                 out.push_back(ty << 16 | tx);
         }
     return out;
@@ -2076,7 +2219,7 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry,
 template <int K>
 static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, int half_dwords,
                           bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
-                          hipStream_t stream)
+                          int lean_raw_nwp, hipStream_t stream)
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     static const int upb_max = [] {  // V1C_UPB=<n>: A/B override of the units per workgroup
@@ -2136,6 +2279,12 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
             if (lean) {                                                                                                               \
                 /* (running the remaining tiles on a side stream, forked and joined with events so that their */                      \
                 /* latency-bound kernel overlaps the lean one, measured 4 % slower on C3 than back to back) */                        \
+                if (lean_raw_nwp > 0)                                                                                                 \
+                    hipLaunchKernelGGL((k_ray_lin3_batch_lean_raw<VW, RT, OW>), merged ? merged_grid : grid, block,                   \
+                                       std::max(lean_lds, (size_t)V1C_LEAN_RING * 1024 * (size_t)lean_raw_nwp), stream, c, ua, bx, n_units, upb,  \
+                                       lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest, slen, smagic,        \
+                                       lean_raw_nwp);                                                                                 \
+                else                                                                                                                  \
                 hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), merged ? merged_grid : grid, block, lean_lds, stream, c, ua,  \
                                    bx, n_units, upb, lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest, slen,  \
                                    smagic);                                                                                           \
@@ -2194,13 +2343,13 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 // buffer size (dwords) it was made for.
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
-                          hipStream_t stream)
+                                int lean_raw_nwp, hipStream_t stream)
 {
     const TileBox* bx = (const TileBox*)boxes;
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, stream); break;
-    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, stream); break;
-    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, stream); break;
+    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream); break;
+    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream); break;
+    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -172,6 +172,7 @@ struct v1c_plan {
     const uint32_t* rest_list = nullptr;  // tiles the lean batch kernel leaves to the general one (device)
     int n_rest = 0;
     int lean_half = 256;          // box buffer dwords of the lean batch kernel (<= half_dwords)
+    int lean_raw_nwp = 0;         // > 0: batches through k_ray_lin3_batch_lean_raw, box buffers of so many KB
     int strip_len = 0;            // XCD interleave: tiles per strip (0: one block per XCD), tile_xcd_strips()
     // apply_lr pairs of unrotated chains: boxes of the bands that mirror the tiles about the equator and the tiles
     // the mirror launch leaves to the pair kernel (k_ray_lin3_pair_mirror); mirror_boxes == nullptr: not used
@@ -464,7 +465,12 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     p->strip_len = tile_xcd_strips(hb.data(), g, p->half_dwords, p->lean_half);
                     if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                         std::fprintf(stderr, "[v1c] XCD interleave: strips of %d tiles\n", p->strip_len);
-                    const std::vector<uint32_t> rest = tile_rest_list(hb.data(), g, p->lean_half);
+                    {  // V1C_LEAN_RAW=0: the register-staged lean kernel, <n> > 1: n KB per box buffer
+                        const char* sw = tuning_env("V1C_LEAN_RAW");
+                        const int v = sw ? std::atoi(sw) : 1;
+                        p->lean_raw_nwp = v == 1 ? tile_lean_raw_passes(hb.data(), g) : v > 1 ? std::min(v, 16) : 0;
+                    }
+                    const std::vector<uint32_t> rest = tile_rest_list(hb.data(), g, p->lean_half, p->lean_raw_nwp);
                     const dim3 full((unsigned)((g.dst_w + 63) / 64), (unsigned)((g.dst_h + 15) / 16));
                     if (full.x <= 0xffffu && full.y <= 0xffffu) {
                         if ((rc = upload(p, rest, &p->rest_list))) {
@@ -474,7 +480,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         p->n_rest = (int)rest.size();
                     }
                     if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
-                        std::fprintf(stderr, "[v1c] lean batch kernel: %d of %zu tiles left to the general kernel\n", p->n_rest, hb.size() / 32);
+                        std::fprintf(stderr, "[v1c] lean batch kernel: %d of %zu tiles left to the general kernel (raw box KB %d)\n", p->n_rest, hb.size() / 32, p->lean_raw_nwp);
                 }
                 // bilinear pairs of an unrotated chain whose rows mirror about an integer row (the default Normalize
                 // centre H / 2): boxes of the mirrored bands + the list of tiles that launch leaves to the pair kernel
@@ -656,7 +662,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
                                              shared_entry && !p->disable_shared_entry, mpoly_all && !p->disable_mpoly,
-                                             any_rot ? nullptr : p->rest_list, p->n_rest, p->lean_half, p->strip_len, st));
+                                             any_rot ? nullptr : p->rest_list, p->n_rest, p->lean_half, p->strip_len, p->lean_raw_nwp, st));
             } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }
