@@ -62,6 +62,11 @@ WORKLOADS = {
                desc="L+R 2048x2048 fisheye -> 4096x2048 SBS equirect, equidistant, bilinear"),
     "C4": dict(size=8192, poly=[0, 1, -0.1], rot="ry45", interp=4,
                desc="L+R 8192x8192 -> 16384x8192 SBS, Euler rotation + PolynomialScaler, Lanczos4"),
+    # (not a BASELINE config: a rotated bilinear pair -- the pair kernels the unrotated configs above do not reach; tools/ab.sh)
+    "C2R": dict(size=4096, poly=[0, 1, -0.1], rot="ry45", interp=1,
+                desc="L+R 4096x4096 -> 8192x4096 SBS, Euler rotation + PolynomialScaler, bilinear (A/B only)"),
+    "C2N": dict(size=4080, poly=[0, 1, -0.1], rot=None, interp=1,
+                desc="L+R 4080x4080 -> 8160x4080 SBS (rows do not mirror about a tile boundary), bilinear (A/B only)"),
     # batch shapes: `frames` SBS frames per GPU per step (BASELINE configs 3 and 5 shard 8 resp. 32 per GPU)
     "C3": dict(size=2880, poly=None, rot=None, interp=1, frames=8,
                desc="8 SBS frames 5760x2880 per GPU (of 64 over 8 GPUs), equidistant, bilinear"),

@@ -1875,11 +1875,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
         const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
-    constexpr int D = V1C_LEAN_RING - 1;  // prefetch distance (units)
-    raw_box_dma(b, ua.u[z0].src, (uint32_t)ua.u[z0].src_pitch, tid, raw0, np);
-    if (D > 1 && nu > 1)
-        raw_box_dma(b, ua.u[z0 + 1].src, (uint32_t)ua.u[z0 + 1].src_pitch, tid, raw0 + box_bytes, np);
-    wait_vm_barrier(D > 1 && nu > 1 ? 2 * np : np);  // table slice landed
+    // Requests are counted per wave in issue order (vmcnt's order): `issued` so far, `done_at[i]` = the count right behind the
+    // box requested into buffer i -- that box has landed once at most issued - done_at[i] requests are outstanding.
+    constexpr int R = V1C_LEAN_RING;
+    int issued = 1, done_at[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        done_at[i] = 0;
+        if (i < nu) {
+            raw_box_dma(b, ua.u[z0 + i].src, (uint32_t)ua.u[z0 + i].src_pitch, tid, raw0 + (uint32_t)i * box_bytes, np);
+            issued += np, done_at[i] = issued;
+        }
+    }
+    wait_vm_barrier(issued - 1);  // table slice landed
     const uint32_t pitch = (uint32_t)raw_units_per_row(b.cpr) * 16u;
     uint32_t ta[kPX];
     BlendW W[kPX];
@@ -1896,14 +1904,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
             W[k] = blend_weights(L.sx[k], L.sy[k]);
         }
     }
-    uint32_t cur = 0, nxt = (uint32_t)D * box_bytes;  // byte offsets of the buffers of unit u and unit u + D
+    uint32_t cur = 0;  // byte offset of unit u's buffer (u % R)
+    int slot = 0;
     for (int u = 0; u < nu; u++) {
-        // unit u's box: everything older has landed once at most the requests younger than it are outstanding -- the passes of
-        // the units between u and u + D and the stores of the last min(u, D) units (at least one instruction each)
-        wait_vm_barrier((D > 1 && u + 1 < nu ? np : 0) + min(u, D));
-        if (u + D < nu)
-            raw_box_dma(b, ua.u[z0 + u + D].src, (uint32_t)ua.u[z0 + u + D].src_pitch, tid, raw0 + nxt, np);
-        asm volatile("" ::: "memory");  // (the counts above rely on the program order request -> taps -> store)
+        int mark = done_at[0];
+#pragma unroll
+        for (int i = 1; i < R; i++)
+            mark = slot == i ? done_at[i] : mark;
+        wait_vm_barrier(issued - mark);  // unit u's box landed (every wave's part of it: barrier)
+        // everyone is done with unit u - 1: its buffer takes the box of unit u - 1 + R
+        if (u >= 1 && u - 1 + R < nu) {
+            const int z = z0 + u - 1 + R;
+            const uint32_t prev = cur == 0 ? (uint32_t)(R - 1) * box_bytes : cur - box_bytes;
+            raw_box_dma(b, ua.u[z].src, (uint32_t)ua.u[z].src_pitch, tid, raw0 + prev, np);
+            issued += np;
+#pragma unroll
+            for (int i = 0; i < R; i++)
+                done_at[i] = (slot == 0 ? R - 1 : slot - 1) == i ? issued : done_at[i];
+        }
+        asm volatile("" ::: "memory");  // (the counts rely on the program order request -> taps -> store)
         uint32_t pix[kPX];
 #pragma unroll
         for (int k = 0; k < kPX; k++) {
@@ -1914,8 +1933,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
                                __builtin_amdgcn_alignbyte(b2, b1, a), W[k]);
         }
         store_interior(ua, z0 + u, t, pix);
-        cur = cur == (uint32_t)D * box_bytes ? 0u : cur + box_bytes;
-        nxt = nxt == (uint32_t)D * box_bytes ? 0u : nxt + box_bytes;
+        issued += 1;  // the unit's store (at least one instruction; more only make the next wait longer than needed)
+        cur = cur == (uint32_t)(R - 1) * box_bytes ? 0u : cur + box_bytes;
+        slot = slot == R - 1 ? 0 : slot + 1;
     }
 }
 
@@ -2256,6 +2276,9 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
                 (lean_pair ? (upb >= 2 && n_units % upb != 1) : (upb > 2 && (n_units % upb == 0 || n_units % upb > 2)));
     for (int k = 0; k < n_units && lean; k++)
         lean = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
+    // (An LDS-DMA form of the plain pair kernel -- k_ray_lin3_pair_mirror_raw without the mirror image -- was built and removed:
+    // bit-identical, but 0.0535 against 0.0511 ms on an unrotated 4080^2 pair and 0.0733 against 0.0684 ms on a rotated
+    // 4096^2 pair (94 VGPRs): with one tile per workgroup the interleaved cells' single ds_read2_b64 per tap row wins.)
     // the few remaining tiles are served two units per workgroup (the pair instantiation): a workgroup
     // looping over 8 units would be one long serial chain with nothing to overlap it
     const dim3 rest_grid((unsigned)std::max(n_rest, 1), 1, (unsigned)((n_units + 1) / 2));
