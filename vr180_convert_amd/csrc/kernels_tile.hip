@@ -2037,7 +2037,11 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     const size_t lds = std::max((size_t)half_dwords * 8 + 16, (size_t)4 * 1024 * (size_t)std::max(raw_nwp, 0));
     const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
     const unsigned per = (grid.x * grid.y) >> 3;
-    const unsigned slen = 2u * grid.x < per ? 2u * grid.x : 0u;  // two tile rows per strip (tile_xcd_strips)
+    static const unsigned strip_rows = [] {  // V1C_MIRROR_STRIP_ROWS=<n>: A/B override (0: one block per XCD)
+        const char* e = tuning_env("V1C_MIRROR_STRIP_ROWS");
+        return e ? (unsigned)std::atoi(e) : 2u;
+    }();
+    const unsigned slen = strip_rows && strip_rows * grid.x < per ? strip_rows * grid.x : 0u;  // two tile rows per strip (tile_xcd_strips)
     const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
     if (raw_nwp > 0) {
         // (whole rows, a multiple of 8 of them: the pair rows keep their XCDs)
