@@ -1058,6 +1058,9 @@ def test_remap_sharded_on_the_devices_there_are(V, oracle_mod):
     ((1000, 1000), (1028, 512), 470.0), # width not a multiple of the tile (64): ragged last tile column -> rest list
     ((700, 700), (512, 480), 350.0),    # 480 = 15 * 32: odd number of tile-row pairs
     ((257, 263), (128, 100), 120.0),    # 100 rows: no mirror launch (not a multiple of 32), plain pair kernel
+    ((1800, 1800), (256, 256), 900.0),  # 7 x minification: boxes far beyond the DMA buffers / LDS -> rest list, global gathers
+    ((120, 120), (1024, 512), 60.0),    # 8 x magnification: boxes of a few rows
+    ((900, 1200), (640, 640), 450.0),   # 2 x minification in x: boxes around the buffer size, some tiles either side
 ])
 def test_mirror_pair_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radius):
     """apply_lr pairs of unrotated bilinear chains take k_ray_lin3_pair_mirror_raw (a tile and its mirror image about

@@ -1527,6 +1527,7 @@ __host__ __device__ inline bool mirror_static_ok(const TileBox& b, const TileBox
 // a box buffer holds `nwp` wave-passes of 64 units (the plan sizes it: tile_mirror_raw_passes); the last unit of a row
 // reads up to 12 bytes past the box (never past the image)
 constexpr int kRawMaxWavePasses = 16;  // 16 KB per box and eye
+constexpr int kMirrorRawMaxKB = 12;    // ... of the mirror launch (4 boxes per workgroup: 48 KB; larger boxes go to the rest list)
 __host__ __device__ inline int raw_units_per_row(int cpr)
 {
     return (3 * cpr + 3) >> 2;
@@ -1993,9 +1994,9 @@ int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, cons
     for (int k = 0; k <= kRawMaxWavePasses; k++) {
         acc += hist[k];
         if (acc * 100 >= n * 98)
-            return std::max(k, 4);
+            return std::min(std::max(k, 4), kMirrorRawMaxKB);
     }
-    return kRawMaxWavePasses;
+    return kMirrorRawMaxKB;
 }
 
 bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
