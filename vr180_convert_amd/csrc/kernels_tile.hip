@@ -1675,8 +1675,13 @@ __device__ __forceinline__ void raw_box_dma(const TileBox& b, const uint8_t* __r
     for (int q = 0; q < kRawMaxWavePasses / 4; q++) {
         if (q < my_passes) {  // wave-uniform
             const uint32_t u = min((uint32_t)(tid + q * 256), last);
-            const uint32_t r = (uint32_t)(((float)u + 0.5f) * rupr), col = u - r * (uint32_t)upr;
-            const uint8_t* gp = src + (org + __umul24(r, spitch) + col * 16u);
+            // (v_mul_u32_u24 by hand: with a scalar factor the compiler picks the quarter-rate v_mul_lo_u32)
+            const uint32_t r = (uint32_t)(((float)u + 0.5f) * rupr);
+            uint32_t rup, rsp;
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(rup) : "v"(r), "v"((uint32_t)upr));
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(rsp) : "v"(r), "v"(spitch));
+            const uint32_t col = u - rup;
+            const uint8_t* gp = src + (org + rsp + col * 16u);
             __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_box + (uint32_t)q * 4096u + wave_off), 16, 0, 0);
         }
     }
