@@ -1388,8 +1388,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
         const RayParams& P = c.ray;
         const int tid = threadIdx.x;
         const int z = blockIdx.z;
-        // (natural tile order here: with one source per unit the swizzle measured 6 % slower on C5)
-        const TileIds t = tile_ids(g, z, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / kLanesX);
+        // (natural tile order unless the host passes strips: with one block of tiles per XCD the swizzle measured 6 % slower on C5)
+        int btx = blockIdx.x, bty = blockIdx.y;
+        if (strip_len)
+            xcd_tile(tiles_x_magic, strip_len, strip_magic, btx, bty);
+        const TileIds t = tile_ids(g, z, tid, btx, bty, gridDim.x, NT / kLanesX);
         const uint8_t* __restrict__ src = ua.u[z].src;
         const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
@@ -1402,7 +1405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
         // unpredicated taps, unconditional stores.  Anything else (tiles cut by the destination's
         // edge, footprints leaving the source) falls through to the general code below.
         // PAIR doubles as "the m-polynomial table is valid for every unit of this launch" here.
-        const bool tile_full = ((int)(blockIdx.x + 1) * kTW <= g.dst_w) & ((int)(blockIdx.y + 1) * (NT / kLanesX) <= g.dst_h);
+        const bool tile_full = ((btx + 1) * kTW <= g.dst_w) & ((bty + 1) * (NT / kLanesX) <= g.dst_h);
         if (K == 2 && OWN == 0 && tile_full) {
             if (PAIR)
                 lane_coords<VAR_W, ROT, K, 0, 2, 1>(c, ua, z, rc, kPX, P.radial_m, 0, P.n_int, L);
@@ -2302,7 +2305,12 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     const bool merged = !merge_off && n_rest > 0 && (size_t)n_rest * ((n_units + 1) / 2) <= (size_t)grid.x * grid.y;
     const dim3 merged_grid(grid.x, grid.y, grid.z + 1);
     const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
-    const unsigned slen = bx && strip_len > 0 && (unsigned)strip_len < ((grid.x * grid.y) >> 3) ? (unsigned)strip_len : 0u;
+    static const unsigned nobox_strip_rows = [] {  // V1C_NOBOX_STRIP_ROWS=<n>: XCD strips of n tile rows for launches without boxes
+        const char* e = tuning_env("V1C_NOBOX_STRIP_ROWS");
+        return e ? (unsigned)std::atoi(e) : 0u;
+    }();
+    const unsigned slen = bx ? (strip_len > 0 && (unsigned)strip_len < ((grid.x * grid.y) >> 3) ? (unsigned)strip_len : 0u)
+                             : (nobox_strip_rows * grid.x < ((grid.x * grid.y) >> 3) ? nobox_strip_rows * grid.x : 0u);
     const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
     // Only combinations a plan can select are instantiated: the lean batch kernel and the tile-list form exist for
     // bilinear plans with boxes; launches without boxes (units that override the rotation) always rotate.
