@@ -56,6 +56,9 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_CHUNK_MAP_FP32
 #define V1C_CHUNK_MAP_FP32 1  // chunk -> (row, column) of the staging map by an fp32 reciprocal (0: integer magic multiply)
 #endif
+#ifndef V1C_RAW_SETPRIO
+#define V1C_RAW_SETPRIO 0  // > 0: wave priority of the mirror-raw kernel's sampling phase (A/B builds)
+#endif
 #ifndef V1C_LEAN_RING
 #define V1C_LEAN_RING 2  // box buffers of k_ray_lin3_batch_lean_raw (2 or 3: the boxes of 1 or 2 units in flight; C3: 0.1807 / 0.1852 ms,
                          // 7 / 5 workgroups per CU)
@@ -1776,6 +1779,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     ty += 1;
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
     // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
+#if V1C_RAW_SETPRIO >= 4
+    __builtin_amdgcn_s_setprio(3);  // (the prologue -- requests out as early as possible -- ahead of other waves' arithmetic)
+#endif
     RowCol rc;
     load_rowcol<0>(P, t.xc, t.jc, rc);
     const uint8_t* __restrict__ src0 = ua.u[0].src;
@@ -1807,6 +1813,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     raw_box_dma(q, src1, pitch1, tid, raw_q + box_bytes, np);
     // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
     // what the barrier publishes -- vmcnt counts in issue order -- then joins.
+#if V1C_RAW_SETPRIO >= 4
+    __builtin_amdgcn_s_setprio(0);
+#endif
     wait_vm_barrier(4 * np);  // table slice landed (this wave's 4 x np box loads may still be in flight)
     LaneCoords L;
     if (mpoly)
@@ -1814,6 +1823,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     else
         lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     wait_vm_barrier(2 * np);  // the tile's two boxes
+#if V1C_RAW_SETPRIO
+    __builtin_amdgcn_s_setprio(V1C_RAW_SETPRIO & 3);
+#endif
     uint32_t p0[kPX], p1[kPX];
     gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
     // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
