@@ -1091,3 +1091,43 @@ def test_remap_sharded_splits_rows_when_devices_outnumber_eyes(V, oracle_mod):
     for ndev in (4, 8):
         got = V.remap_sharded(CS.to_product(spec), [(left, right)], size_output=(256, 208), interpolation=4, radius="max", devices=[0] * ndev)
         assert np.array_equal(got[0], want), ndev
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_dma_kernels_random_geometries(V, oracle_mod, dev, seed):
+    """The LDS-DMA kernels (k_ray_lin3_pair_mirror_raw for pairs, k_ray_lin3_batch_lean_raw for batches) on seeded random
+    geometries: sources that are column halves of one SBS frame (pitched views whose rows end inside the frame / at its
+    last byte -- the 16-byte units of a box row may read up to 12 bytes past the box, never past the allocation),
+    magnification and minification, radius, polynomial.  Every output byte against the oracle."""
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    rng = np.random.default_rng(900 + seed)
+    h_in = int(rng.integers(6, 40)) * 16 + int(rng.integers(0, 16))
+    w_in = int(rng.integers(6, 40)) * 16 + int(rng.integers(0, 4)) * 4  # (views of an SBS frame stay dword-aligned: w_in % 4 == 0)
+    out_w = int(rng.integers(2, 12)) * 64 + int(rng.choice([0, 0, 4, 60]))
+    out_h = int(rng.integers(3, 12)) * 32
+    radius = float(rng.uniform(0.35, 0.75)) * min(h_in, w_in)
+    spec = [("equirect_enc", True)]
+    if rng.random() < 0.6:
+        spec.append(("poly", [0, 1, float(rng.uniform(-0.2, 0.1))]))
+    spec.append(CS.EQUI)
+    frame = noise_disc(h_in, 2 * w_in, 40 + seed)
+    frame[::7, ::5] = 255
+    frame[-1, -16:] = 200  # the frame's last bytes are not black: an over-read would show
+    left, right = frame[:, :w_in], frame[:, w_in:]
+    want = O.apply_lr(spec, left, right, size_output=(out_w, out_h), interpolation=1, radius=radius, border_value=(9, 8, 7))
+    fr = torch.from_numpy(frame).to(dev)
+    got = V.apply_lr_tensors(CS.to_product(spec), fr[:, :w_in], fr[:, w_in:], size_output=(out_w, out_h), interpolation=1,
+                             radius=radius, boarder_value=(9, 8, 7)).cpu().numpy()
+    assert np.array_equal(got, want), ("pair", h_in, w_in, out_w, out_h, int((got != want).sum()))
+    # the same map over a batch of 5 views (3 + 2 units per workgroup): the batch kernel
+    frames = [noise_disc(h_in, 2 * w_in, 60 + 5 * seed + f) for f in range(3)]
+    srcs_np = [f[:, :w_in] for f in frames] + [f[:, w_in:] for f in frames[:2]]
+    dev_frames = [torch.from_numpy(f).to(dev) for f in frames]
+    srcs = [d[:, :w_in] for d in dev_frames] + [d[:, w_in:] for d in dev_frames[:2]]
+    dsts = [torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=dev) for _ in srcs]
+    V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=radius, interpolation=1)
+    wants = O.apply(spec, srcs_np, size_output=(out_w, out_h), interpolation=1, radius=radius)
+    for k in range(5):
+        assert np.array_equal(dsts[k].cpu().numpy(), wants[k]), ("batch", k, h_in, w_in, out_w, out_h)
