@@ -16,6 +16,7 @@ import ctypes as C
 import threading
 import time
 from collections import OrderedDict
+import logging
 from logging import getLogger
 from pathlib import Path
 from typing import Any, Literal, Sequence
@@ -50,7 +51,15 @@ def _device(device: Any = None) -> torch.device:
     return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
 
 
+try:  # the raw handle of the current stream without building a torch.cuda.Stream object (4 us per call)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    _raw_stream = None
+
+
 def _stream_ptr(dev: torch.device) -> int:
+    if _raw_stream is not None and dev.index is not None:
+        return int(_raw_stream(dev.index))
     return int(torch.cuda.current_stream(dev).cuda_stream)
 
 
@@ -247,15 +256,38 @@ class _NoKey(Exception):
     """The transformer holds state the memo key cannot capture exactly: lower it on every call."""
 
 
+_FIELD_NAMES: dict = {}  # type -> tuple of dataclass field names (built-in stages), None (a foreign dataclass), False (no dataclass)
+
+
 def _param_key(obj: Any):
     """Exact, hashable image of a built-in transformer's parameters: floats by their bits
     (``float.hex``), arrays by dtype / shape / bytes, quaternion-likes by their four components,
     dataclass stages field by field.  ``repr`` is NOT used: NumPy prints arrays with 8 digits and
     honours ``np.set_printoptions``, numpy-quaternion prints ``%.15g`` -- two rotations 2e-9
-    apart would share a key and the second call would silently reuse the first one's plan."""
-    import dataclasses
+    apart would share a key and the second call would silently reuse the first one's plan.
+    (Runs on every call of the device-resident API: exact-type tests first, field names cached per class.)"""
+    t = type(obj)
+    if t is float:
+        return ("f", obj.hex())
+    if t is int:
+        return ("i", obj)
+    if obj is None or t is bool or t is str or t is bytes:
+        return obj
+    names = _FIELD_NAMES.get(t, 0)
+    if names == 0:
+        import dataclasses
 
-    if obj is None or isinstance(obj, (bool, str, bytes)):
+        if dataclasses.is_dataclass(t):
+            # a user subclass may carry state outside its fields
+            names = tuple(f.name for f in dataclasses.fields(t)) if t.__module__ == TransformerBase.__module__ else None
+        else:
+            names = False
+        _FIELD_NAMES[t] = names
+    if names is None:
+        raise _NoKey
+    if names is not False:
+        return (t.__name__, tuple([_param_key(getattr(obj, n)) for n in names]))
+    if isinstance(obj, (bool, str, bytes)):
         return obj
     if isinstance(obj, (int, np.integer)):
         return ("i", int(obj))
@@ -267,11 +299,7 @@ def _param_key(obj: Any):
         a = np.ascontiguousarray(obj)
         return ("nd", a.dtype.str, a.shape, a.tobytes())
     if isinstance(obj, (list, tuple)):
-        return (type(obj).__name__, tuple(_param_key(v) for v in obj))
-    if dataclasses.is_dataclass(obj) and not isinstance(obj, type):
-        if type(obj).__module__ != TransformerBase.__module__:
-            raise _NoKey  # a user subclass may carry state outside its fields
-        return (type(obj).__name__, tuple(_param_key(getattr(obj, f.name)) for f in dataclasses.fields(obj)))
+        return (t.__name__, tuple([_param_key(v) for v in obj]))
     if all(hasattr(obj, c) for c in "wxyz"):
         return ("q", tuple(float(getattr(obj, c)).hex() for c in "wxyz"))
     raise _NoKey
@@ -486,7 +514,8 @@ def get_radius_smart(radius: float | Literal["auto", "max"], images: Sequence[An
         radius_ = min(images[0].shape[0] / 2, images[0].shape[1] / 2)
     else:
         radius_ = radius
-    LOG.info(f"Radius: {radius_}, strategy: {radius}, image shape: {tuple(images[0].shape)}")
+    if LOG.isEnabledFor(logging.INFO):
+        LOG.info(f"Radius: {radius_}, strategy: {radius}, image shape: {tuple(images[0].shape)}")
     return radius_
 
 
