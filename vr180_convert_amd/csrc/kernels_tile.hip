@@ -56,9 +56,6 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_CHUNK_MAP_FP32
 #define V1C_CHUNK_MAP_FP32 1  // chunk -> (row, column) of the staging map by an fp32 reciprocal (0: integer magic multiply)
 #endif
-#ifndef V1C_RAW_SETPRIO
-#define V1C_RAW_SETPRIO 0  // > 0: wave priority of the mirror-raw kernel's sampling phase (A/B builds)
-#endif
 #ifndef V1C_LEAN_RING
 #define V1C_LEAN_RING 2  // box buffers of k_ray_lin3_batch_lean_raw (2 or 3: the boxes of 1 or 2 units in flight; C3: 0.1807 / 0.1852 ms,
                          // 7 / 5 workgroups per CU)
@@ -1654,14 +1651,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 
 // ---- the same workgroup with the boxes brought in by LDS-DMA, as they are in memory ----
 // global_load_lds_dwordx4 copies 16 bytes per lane from any dword-aligned address straight into LDS (lane-linear: unit
-// u = pass * 256 + tid at byte 16 u), so nothing of a box ever sits in a VGPR: all four boxes of the workgroup (two
+// u = 256 * pass + tid at byte 16 u), so nothing of a box ever sits in a VGPR: all four boxes of the workgroup (two
 // eyes x tile and mirrored band) and the table slice are requested in the prologue and the coordinates are evaluated
 // WHILE they are in flight (with register staging that overlap costs the staging registers' occupancy: DESIGN 4.4).
 // The box stays packed BGR (row pitch upr x 16 bytes); a tap pair (6 bytes at byte 3 ix) is cut out of three dwords
 // read at the dword below it (ds_read2_b32 + ds_read_b32: b64 / b96 reads that are not naturally aligned are
 // microcoded, 64 cycles) with two v_alignbyte_b32, then blended as the global-memory fallback does (blend3<3>).
-// vmcnt counts loads in issue order, so the waits below are exact: every lane issues every pass (units past the box are
-// clamped to its last unit and land in the unused tail of the box's kRawBoxBytes).
+// vmcnt counts requests in issue order, so the waits below are exact: every lane of a wave issues each of the wave's passes
+// (units past the box are clamped to its last unit and land in the unused tail of the box buffer).
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
@@ -1696,29 +1693,15 @@ __device__ __forceinline__ void raw_box_dma(const TileBox& b, const uint8_t* __r
 // s_waitcnt vmcnt(n) + s_barrier for a wave-uniform n (the count is an immediate); no fence: see the kernels
 __device__ __forceinline__ void wait_vm_barrier(int n)
 {
+#define V1C_WAIT_CASE(i) \
+    case i: asm volatile("s_waitcnt vmcnt(" #i ")\n\ts_barrier" ::: "memory"); break;
     switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(13)\n\ts_barrier" ::: "memory"); break;
-    case 14: asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory"); break;
-    case 15: asm volatile("s_waitcnt vmcnt(15)\n\ts_barrier" ::: "memory"); break;
-    case 16: asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); break;
-    case 17: asm volatile("s_waitcnt vmcnt(17)\n\ts_barrier" ::: "memory"); break;
-    case 18: asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory"); break;
-    case 19: asm volatile("s_waitcnt vmcnt(19)\n\ts_barrier" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory"); break;
+        V1C_WAIT_CASE(0) V1C_WAIT_CASE(1) V1C_WAIT_CASE(2) V1C_WAIT_CASE(3) V1C_WAIT_CASE(4) V1C_WAIT_CASE(5) V1C_WAIT_CASE(6)
+        V1C_WAIT_CASE(7) V1C_WAIT_CASE(8) V1C_WAIT_CASE(9) V1C_WAIT_CASE(10) V1C_WAIT_CASE(11) V1C_WAIT_CASE(12) V1C_WAIT_CASE(13)
+        V1C_WAIT_CASE(14) V1C_WAIT_CASE(15) V1C_WAIT_CASE(16) V1C_WAIT_CASE(17) V1C_WAIT_CASE(18) V1C_WAIT_CASE(19)
+    default: asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory"); break;  // (a smaller count only waits longer)
     }
+#undef V1C_WAIT_CASE
 }
 
 // taps of both eyes of a lane's 4 pixels from the raw boxes at LDS byte addresses `raw` (eye 0) and `raw + eye_off` (eye 1)
@@ -1779,9 +1762,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     ty += 1;
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
     // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
-#if V1C_RAW_SETPRIO >= 4
-    __builtin_amdgcn_s_setprio(3);  // (the prologue -- requests out as early as possible -- ahead of other waves' arithmetic)
-#endif
     RowCol rc;
     load_rowcol<0>(P, t.xc, t.jc, rc);
     const uint8_t* __restrict__ src0 = ua.u[0].src;
@@ -1813,9 +1793,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     raw_box_dma(q, src1, pitch1, tid, raw_q + box_bytes, np);
     // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
     // what the barrier publishes -- vmcnt counts in issue order -- then joins.
-#if V1C_RAW_SETPRIO >= 4
-    __builtin_amdgcn_s_setprio(0);
-#endif
     wait_vm_barrier(4 * np);  // table slice landed (this wave's 4 x np box loads may still be in flight)
     LaneCoords L;
     if (mpoly)
@@ -1823,9 +1800,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     else
         lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     wait_vm_barrier(2 * np);  // the tile's two boxes
-#if V1C_RAW_SETPRIO
-    __builtin_amdgcn_s_setprio(V1C_RAW_SETPRIO & 3);
-#endif
     uint32_t p0[kPX], p1[kPX];
     gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
     // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
