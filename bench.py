@@ -448,6 +448,10 @@ def main() -> None:
     for i in range(args.steps):
         step(args.warmup + i)
     e1.record()
+    # (the host polls the closing event before it synchronises: a blocking hipDeviceSynchronize wakes tens of microseconds
+    # after the GPU is done, which is several per cent of a 20-step region of 50 us kernels)
+    while not e1.query():
+        pass
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
