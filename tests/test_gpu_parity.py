@@ -1131,3 +1131,33 @@ def test_dma_kernels_random_geometries(V, oracle_mod, dev, seed):
     wants = O.apply(spec, srcs_np, size_output=(out_w, out_h), interpolation=1, radius=radius)
     for k in range(5):
         assert np.array_equal(dsts[k].cpu().numpy(), wants[k]), ("batch", k, h_in, w_in, out_w, out_h)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_pairs_random_interpolation_border_rotation(V, oracle_mod, dev, seed):
+    """apply_lr pairs over interpolation x border mode x rotation x size, seeded: the lane-remapped K x K pair gather (bicubic,
+    Lanczos4), the pair kernels with and without a rotation, footprints leaving the source under every border mode."""
+    from vr180_convert_amd import _abi
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    rng = np.random.default_rng(1700 + seed)
+    interp = int(rng.choice([0, 1, 2, 4]))
+    border = int(rng.choice([_abi.BORDER_CONSTANT, _abi.BORDER_REPLICATE, _abi.BORDER_REFLECT, _abi.BORDER_WRAP, _abi.BORDER_REFLECT_101]))
+    h_in, w_in = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+    out_w, out_h = int(rng.integers(1, 6)) * 64 + int(rng.choice([0, 4, 33])), int(rng.integers(2, 10)) * 16 + int(rng.choice([0, 0, 5]))
+    radius = float(rng.uniform(0.3, 1.2)) * min(h_in, w_in) / 2
+    spec = [("equirect_enc", True)]
+    if rng.random() < 0.5:
+        spec.append(("rot", CS.ry(float(rng.uniform(-0.8, 0.8)))))
+    if rng.random() < 0.5:
+        spec.append(("poly", [0, 1, float(rng.uniform(-0.2, 0.1))]))
+    spec.append(CS.EQUI)
+    left, right = noise_disc(h_in, w_in, 300 + seed), noise_disc(h_in, w_in, 400 + seed)
+    left[::5, ::3] = 255
+    want = O.apply_lr(spec, left, right, size_output=(out_w, out_h), interpolation=interp, radius=radius, border_mode=border,
+                      border_value=(3, 200, 77))
+    got = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev),
+                             size_output=(out_w, out_h), interpolation=interp, radius=radius, boarder_mode=border,
+                             boarder_value=(3, 200, 77)).cpu().numpy()
+    assert np.array_equal(got, want), (interp, border, h_in, w_in, out_w, out_h, int((got != want).sum()))
