@@ -87,6 +87,30 @@ def test_calibration_rotators_align_the_eyes():
     np.testing.assert_allclose([qr.w, qr.x, qr.y, qr.z], want_r, atol=1e-16)
 
 
+def test_fitted_quaternion_sign_never_doubles_the_per_eye_rotation():
+    """q and -q are one rotation, but ``phi = arccos(q.w)`` (cli.py:308-311) is not sign-blind: rotation_match returns
+    w >= 0 whatever LAPACK's eigenvector sign, and calibration_rotators gives each eye HALF the angle for q and for -q."""
+    from vr180_convert_amd.calibration import calibration_rotators
+    from vr180_convert_amd.quat import as_rotation_matrix, quaternion
+
+    def angle(m):
+        return float(np.arccos(np.clip((np.trace(m) - 1.0) / 2.0, -1.0, 1.0)))
+
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        rv = rng.normal(0, 0.02, 3)
+        q = from_rotation_vector(rv)
+        pts = rng.normal(size=(40, 3))
+        got = rotation_match(pts, rotate_vectors(q, pts))
+        assert got.w >= 0
+        theta = float(np.linalg.norm(rv))
+        for qq in (got, quaternion(-got.w, -got.x, -got.y, -got.z)):
+            ql, qr = calibration_rotators(qq)
+            np.testing.assert_allclose(angle(as_rotation_matrix(qr)), theta / 2, rtol=1e-3, atol=1e-9)
+            np.testing.assert_allclose(angle(as_rotation_matrix(ql)), theta / 2, rtol=1e-3, atol=1e-9)
+            np.testing.assert_allclose(as_rotation_matrix(qr) @ as_rotation_matrix(qr), as_rotation_matrix(q), atol=1e-4)  # pseudo-half: O(phi^3)
+
+
 def test_calibration_names_live_in_remapper_like_the_reference():
     import vr180_convert_amd.remapper as R
     from vr180_convert_amd import calibration

@@ -147,3 +147,36 @@ def test_lr_and_s_commands_match_the_oracle(tmp_path, oracle_mod):
     assert r.exit_code == 0, (r.stdout, r.exception)
     made = list(tmp_path.glob("L-R-*.png"))
     assert len(made) == 1 and _io.imread(made[0]).shape == (128, 256, 3)
+    # ... and its pixels: the same points through the (reference-pinned, tests/test_calibration.py) calibration maths give
+    # the two per-eye matrices the CLI inserted behind the encoder (cli.py:286-319); the oracle renders them
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.calibration import calibration_rotators, match_lr, rotation_match
+    from vr180_convert_amd.quat import as_rotation_matrix
+
+    pts = [(100, 100), (104, 101), (160, 90), (163, 92), (80, 170), (82, 173)]
+    vl, vr = match_lr(T.FisheyeDecoder("equidistant"), pts[0::2], pts[1::2], [img, img], radius="max")
+    ql, qr = calibration_rotators(rotation_match(vl, vr))
+    specs = tuple([("equirect_enc", True), ("rot", as_rotation_matrix(q)), CS.EQUI] for q in (ql, qr))
+    want = O.apply_lr(specs, img, img, size_output=(128, 128), interpolation=1, radius="max")
+    assert np.array_equal(_io.imread(made[0]), want)
+
+
+def test_name_unique_hashes_the_swapped_clock_offset(tmp_path, monkeypatch):
+    """cli.py:174-176, 334-352: --swap negates the clock offset BEFORE the name hash is taken, so the default 0.0 enters
+    the hash as "-0.0"; the same options give the file name the reference's CLI gives."""
+    import hashlib
+
+    import vr180_convert_amd.remapper as R
+
+    calls = []
+    monkeypatch.setattr(R, "apply_lr", lambda *a, **k: calls.append(k))
+    l, r_ = tmp_path / "L.png", tmp_path / "R.png"
+    l.write_bytes(b"x"), r_.write_bytes(b"x")
+    for swap, off in ((True, "-0.0"), (False, "0.0")):
+        calls.clear()
+        args = ["lr", str(l), str(r_), "--radius", "max", "--size", "64x64", "--name-unique"] + (["--swap"] if swap else [])
+        res = runner.invoke(cli.app, args)
+        assert res.exit_code == 0, (res.stdout, res.exception)
+        tag = hashlib.sha256("".join(["", "64x64", "inter_lanczos4", "border_constant", "0", "max", "False", off, str(swap)]).encode()).hexdigest()[:8]
+        first, second = ("R", "L") if swap else ("L", "R")
+        assert calls[0]["out_path"] == tmp_path / f"{first}-{second}-{tag}.png", calls[0]["out_path"]

@@ -952,6 +952,50 @@ def test_apply_lr_tuple_transformers_unequal_eye_widths(V, oracle_mod, tmp_path)
     assert np.array_equal(_io.imread(out_p), want)
 
 
+@pytest.mark.parametrize("robust", [False, True])
+def test_calibrated_pair_pixels_vs_oracle(V, oracle_mod, dev, robust):
+    """SURVEY 8f-3 on the device path (cli.py:286-319): matched points -> match_lr -> rotation_match(_robust) ->
+    calibration_rotators -> a (tL, tR) pair of chains through the HIP kernels; the oracle renders the same two
+    matrices.  The points are the pixel positions at which the two eyes see the same rays when the right camera is
+    rotated by a known small rotation (plus two gross mismatches for the robust fit), so the fit is also checked
+    against that rotation."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.calibration import calibration_rotators, match_lr, rotate_vectors, rotation_match, rotation_match_robust
+    from vr180_convert_amd.chain import DenormalizeTransformer, equidistant_from_3d
+    from vr180_convert_amd.quat import as_rotation_matrix, from_rotation_vector
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    n, radius = 400, 200.0
+    left, right = noise_disc(n, n, 41), noise_disc(n, n, 42)
+    dec = T.FisheyeDecoder("equidistant")
+    q_true = from_rotation_vector([0.015, -0.03, 0.02])
+    rng = np.random.default_rng(5)
+    rays = rng.normal(size=(60, 3)) * [0.5, 0.5, 0.1] + [0, 0, 1]
+    rays /= np.linalg.norm(rays, axis=-1, keepdims=True)
+    to_px = dec * DenormalizeTransformer(scale=(radius, radius), center=(n // 2, n // 2))
+    pl = np.stack(to_px.transform(*equidistant_from_3d(rays)), -1)
+    pr = np.stack(to_px.transform(*equidistant_from_3d(rotate_vectors(q_true, rays))), -1)
+    if robust:
+        pr[:2] += [[40.0, -35.0], [-50.0, 30.0]]
+    vl, vr = match_lr(dec, pl, pr, [left, right], radius=radius)
+    if robust:
+        q, dropped = rotation_match_robust(vl, vr)
+        assert dropped[:2].all()
+    else:
+        q = rotation_match(vl, vr)
+    np.testing.assert_allclose(as_rotation_matrix(q), as_rotation_matrix(q_true), atol=2e-6)  # (float32 points: match_lr)
+    ql, qr = calibration_rotators(q)
+    head = T.EquirectangularEncoder()
+    pair = (head * T.Euclidean3DRotator(ql) * dec, head * T.Euclidean3DRotator(qr) * dec)
+    specs = tuple([("equirect_enc", True), ("rot", as_rotation_matrix(h)), CS.EQUI] for h in (ql, qr))
+    for interp in (1, 4):
+        got = V.apply_lr_tensors(pair, torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev), size_output=(320, 320),
+                                 interpolation=interp, radius=radius).cpu().numpy()
+        want = O.apply_lr(specs, left, right, size_output=(320, 320), interpolation=interp, radius=radius)
+        assert np.array_equal(got, want), (interp, int((got != want).sum()))
+
+
 def test_memo_keys_are_exact_not_printed(V, oracle_mod, dev):
     """Two chains whose parameters differ below NumPy's print precision (and under a coarse
     np.set_printoptions) must not share a lowered chain / plan: each call equals ITS oracle result."""
@@ -1050,6 +1094,29 @@ def test_remap_sharded_on_the_devices_there_are(V, oracle_mod):
         w = np.concatenate([O.apply(CS.c5_spec(f, eye), [frames[f][:, eye * n:(eye + 1) * n]], size_output=(64, 64), interpolation=1,
                                     radius=n / 2)[0] for eye in (0, 1)], axis=1)
         assert np.array_equal(got[f], w), f
+
+
+def test_remap_sharded_border_transparent_is_deterministic(V, oracle_mod):
+    """BORDER_TRANSPARENT skips pixels: the staging ring of remap_sharded reuses its destination slots across groups, so
+    they are zeroed per group like apply()'s destinations (the reference's cv2 leaves such pixels undefined; the engine and
+    the oracle define them as 0).  More frames than ring slots, two workers, banded and unit-sharded paths agree."""
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    n = 96
+    frames = [noise_disc(n, 2 * n, 170 + f) for f in range(9)]
+    for f in frames:
+        f[:, :] = np.maximum(f, 1)  # no zero pixel anywhere: a stale pixel of another frame cannot pass for a zero
+    spec = [("equirect_enc", True), ("zoom", 0.6), CS.EQUI]  # zoomed out: a wide rim of skipped pixels
+    want = [O.apply_lr(spec, fr[:, :n], fr[:, n:], size_output=(80, 64), interpolation=1, radius="max", border_mode=5) for fr in frames]
+    assert any((w == 0).any() for w in want)
+    for devices in ([0], [0, 0]):
+        got = V.remap_sharded(CS.to_product(spec), frames, size_output=(80, 64), interpolation=1, radius="max", boarder_mode=5,
+                              devices=devices)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want)), devices
+    got = V.remap_sharded(CS.to_product(spec), [(frames[0][:, :n], frames[0][:, n:])], size_output=(80, 64), interpolation=1,
+                          radius="max", boarder_mode=5, devices=[0] * 8)
+    assert np.array_equal(got[0], want[0])
 
 
 @pytest.mark.parametrize("src_hw,out_wh,radius", [

@@ -100,4 +100,15 @@ def draw_anaglyph_labels(combine: np.ndarray) -> np.ndarray:
     if _cv is not None:  # pragma: no cover
         _cv.putText(combine, "L", (0, len(combine[1]) // 10), _cv.FONT_HERSHEY_SIMPLEX, len(combine) // 1000, colors[0], 2, _cv.LINE_AA)
         _cv.putText(combine, "R", (len(combine[1]) // 2, len(combine[0]) // 10), _cv.FONT_HERSHEY_SIMPLEX, len(combine) // 1000, colors[1], 2, _cv.LINE_AA)
+    else:
+        global _LABEL_WARNED
+        if not _LABEL_WARNED:
+            _LABEL_WARNED = True
+            import warnings
+
+            warnings.warn("apply_lr(merge=True): cv2 is not installed, so the 'L' / 'R' labels the reference draws with "
+                          "cv2.putText (remapper.py:498-516) are missing from the anaglyph", RuntimeWarning, stacklevel=3)
     return combine
+
+
+_LABEL_WARNED = False

@@ -48,13 +48,18 @@ def rotation_match(points_to_be_rotated: np.ndarray, points: np.ndarray) -> quat
     eigenvalue).  Since ``|R a - b|^2 = |a|^2 + |b|^2 - 2 b.(R a)``, ``B = sum_k (|a_k|^2 + |b_k|^2) I - 2 N``
     with Horn's matrix N of the 3x3 correlation of the two point sets: the minimiser of E is the eigenvector
     of N's LARGEST eigenvalue -- one 3x3 product and one symmetric 4x4 eigenproblem (``eigh``), whatever
-    the number of points.  The sign of the result is arbitrary (q and -q are one rotation)."""
+    the number of points.  q and -q are one rotation, and LAPACK returns either; the result is canonicalised to
+    ``w >= 0`` because the CLI's half-rotation (``calibration_rotators``: ``phi = arccos(q.w)``) is sign-sensitive --
+    with w < 0 it applies the FULL rotation to each eye instead of half (the reference takes whichever sign
+    ``np.linalg.eig`` happens to return, remapper.py:140-143)."""
     a = np.asarray(points_to_be_rotated, dtype=float).reshape(-1, 3)
     b = np.asarray(points, dtype=float).reshape(-1, 3)
     if a.shape != b.shape:
         raise ValueError("point sets must have the same shape")
     lam, vec = np.linalg.eigh(_horn_matrix(a, b))  # ascending eigenvalues
     w, x, y, z = vec[:, -1]
+    if w < 0 or (w == 0 and (x, y, z) < (0, 0, 0)):
+        w, x, y, z = -w, -x, -y, -z
     if LOG.isEnabledFor(logging.DEBUG):
         e_min = float(np.sum(a * a) + np.sum(b * b) - 2.0 * lam[-1])  # = smallest eigenvalue of B = min E
         LOG.debug("Error: %s", np.sqrt(max(e_min, 0.0)) / max(len(b), 1))
@@ -116,8 +121,12 @@ def calibration_rotators(q: Any) -> tuple[quaternion, quaternion]:
     """The two quaternions the reference's CLI wraps in ``Euclidean3DRotator`` for the left and the
     right eye (cli.py:308-319): ``half_q = sin(phi / 2) / sin(phi) * q + 0.5`` with
     ``phi = arccos(q.w)`` -- generally NOT unit (the rotator normalises) --
-    left: ``conj(half_q)``, right: ``half_q``."""
+    left: ``conj(half_q)``, right: ``half_q``.  The formula halves the rotation only for ``w >= 0``
+    (for w < 0, phi > pi / 2 and ``k q + 0.5`` normalises to the full rotation or worse), so the equivalent
+    quaternion -q is used then: every sign of a fitted q gives each eye half the inter-eye rotation."""
     w, x, y, z = (q.w, q.x, q.y, q.z) if hasattr(q, "w") else tuple(float(c) for c in q)
+    if w < 0:
+        w, x, y, z = -w, -x, -y, -z
     phi = np.arccos(w)
     k = np.sin(phi / 2) / np.sin(phi)
     half = quaternion(k * w + 0.5, k * x, k * y, k * z)

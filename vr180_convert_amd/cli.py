@@ -211,8 +211,9 @@ def lr(
     border = _flag(border_mode, _BORDERS, "border_", "border mode")
     radius_ = parse_radius(radius)
     chain: Any = parse_transformer(transformer)
+    # (the reference hashes the option AFTER --swap negated it, cli.py:174-176, 347: str(-0.0) == "-0.0" even for the default)
     tag = unique_suffix(transformer, size, interpolation, border_mode, border_value, radius, merge,
-                        autosearch_timestamp_calib_r_earlier_l, swap) if name_unique else ""
+                        r_earlier_l, swap) if name_unique else ""
     out = output_path(out_path, left_path, right_path, tag)
     if automatch != "":
         chain = calibrated_pair(chain, automatch, left_path, right_path, radius_,

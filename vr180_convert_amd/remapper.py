@@ -320,12 +320,14 @@ def _lower_cached(t: TransformerBase, *, radius, size_input, size_output) -> _ab
     if k is None:
         return lower_for_get_map(t, radius=radius, size_input=size_input, size_output=size_output)
     key = (k, float(radius).hex(), tuple(size_input), tuple(size_output))
-    ch = _LOWERED.get(key)
+    with _PLANS_LOCK:  # (the per-device worker threads of sharding.remap_sharded share this cache)
+        ch = _LOWERED.get(key)
     if ch is None:
         ch = lower_for_get_map(t, radius=radius, size_input=size_input, size_output=size_output)
-        _LOWERED[key] = ch
-        while len(_LOWERED) > 64:
-            _LOWERED.popitem(last=False)
+        with _PLANS_LOCK:
+            _LOWERED[key] = ch
+            while len(_LOWERED) > 64:
+                _LOWERED.popitem(last=False)
     return ch
 
 

@@ -251,6 +251,9 @@ def remap_sharded(transformer: Any, frames: Sequence[Any], *, size_output: tuple
 
                     def remap(srcs_g, dsts_g, idx, ids=ids, r=r):
                         gshard = Shard(shard.rank, shard.world, tuple(ids[i] for i in idx))
+                        if boarder_mode == 5:  # BORDER_TRANSPARENT: the ring's reused slots must not show through skipped pixels
+                            for d in dsts_g:
+                                d.zero_()
                         job = build_rank_job(transformer, gshard, dict(zip(gshard.units, srcs_g)), dict(zip(gshard.units, dsts_g)),
                                              radius=r, size_output=size_output, device=dev,
                                              rotations=None if rotations is None else
