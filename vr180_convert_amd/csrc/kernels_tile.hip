@@ -1662,32 +1662,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-// `lds_box`: LDS byte address of the box (wave-uniform); wave w runs pass q iff 4 q + w < nwp (all its lanes: units past the
-// box are clamped to the last one and land in the unused tail of the buffer) -- `my_passes` of them
-__device__ __forceinline__ void raw_box_dma(const TileBox& b, const uint8_t* __restrict__ src, uint32_t spitch, int tid, uint32_t lds_box,
-                                            int my_passes)
+// A box by LDS-DMA with a lane -> unit mapping that is the same for every wave-instruction ("pass"): R = floor(64 / upr) whole
+// rows per pass, lane l copies unit l % upr of row l / upr of the pass (lanes >= R * upr idle: exec-masked), so that a pass is a
+// scalar source base, a scalar LDS base (M0) and one instruction -- no per-lane address arithmetic per pass (the lane-linear
+// form divided every lane's unit index by upr in every pass: ~13 VALU instructions per pass, 65 per wave and tile pair on
+// C2).  Pass k starts at row k R; the last one is moved up to end with the box (rows copied twice are the same bytes).
+// Wave w runs passes w, w + 4, ...; returns how many (wave-uniform: the caller's vmcnt bookkeeping).
+struct RawLanes {
+    uint32_t row_l, col16;  // per lane: row of the pass and byte offset in the row
+    int R, upr;             // wave-uniform
+};
+
+__device__ __forceinline__ RawLanes raw_lanes(int cpr, int lane)
 {
-    const int upr = raw_units_per_row(b.cpr);
-    // floor(u / upr) for u < 16 K, upr <= 48 without a division: (u + 0.5) / upr stays 0.5 / 48 away from every integer, fp32's
-    // error here is < 1e-4 (the integer form needs a dependent table read or quarter-rate multiplies)
-    const float rupr = __builtin_amdgcn_rcpf((float)upr);
-    const uint32_t last = (uint32_t)(b.nrows * upr - 1);
-    const uint32_t org = __umul24((uint32_t)b.y0, spitch) + (uint32_t)b.x0 * 3u;
-    const uint32_t wave_off = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
-#pragma unroll
-    for (int q = 0; q < kRawMaxWavePasses / 4; q++) {
-        if (q < my_passes) {  // wave-uniform
-            const uint32_t u = min((uint32_t)(tid + q * 256), last);
-            // (v_mul_u32_u24 by hand: with a scalar factor the compiler picks the quarter-rate v_mul_lo_u32)
-            const uint32_t r = (uint32_t)(((float)u + 0.5f) * rupr);
-            uint32_t rup, rsp;
-            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(rup) : "v"(r), "v"((uint32_t)upr));
-            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(rsp) : "v"(r), "v"(spitch));
-            const uint32_t col = u - rup;
-            const uint8_t* gp = src + (org + rsp + col * 16u);
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_box + (uint32_t)q * 4096u + wave_off), 16, 0, 0);
-        }
+    RawLanes m;
+    m.upr = raw_units_per_row(cpr);
+    // floor(64 / upr) and floor(l / upr) without a division: (64 + 0.5) / upr and (l + 0.5) / upr stay 0.5 / 48 away from
+    // every integer, fp32's error here is < 1e-4
+    const float rupr = __builtin_amdgcn_rcpf((float)m.upr);
+    m.R = __builtin_amdgcn_readfirstlane((int)(64.5f * rupr));
+    m.row_l = (uint32_t)(((float)lane + 0.5f) * rupr);
+    m.col16 = ((uint32_t)lane - __umul24(m.row_l, (uint32_t)m.upr)) * 16u;
+    return m;
+}
+
+__device__ __forceinline__ int raw_box_dma(const TileBox& b, const RawLanes& m, const uint8_t* __restrict__ src, uint32_t spitch, int lane,
+                                            int wave, uint32_t lds_box)
+{
+    uint32_t voff;  // (v_mul_u32_u24 by hand: with a scalar factor the compiler picks the quarter-rate v_mul_lo_u32)
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(voff) : "v"(m.row_l), "v"(spitch));
+    voff += m.col16;
+    const int rows = min(m.R, b.nrows);
+    const int last0 = b.nrows - rows;  // first row of the last pass
+    const bool active = lane < rows * m.upr;
+    const uint8_t* org = src + (__umul24((uint32_t)b.y0, spitch) + (uint32_t)b.x0 * 3u);
+    const uint32_t lpitch = (uint32_t)m.upr * 16u;
+    int n = 0;
+    for (int r0 = wave * m.R; r0 < b.nrows; r0 += 4 * m.R) {  // wave-uniform
+        const int rs = min(r0, last0);
+        const uint8_t* gp = org + (uint32_t)rs * spitch + voff;
+        if (active)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_box + (uint32_t)rs * lpitch), 16, 0, 0);
+        n++;
     }
+    return n;
 }
 
 // s_waitcnt vmcnt(n) + s_barrier for a wave-uniform n (the count is an immediate); no fence: see the kernels
@@ -1780,26 +1798,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
     const uint32_t box_bytes = (uint32_t)nwp * 1024u;
     const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + 2u * box_bytes;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int np = (nwp - wave + 3) >> 2;  // this wave's passes per box
-    {  // table slice: nidx * 4 units of 16 bytes, one pass (clamped like the boxes)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    {  // table slice: nidx * 4 units of 16 bytes, one pass (units past the slice: clamped, they land in the unused tail of tabw)
         const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
         const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
-    raw_box_dma(b, src0, pitch0, tid, raw_b, np);
-    raw_box_dma(b, src1, pitch1, tid, raw_b + box_bytes, np);
-    raw_box_dma(q, src0, pitch0, tid, raw_q, np);
-    raw_box_dma(q, src1, pitch1, tid, raw_q + box_bytes, np);
+    const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
+    const int nb = raw_box_dma(b, mb, src0, pitch0, lane, wave, raw_b);  // this wave's requests per box of the tile ...
+    raw_box_dma(b, mb, src1, pitch1, lane, wave, raw_b + box_bytes);
+    const int nq = raw_box_dma(q, mq, src0, pitch0, lane, wave, raw_q);  // ... and of the mirrored band
+    raw_box_dma(q, mq, src1, pitch1, lane, wave, raw_q + box_bytes);
     // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
     // what the barrier publishes -- vmcnt counts in issue order -- then joins.
-    wait_vm_barrier(4 * np);  // table slice landed (this wave's 4 x np box loads may still be in flight)
+    wait_vm_barrier(2 * nb + 2 * nq);  // table slice landed (this wave's box loads may still be in flight)
     LaneCoords L;
     if (mpoly)
         lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     else
         lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
-    wait_vm_barrier(2 * np);  // the tile's two boxes
+    wait_vm_barrier(2 * nq);  // the tile's two boxes
     uint32_t p0[kPX], p1[kPX];
     gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
     // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
@@ -1863,8 +1881,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
     const uint32_t box_bytes = (uint32_t)nwp * 1024u;
     const uint32_t raw0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int np = (nwp - wave + 3) >> 2;  // this wave's passes per box
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const RawLanes ml = raw_lanes(b.cpr, lane);
     {
         const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
         const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
@@ -1878,8 +1896,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     for (int i = 0; i < R; i++) {
         done_at[i] = 0;
         if (i < nu) {
-            raw_box_dma(b, ua.u[z0 + i].src, (uint32_t)ua.u[z0 + i].src_pitch, tid, raw0 + (uint32_t)i * box_bytes, np);
-            issued += np, done_at[i] = issued;
+            issued += raw_box_dma(b, ml, ua.u[z0 + i].src, (uint32_t)ua.u[z0 + i].src_pitch, lane, wave, raw0 + (uint32_t)i * box_bytes);
+            done_at[i] = issued;
         }
     }
     wait_vm_barrier(issued - 1);  // table slice landed
@@ -1911,8 +1929,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
         if (u >= 1 && u - 1 + R < nu) {
             const int z = z0 + u - 1 + R;
             const uint32_t prev = cur == 0 ? (uint32_t)(R - 1) * box_bytes : cur - box_bytes;
-            raw_box_dma(b, ua.u[z].src, (uint32_t)ua.u[z].src_pitch, tid, raw0 + prev, np);
-            issued += np;
+            issued += raw_box_dma(b, ml, ua.u[z].src, (uint32_t)ua.u[z].src_pitch, lane, wave, raw0 + prev);
 #pragma unroll
             for (int i = 0; i < R; i++)
                 done_at[i] = (slot == 0 ? R - 1 : slot - 1) == i ? issued : done_at[i];
