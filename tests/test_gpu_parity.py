@@ -772,7 +772,9 @@ def test_batch_plan_run_is_graph_capturable(V, oracle_mod, dev):
 
 @pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_DISABLE_MPOLY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"},
                                  {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_LEAN": "1"}, {"V1C_DISABLE_MERGE": "1"}, {"V1C_XCD_STRIPS": "2"},
-                                 {"V1C_DISABLE_MIRROR": "1"}, {"V1C_MIRROR_RAW": "0"}, {"V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_RAW": "7"}, {"V1C_LEAN_RAW": "0"}, {"V1C_LEAN_RAW": "4"}, {}],
+                                 {"V1C_DISABLE_MIRROR": "1"}, {"V1C_MIRROR_RAW": "0"}, {"V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_RAW": "7"}, {"V1C_MIRROR_PIPE": "1"},
+                                 {"V1C_MIRROR_PIPE": "1", "V1C_PIPE_SINGLE_ROWS": "0"}, {"V1C_MIRROR_PIPE": "1", "V1C_MIRROR_RAW": "7", "V1C_PIPE_SINGLE_ROWS": "3"},
+                                 {"V1C_LEAN_RAW": "0"}, {"V1C_LEAN_RAW": "4"}, {}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_variants_bit_exact(env):
     """The instantiations the default configuration does not reach (per-pixel table fallback,

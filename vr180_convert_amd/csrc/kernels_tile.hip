@@ -1338,6 +1338,17 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, uns
 #if V1C_XCD_SWIZZLE
     const unsigned ntile = gridDim.x * (rows ? rows : gridDim.y), lin = (blockIdx.y - row0) * gridDim.x + blockIdx.x;
     const unsigned per = ntile >> 3;  // tiles per XCD; the remainder keeps its natural order
+    if (strip_len & 0x80000000u) {
+        // block mode (gridDim.x a multiple of 8): XCD x serves tile columns [x BW, (x + 1) BW), BW = gridDim.x / 8, in blocks of BH =
+        // strip_len & 0xffff tile rows, row-major inside a block -- the eight XCDs still work side by side in one band of BH tile rows,
+        // but a block's halo (source rows / columns its neighbours fetch too) is its perimeter 2 (BW + BH) instead of the
+        // 2 (gridDim.x + 2) of a two-row strip
+        const unsigned BW = gridDim.x >> 3, BH = strip_len & 0xffffu, i = lin >> 3, x = lin & 7u;
+        const unsigned blk = BW * BH, kb = i / blk, r = i - kb * blk, rr = r / BW;
+        ty = (int)(kb * BH + rr);
+        tx = (int)(x * BW + (r - rr * BW));
+        return;
+    }
     if (lin < per * 8u) {
         unsigned m = (lin & 7u) * per + (lin >> 3);
         if (strip_len) {
@@ -1827,6 +1838,197 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     store_pair_row(ua, t, mirror_h - t.j, p0, p1);
 }
 
+// ---- two tile pairs per workgroup: the second pair's boxes are in flight while the first one is sampled ----
+// k_ray_lin3_pair_mirror_raw's workgroup is a serial chain: requests -> coordinates -> gather + stores; its loads are in flight only during
+// the first third of its life, and what keeps HBM busy meanwhile is the other five workgroups of the CU.  Here a workgroup serves
+// the tile pairs of TWO vertically adjacent tile rows (ty, ty + 1 and the bands that mirror them) with the SAME four box buffers:
+//   requests: tables (both pairs), boxes a (tile of pair 0), a' (its mirrored band)
+//   coordinates 0 | gather a | -> slots of a are free: request b (tile of pair 1) | store a | gather a' | -> request b' | store a'
+//   coordinates 1 | gather b | store b | gather b' | store b'
+// so b and b' fly behind the stores of pair 0 and the coordinates of pair 1 at no cost in LDS or registers (LDS-DMA needs
+// neither staging registers nor a second set of buffers), the prologue (kernel arguments, tile boxes, XCD mapping) is paid once
+// per two pairs, and the row / column table values come through LDS (one 16-byte DMA unit per 2 columns / rows of the
+// workgroup instead of 88 bytes per lane from the vector cache: the column values serve both pairs).
+// The last `gridDim.y - rest_rows - rows2` rows of workgroups serve ONE tile row each: short workgroups at the end of the
+// dispatch order halve the launch's tail.  vmcnt bookkeeping as in k_ray_lin3_pair_mirror_raw; stores are counted as
+// kStoresPerPairRow requests per store_pair_row (tests/test_vmcnt_protocol.py checks the disassembly for exactly that).
+#ifndef V1C_PIPE_WAVES
+#define V1C_PIPE_WAVES 5  // waves per SIMD k_ray_lin3_pair_mirror_pipe is compiled for (at least)
+#endif
+constexpr int kStoresPerPairRow = 2;  // store_pair_row: one global_store_dwordx3 per eye (a LOWER bound is what the waits need)
+constexpr int kPipeColBytes = 2 * kTW * 8, kPipeRowBytes = 3 * 32 * 8;  // column values (sin, 1 - cos) of 64 columns; row values (sin, cos, 1 - cos) of 32 rows
+
+// s_waitcnt vmcnt(n) lgkmcnt(0) + s_barrier: as wait_vm_barrier, and this wave's LDS reads have returned (the barrier hands the
+// buffers they read to the next DMA requests)
+__device__ __forceinline__ void wait_vm_lgkm_barrier(int n)
+{
+#define V1C_WAIT_CASE(i) \
+    case i: asm volatile("s_waitcnt vmcnt(" #i ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    switch (n) {
+        V1C_WAIT_CASE(0) V1C_WAIT_CASE(1) V1C_WAIT_CASE(2) V1C_WAIT_CASE(3) V1C_WAIT_CASE(4) V1C_WAIT_CASE(5) V1C_WAIT_CASE(6)
+        V1C_WAIT_CASE(7) V1C_WAIT_CASE(8) V1C_WAIT_CASE(9) V1C_WAIT_CASE(10) V1C_WAIT_CASE(11) V1C_WAIT_CASE(12) V1C_WAIT_CASE(13)
+        V1C_WAIT_CASE(14) V1C_WAIT_CASE(15) V1C_WAIT_CASE(16) V1C_WAIT_CASE(17) V1C_WAIT_CASE(18) V1C_WAIT_CASE(19)
+    default: asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+#undef V1C_WAIT_CASE
+}
+
+// the lane's row / column values from the workgroup's LDS copy (`rows` = [3][32] doubles: sin, cos, 1 - cos of the latitude of the
+// rows of both tile rows; `cols` = [2][64]: sin, 1 - cos of the longitude of the tile's columns)
+__device__ __forceinline__ void rowcol_from_lds(uint32_t lds_cols, uint32_t lds_rows, int lx, int row, RowCol& rc)
+{
+    typedef const __attribute__((address_space(3))) double* lds_f64_ptr;
+    const lds_f64_ptr pr = (lds_f64_ptr)(uintptr_t)(lds_rows + (uint32_t)row * 8u);
+    rc.sl = pr[0], rc.cl = pr[32], rc.hl = pr[64];
+    const lds_f64_ptr pc = (lds_f64_ptr)(uintptr_t)(lds_cols + (uint32_t)lx * (kPX * 8u));
+#pragma unroll
+    for (int k = 0; k < kPX; k++)
+        rc.slon[k] = pc[k], rc.qlon[k] = pc[kTW + k];
+}
+
+template <int VAR_W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_PIPE_WAVES, 8))) void k_ray_lin3_pair_mirror_pipe(
+    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
+    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp,
+    unsigned rest_rows, unsigned rows2, unsigned tab_off, unsigned cols_off, unsigned tab_rest_off)
+{
+    constexpr int NT = 256;
+    // dynamic LDS: 4 box buffers of nwp KB | tab_off: the table slices of both pairs | cols_off: column values | row values
+    // (the general pair code of the rest rows: its cell buffers at 0, its table slice at tab_rest_off)
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
+    const int tid = threadIdx.x;
+    if (blockIdx.y < rest_rows) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= (unsigned)n_rest)
+            return;
+        const uint32_t v = rest_list[lin];
+        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
+                                                  (double*)((uint8_t*)dyn_box + tab_rest_off), (glb_u32_ptr)c.itab);
+        return;
+    }
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    int tx, gy;
+    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, gy, gridDim.y - rest_rows, rest_rows);
+    // group row gy: the first rows2 serve tile rows 1 + 2 gy and 2 + 2 gy, the others one tile row each
+    const bool two = (unsigned)gy < rows2;
+    const int ty0 = two ? 1 + 2 * gy : 1 + (int)rows2 + gy;
+    const int tile0 = ty0 * (int)gridDim.x + tx;
+    const TileBox bA = load_tile_box(boxes, tile0), qA = load_tile_box(mboxes, tile0);
+    int tile1 = tile0 + (two ? (int)gridDim.x : 0);
+    const TileBox bB = load_tile_box(boxes, tile1), qB = load_tile_box(mboxes, tile1);
+    const bool okA = mirror_raw_static_ok(bA, qA, nwp, g.src_h, g.src_w);
+    const bool okB = two && mirror_raw_static_ok(bB, qB, nwp, g.src_h, g.src_w);
+    if (!okA && !okB)
+        return;
+    // pair 0 = the first eligible one, pair 1 = tile row ty0 + 1 when both are
+    const TileBox b0 = okA ? bA : bB, q0 = okA ? qA : qB;
+    const int jo0 = okA ? 0 : 16;      // rows of pair 0 relative to ty0 * 16
+    const bool second = okA && okB;
+    const int nidx1 = bB.nidx, idx01 = bB.idx0;
+    const bool mpoly1 = (bB.interior & 2) != 0;
+    // (the boxes of pair 1 are loaded again where they are used: 16 scalar registers that would otherwise live through pair 0)
+    asm volatile("" : "+s"(tile1));
+    const int lx = tid & (kLanesX - 1), ly = tid >> 4;
+    const int x0 = (tx * kLanesX + lx) * kPX, jbase = ty0 * 16 + ly;
+    TileIds t;  // (store_pair_row reads x0 only)
+    t.x0 = x0;
+    const uint8_t* __restrict__ src0 = ua.u[0].src;
+    const uint8_t* __restrict__ src1 = ua.u[1].src;
+    const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[1].src_pitch;
+    const bool mpoly0 = (b0.interior & 2) != 0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box;
+    const uint32_t box_bytes = (uint32_t)nwp * 1024u;
+    const uint32_t raw_b = lds0, raw_q = lds0 + 2u * box_bytes;
+    const uint32_t lds_tab0 = lds0 + tab_off, lds_tab1 = lds_tab0 + (uint32_t)b0.nidx * (kRadialCoefs * 8u);
+    const uint32_t lds_cols = lds0 + cols_off, lds_rows = lds_cols + kPipeColBytes;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // ---- requests of the prologue: table slices (every wave: 16 entries each), column values (wave 0), row values (waves 1-3) ----
+    {
+        const uint8_t* gp = (const uint8_t*)((mpoly0 ? P.radial_m : P.radial) + (size_t)b0.idx0 * kRadialCoefs) + (uint32_t)tid * 16u;
+        if (tid < b0.nidx * 4)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab0 + (uint32_t)wave * 1024u), 16, 0, 0);
+    }
+    if (second) {
+        const uint8_t* gp = (const uint8_t*)((mpoly1 ? P.radial_m : P.radial) + (size_t)idx01 * kRadialCoefs) + (uint32_t)tid * 16u;
+        if (tid < nidx1 * 4)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab1 + (uint32_t)wave * 1024u), 16, 0, 0);
+    }
+    if (wave == 0) {
+        const double* ps = (lane < 32 ? P.col_s : P.col_h) + (tx * kTW + (lane & 31) * 2);
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)ps, (lds_void_ptr)(uintptr_t)lds_cols, 16, 0, 0);
+    } else if (lane < 16) {  // (three code paths: a pointer selected by the wave index ends up as an indexed array in scratch)
+        const int ro = ty0 * 16 + lane * 2;
+        if (wave == 1)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_s + ro), (lds_void_ptr)(uintptr_t)lds_rows, 16, 0, 0);
+        else if (wave == 2)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_c + ro), (lds_void_ptr)(uintptr_t)(lds_rows + 256u), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_h + ro), (lds_void_ptr)(uintptr_t)(lds_rows + 512u), 16, 0, 0);
+    }
+    // ---- boxes of pair 0 ----
+    const RawLanes mb0 = raw_lanes(b0.cpr, lane), mq0 = raw_lanes(q0.cpr, lane);
+    const int na = raw_box_dma(b0, mb0, src0, pitch0, lane, wave, raw_b);
+    raw_box_dma(b0, mb0, src1, pitch1, lane, wave, raw_b + box_bytes);
+    const int nm = raw_box_dma(q0, mq0, src0, pitch0, lane, wave, raw_q);
+    raw_box_dma(q0, mq0, src1, pitch1, lane, wave, raw_q + box_bytes);
+    wait_vm_barrier(2 * na + 2 * nm);  // tables, row / column values landed (the box requests behind them may be in flight)
+    LaneCoords L;
+    {
+        RowCol rc;
+        rowcol_from_lds(lds_cols, lds_rows, lx, jo0 + ly, rc);
+        const double* tab = (const double*)((const uint8_t*)dyn_box + tab_off);
+        if (mpoly0)
+            lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, tab, b0.idx0, b0.nidx, L);
+        else
+            lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, tab, b0.idx0, b0.nidx, L);
+    }
+    wait_vm_barrier(2 * nm);  // the tile's two boxes
+    uint32_t p0[kPX], p1[kPX];
+    const TileBox b1 = load_tile_box(boxes, tile1);
+    gather_pair_raw(b0, raw_b, box_bytes, L.sx, L.sy, p0, p1);
+    // the mirrored band's boxes (waited for before the tile's stores are issued: stores count in vmcnt too); every wave has
+    // read its taps of the tile's boxes: their buffers take the tile of pair 1
+    wait_vm_lgkm_barrier(0);
+    int nb = 0;
+    if (second) {
+        const RawLanes mb1 = raw_lanes(b1.cpr, lane);
+        nb = raw_box_dma(b1, mb1, src0, pitch0, lane, wave, raw_b);
+        raw_box_dma(b1, mb1, src1, pitch1, lane, wave, raw_b + box_bytes);
+    }
+    const int j0 = jbase + jo0;
+    store_pair_row(ua, t, j0, p0, p1);
+    const TileBox q1 = load_tile_box(mboxes, tile1);
+    gather_pair_raw(q0, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
+    if (!second) {
+        store_pair_row(ua, t, mirror_h - j0, p0, p1);
+        return;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the band's buffers take the band of pair 1
+    const RawLanes mq1 = raw_lanes(q1.cpr, lane);
+    const int nq = raw_box_dma(q1, mq1, src0, pitch0, lane, wave, raw_q);
+    raw_box_dma(q1, mq1, src1, pitch1, lane, wave, raw_q + box_bytes);
+    store_pair_row(ua, t, mirror_h - j0, p0, p1);
+    {
+        RowCol rc;
+        rowcol_from_lds(lds_cols, lds_rows, lx, 16 + ly, rc);
+        const double* tab = (const double*)((const uint8_t*)dyn_box + tab_off) + (size_t)b0.nidx * kRadialCoefs;
+        if (mpoly1)
+            lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, tab, idx01, nidx1, L);
+        else
+            lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, tab, idx01, nidx1, L);
+    }
+    // behind the boxes of tile 1: store a, the band's 2 nq requests, store a'
+    wait_vm_barrier(2 * nq + 2 * kStoresPerPairRow);
+    gather_pair_raw(b1, raw_b, box_bytes, L.sx, L.sy, p0, p1);
+    wait_vm_barrier(kStoresPerPairRow);  // behind the band's boxes: store a'
+    const int j1 = jbase + 16;
+    store_pair_row(ua, t, j1, p0, p1);
+    gather_pair_raw(q1, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
+    store_pair_row(ua, t, mirror_h - j1, p0, p1);
+    (void)nb;
+}
+
 // ---- batches (units sharing one map) with the boxes by LDS-DMA: k_ray_lin3_batch_lean's loop on raw boxes ----
 // V1C_LEAN_RING box buffers of nwp KB in a ring: unit u is sampled from its buffer while the boxes of the next ring - 1 units
 // are in flight (requested behind the barrier that tells everyone is done with the unit whose buffer they take): the
@@ -2041,8 +2243,26 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
     return rest.size() <= (size_t)d.x * (TYh - 1) && rest.size() * 4 <= (size_t)d.x * d.y;
 }
 
+// Table entries (per pair) the workgroups of k_ray_lin3_pair_mirror_pipe keep in LDS: the largest slice among the tile pairs that
+// launch serves
+int tile_mirror_pipe_tab(const void* host_boxes, const void* host_mboxes, const Geom& g, int raw_nwp)
+{
+    const TileBox* b = (const TileBox*)host_boxes;
+    const TileBox* q = (const TileBox*)host_mboxes;
+    const dim3 d = tile_grid(g, tile_threads(g), 1);
+    int m = 1;
+    for (unsigned ty = 1; ty < d.y / 2; ty++)
+        for (unsigned tx = 0; tx < d.x; tx++) {
+            const size_t i = (size_t)ty * d.x + tx;
+            if (mirror_raw_static_ok(b[i], q[i], raw_nwp, g.src_h, g.src_w))
+                m = std::max(m, b[i].nidx);
+        }
+    return m;
+}
+
+// `pipe_tab` > 0 (with raw_nwp > 0): k_ray_lin3_pair_mirror_pipe, two tile rows per workgroup, pipe_tab table entries per pair in LDS
 hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
-                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, hipStream_t stream)
+                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream)
 {
     const dim3 full = tile_grid(c.g, 256, 1);
     const dim3 grid(full.x, full.y / 2 - 1, 2), block(256, 1, 1);
@@ -2053,8 +2273,44 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
         const char* e = tuning_env("V1C_MIRROR_STRIP_ROWS");
         return e ? (unsigned)std::atoi(e) : 2u;
     }();
-    const unsigned slen = strip_rows && strip_rows * grid.x < per ? strip_rows * grid.x : 0u;  // two tile rows per strip (tile_xcd_strips)
+    unsigned slen = strip_rows && strip_rows * grid.x < per ? strip_rows * grid.x : 0u;  // two tile rows per strip (tile_xcd_strips)
     const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    static const unsigned block_rows = [] {  // V1C_MIRROR_BLOCK_ROWS=<n>: XCD blocks of gridDim.x / 8 columns x n tile rows (xcd_tile)
+        const char* e = tuning_env("V1C_MIRROR_BLOCK_ROWS");
+        return e ? (unsigned)std::atoi(e) : 0u;
+    }();
+    if (block_rows && grid.x % 8 == 0 && raw_nwp > 0)
+        slen = 0x80000000u | std::min(block_rows, 0xffffu);
+    if (raw_nwp > 0 && pipe_tab > 0) {
+        // group rows: rows2 of them serve two tile rows, the last n1 one tile row each -- by default about one round of resident
+        // workgroups (6 per CU), so that the launch ends on short workgroups; V1C_PIPE_SINGLE_ROWS=<n>: A/B override
+        static const int single_rows = [] {
+            const char* e = tuning_env("V1C_PIPE_SINGLE_ROWS");
+            return e ? std::atoi(e) : -1;
+        }();
+        const unsigned M = grid.y;  // tile rows 1 .. TY / 2 - 1
+        unsigned n1 = single_rows >= 0 ? (unsigned)single_rows : (1536u + full.x - 1) / full.x;
+        n1 = std::min(n1, M);
+        if ((M - n1) & 1u)
+            n1 += 1;
+        const unsigned rows2 = (M - n1) / 2;
+        const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
+        const dim3 pgrid(full.x, rows2 + n1 + rest_rows, 1);
+        const unsigned pper = (pgrid.x * (rows2 + n1)) >> 3;
+        const unsigned pslen = strip_rows && pgrid.x < pper ? pgrid.x : 0u;  // one group row (two tile rows) per strip
+        const unsigned psmagic = pslen ? (unsigned)(0x100000000ull / pslen) + 1u : 0u;
+        const unsigned tab_off = 4u * 1024u * (unsigned)raw_nwp;
+        const unsigned cols_off = tab_off + 2u * (unsigned)pipe_tab * (unsigned)(kRadialCoefs * 8);
+        const unsigned tab_rest_off = ((unsigned)half_dwords * 8u + 16u + 15u) & ~15u;
+        const size_t plds = std::max((size_t)cols_off + kPipeColBytes + kPipeRowBytes, (size_t)tab_rest_off + kTabSlice * kRadialCoefs * 8);
+        if (c.ray.var_is_w)
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_pipe<1>), pgrid, block, plds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, pslen, psmagic, raw_nwp, rest_rows, rows2, tab_off, cols_off, tab_rest_off);
+        else
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_pipe<0>), pgrid, block, plds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, pslen, psmagic, raw_nwp, rest_rows, rows2, tab_off, cols_off, tab_rest_off);
+        return hipGetLastError();
+    }
     if (raw_nwp > 0) {
         // (whole rows, a multiple of 8 of them: the pair rows keep their XCDs)
         const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;

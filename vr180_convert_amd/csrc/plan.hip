@@ -180,6 +180,7 @@ struct v1c_plan {
     const uint32_t* mirror_rest = nullptr;
     int n_mirror_rest = 0;
     int mirror_raw_nwp = 0;  // > 0: the mirror launch brings its boxes in by LDS-DMA (k_ray_lin3_pair_mirror_raw), buffers of so many KB
+    int mirror_pipe_tab = 0;  // > 0: ... two tile rows per workgroup (k_ray_lin3_pair_mirror_pipe), so many table entries per pair in LDS
     int mirror_h = 0;
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     bool disable_shared_entry = false;  // V1C_DISABLE_SHARED_ENTRY=1: keep the per-pixel table fallback compiled in
@@ -513,6 +514,14 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                                 return rc;
                             }
                             p->mirror_boxes = mbx, p->n_mirror_rest = (int)mrest.size(), p->mirror_h = g.dst_h;
+                            // V1C_MIRROR_PIPE=1 (A/B builds): two tile rows per workgroup (k_ray_lin3_pair_mirror_pipe).  Measured r03,
+                            // C2 / C1: 0.0497 / 0.0205 ms against 0.0472 / 0.0185 ms for k_ray_lin3_pair_mirror_raw
+                            const char* pipesw = tuning_env("V1C_MIRROR_PIPE");
+                            if (p->mirror_raw_nwp > 0 && pipesw && pipesw[0] == '1')
+                                p->mirror_pipe_tab = tile_mirror_pipe_tab(hb.data(), hm.data(), g, p->mirror_raw_nwp);
+                            if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
+                                std::fprintf(stderr, "[v1c] mirror launch: largest table slice %d entries\n",
+                                             tile_mirror_pipe_tab(hb.data(), hm.data(), g, p->mirror_raw_nwp));
                         }
                         if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                             std::fprintf(stderr, "[v1c] mirror pair launch: %s, %zu of %zu tiles left to the pair kernel (raw wave-passes %d)\n",
@@ -657,7 +666,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 mirror = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
             if (mirror) {
                 HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h, p->mirror_rest,
-                                                    p->n_mirror_rest, p->mirror_raw_nwp, st));
+                                                    p->n_mirror_rest, p->mirror_raw_nwp, p->mirror_pipe_tab, st));
             } else if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
