@@ -60,6 +60,10 @@ WORKLOADS = {
                desc="L+R 4096x4096 fisheye -> 8192x4096 SBS equirect, PolynomialScaler([0,1,-0.1]), bilinear"),
     "C1": dict(size=2048, poly=None, rot=None, interp=1,
                desc="L+R 2048x2048 fisheye -> 4096x2048 SBS equirect, equidistant, bilinear"),
+    # BASELINE config 1 as it is written: ONE 2048x2048 image through apply() (a single-unit launch: no second eye to share
+    # the coordinates with)
+    "C1S": dict(size=2048, poly=None, rot=None, interp=1, single=True,
+                desc="single 2048x2048 fisheye -> 2048x2048 equirect, equidistant, bilinear (BASELINE config 1)"),
     "C4": dict(size=8192, poly=[0, 1, -0.1], rot="ry45", interp=4,
                desc="L+R 8192x8192 -> 16384x8192 SBS, Euler rotation + PolynomialScaler, Lanczos4"),
     # (not a BASELINE config: a rotated bilinear pair -- the pair kernels the unrotated configs above do not reach; tools/ab.sh)
@@ -153,17 +157,22 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
     O.set_threads(cores)
     size = cfg["size"]
     spec = oracle_spec(cfg)
+    single = bool(cfg.get("single"))
+    eyes = 1 if single else 2
     # output buffers are allocated (and touched) once: the timed passes measure arithmetic, not
     # first-touch page faults of 100 MB of fresh memory per call
     xm, ym = np.zeros((size, size), np.float32), np.zeros((size, size), np.float32)
-    out = np.zeros((size, 2 * size, 3), np.uint8)
+    out = np.zeros((size, eyes * size, 3), np.uint8)
     halves = [np.zeros((size, size, 3), np.uint8), np.zeros((size, size, 3), np.uint8)]
 
     def one_pass():
         # apply_lr with a shared transformer: ONE map (remapper.py:381-386), remap per eye (:388-398),
-        # concatenate (:518)
+        # concatenate (:518); apply() of one image: the map and one remap
         O.get_map(spec, radius=size / 2, size_input=(size, size), size_output=(size, size), out=(xm, ym))
         O.remap(left, xm, ym, cfg["interp"], dst=halves[0])
+        if single:
+            out[:] = halves[0]
+            return
         O.remap(right, xm, ym, cfg["interp"], dst=halves[1])
         out[:, :size], out[:, size:] = halves[0], halves[1]
 
@@ -175,11 +184,11 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
         one_pass()
         times.append(time.perf_counter() - t0)
     best = min(times)
-    mpx = 2 * size * size / 1e6
+    mpx = eyes * size * size / 1e6
     res = {
         "value": round(mpx / best, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
         "sample": f"{len(times)} full passes of the bench workload ({mpx:.1f} Mpx each: fp64 chain per pixel + "
-                  f"fixed-point remap, both eyes, one shared map), best of them, OpenMP {cores} threads",
+                  f"fixed-point remap, {'one image' if single else 'both eyes, one shared map'}), best of them, OpenMP {cores} threads",
     }
     # (A) reference-equivalent path: NumPy chain (single-threaded float64 ufunc passes, like the
     # reference's get_map) on a 1024-row band of the same map + the C remap of that band; and
@@ -196,14 +205,15 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
         O.remap(left, xm, ym, cfg["interp"], dst=bd[0])  # warm
         t0 = time.perf_counter()
         O.remap(left, xm, ym, cfg["interp"], dst=bd[0])
-        O.remap(right, xm, ym, cfg["interp"], dst=bd[1])
+        if not single:
+            O.remap(right, xm, ym, cfg["interp"], dst=bd[1])
         t_rm = time.perf_counter() - t0
         res["numpy_chain_plus_remap"] = {
-            "value": round(2 * size * band / 1e6 / (t_np + t_rm), 3), "unit": "Mpixels/s",
-            "sample": f"top {band} rows of the workload's map: NumPy float64 chain (1 thread) {t_np:.2f} s + C remap of both eyes "
+            "value": round(eyes * size * band / 1e6 / (t_np + t_rm), 3), "unit": "Mpixels/s",
+            "sample": f"top {band} rows of the workload's map: NumPy float64 chain (1 thread) {t_np:.2f} s + C remap of {'the image' if single else 'both eyes'} "
                       f"({cores} threads) {t_rm:.3f} s",
         }
-        res["remap_only"] = {"value": round(2 * size * band / 1e6 / t_rm, 1), "unit": "Mpixels/s",
+        res["remap_only"] = {"value": round(eyes * size * band / 1e6 / t_rm, 1), "unit": "Mpixels/s",
                              "sample": "same band, map precomputed"}
     except Exception as e:  # noqa: BLE001 - the extra baselines must never break the bench line
         res["numpy_chain_plus_remap"] = {"error": repr(e)}
@@ -228,6 +238,9 @@ def spawn_ranks(args, argv: list[str]) -> int:
     return subprocess.call(cmd, env=env)
 
 
+PMC_CHILD_ARGS: list[str] = []  # main(): what besides --workload selects the launch (--split)
+
+
 def _pmc_pass(counter: str, workload: str, timeout_s: float):
     """One `rocprofv3 --pmc <counter>` child pass of this bench (short, nothing else profiled): mean
     counter value of the dominant remap kernel, or None.  The child is a fresh process; this one only waits."""
@@ -240,7 +253,7 @@ def _pmc_pass(counter: str, workload: str, timeout_s: float):
         env.pop(k, None)
     cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
            str(Path(__file__).resolve()), "--workload", workload, "--steps", str(PMC_STEPS), "--warmup", str(PMC_WARMUP), "--no-cpu-baseline",
-           "--traffic", "none", "--no-cold-extra", "--no-condition"]
+           "--traffic", "none", "--no-cold-extra", "--no-condition", *PMC_CHILD_ARGS]
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
         try:
@@ -312,6 +325,10 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
+    ap.add_argument("--split", default="frames", choices=["frames", "eyes", "bands"],
+                    help="how the job is dealt to the ranks (SURVEY.md 8e): frames = every rank its own frames (weak scaling, the "
+                         "default); eyes = ONE L+R pair, one eye per rank (N <= 2); bands = ONE pair, every eye's output rows cut into "
+                         "N / 2 bands (strong scaling; every rank holds the whole source eye of its bands, nothing is exchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
                     help="roofline.traffic: measured by rocprofv3 --pmc child passes of this run (N=1), read from "
@@ -322,6 +339,7 @@ def main() -> None:
                     help="skip the 0.5 s clock / launch-queue conditioning (the --pmc child passes: counters do not depend on clocks)")
     args = ap.parse_args()
 
+    PMC_CHILD_ARGS[:] = ["--split", args.split]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -354,7 +372,8 @@ def main() -> None:
     import vr180_convert_amd as V
     from vr180_convert_amd import _native
     from vr180_convert_amd import remapper as R
-    from vr180_convert_amd.sharding import shard_range
+    from vr180_convert_amd.sharding import (Shard, build_band_job, build_rank_job, plan_band_shards, plan_shards, run_band_job,
+                                            run_rank_job, shard_range)
     from vr180_convert_amd.synth import noise_disc, noise_disc_torch
 
     _native.lib()  # fail loudly if the HIP engine is missing
@@ -362,12 +381,64 @@ def main() -> None:
     size = cfg["size"]
     transformer = build_transformer(cfg)
     frames = cfg.get("frames", 0)
-    units = 2 * max(frames, 1)
+    single = bool(cfg.get("single"))
+    strong = args.split != "frames"
+    if strong and (frames or single):
+        raise SystemExit("--split eyes / bands divide ONE L+R pair: use a pair workload (C2, C4, C1, C2R, C2N)")
+    units = 1 if single else 2 * max(frames, 1)
     set_bytes = units * 3 * (size * size + size * size)
-    nsets = 1 if args.no_rotate else max(ROTATE_MIN_SETS, -(-ROTATE_MIN_BYTES // set_bytes))
+    my_units: list = []
+    if strong:
+        # ONE pair for the whole job (strong scaling): this rank's part of it by the product's partition
+        if args.split == "eyes":
+            if world > 2:
+                raise SystemExit("--split eyes deals the two eyes of one pair: at most 2 ranks (more: --split bands)")
+            my_units = list(plan_shards(1, world)[rank].units)
+            my_px = len(my_units) * size * size
+        else:
+            my_units = list(plan_band_shards(1, world, size)[rank])
+            my_px = sum(r1 - r0 for _, _, r0, r1 in my_units) * size
+        my_eyes = sorted({u[1] for u in my_units})
+        # bytes this rank moves per step: the source rows its output rows read are at most its whole eyes; algorithmic = the
+        # job's 6 B per output pixel times this rank's pixels
+        set_bytes = max(6 * my_px, 1)
+    nsets = 1 if (args.no_rotate or (strong and not my_units)) else max(ROTATE_MIN_SETS, -(-ROTATE_MIN_BYTES // set_bytes))
     left_h = right_h = None
     sets = []
-    if frames:
+    if strong:
+        left_h, right_h = noise_disc(size, size, 0), noise_disc(size, size, 1)
+        for k in range(nsets):
+            eyes_d = {}
+            for e in my_eyes:
+                eyes_d[e] = torch.from_numpy((left_h, right_h)[e]).to(dev) if k == 0 else noise_disc_torch(size, size, e + 100003 * k, dev)
+            sbs = torch.zeros((size, 2 * size, 3), dtype=torch.uint8, device=dev)
+            sources = {(0, e): eyes_d[e] for e in my_eyes}
+            if args.split == "eyes":
+                outputs = {(0, e): sbs[:, e * size:(e + 1) * size] for _, e in my_units}
+                job = build_rank_job(transformer, Shard(rank, world, tuple(my_units)), sources, outputs, radius=size / 2,
+                                     size_output=(size, size), device=dev)
+            else:
+                outputs = {u: sbs[u[2]:u[3], u[1] * size:(u[1] + 1) * size] for u in my_units}
+                job = build_band_job(transformer, my_units, sources, outputs, radius=size / 2, size_output=(size, size), device=dev)
+            sets.append(dict(job=job, sbs=sbs, keep=(eyes_d, sources, outputs)))
+
+        def step(i: int):
+            # the launch side of the gloo-tested host logic (tests/test_sharding_gloo.py): build_*_job above, run_*_job here
+            job = sets[i % nsets]["job"]
+            if args.split == "eyes":
+                run_rank_job(job, interpolation=cfg["interp"])
+            else:
+                run_band_job(job, interpolation=cfg["interp"])
+    elif single:
+        left_h = noise_disc(size, size, 2 * rank)
+        for k in range(nsets):
+            src = torch.from_numpy(left_h).to(dev) if k == 0 else noise_disc_torch(size, size, 2 * rank + 100003 * k, dev)
+            sets.append(dict(left=src, sbs=torch.empty((size, size, 3), dtype=torch.uint8, device=dev)))
+
+        def step(i: int):
+            b = sets[i % nsets]
+            V.remap_tensors(transformer, [b["left"]], [b["sbs"]], radius=size / 2, interpolation=cfg["interp"])
+    elif frames:
         # batch of SBS frames resident in HBM; units are the column halves (pitched views), each eye is
         # written straight into its half of the output SBS frame.  The job's frames*world frames are
         # dealt to the ranks by the product's partition (sharding.shard_range): this rank's block
@@ -460,7 +531,7 @@ def main() -> None:
     kernel_ms_max = allreduce_max(kernel_ms, dev)
     per_rank_ms = allgather_scalar(kernel_ms, dev, world)
 
-    px_per_step = units * size * size * world
+    px_per_step = 2 * size * size if strong else units * size * size * world
     value = px_per_step * args.steps / elapsed / 1e6
     # all eyes of a step: source read once + destination written once (a batch is ceil(units/16) launches:
     # the figure is per step, i.e. per group of launches, for batch workloads)
@@ -472,14 +543,19 @@ def main() -> None:
         line = {
             "metric": "Mpixels/s dual-fisheye->SBS-equirect remap; achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (seeded uint8 noise inside the fisheye circle, black outside), resident in HBM, "
                     f"{nsets} input/output buffer sets rotated per step ({nsets * set_bytes / 2**20:.0f} MiB: L3-cold)"
                     + (" -- REHEARSAL: ranks share devices, gloo; not a measurement" if rehearsal else ""),
             "config": {"workload": f"{args.workload}: {cfg['desc']}", "units_per_step_per_gpu": units,
                        "arithmetic": "f64 coordinates (fused chain), u8 pixels with int32 fixed-point blend",
-                       "sharding": "frames over ranks (sharding.shard_range), no collective", "kernel_path": paths,
+                       "sharding": {"frames": "frames over ranks (sharding.shard_range), no collective",
+                                    "eyes": "ONE pair, one eye per rank (sharding.plan_shards / build_rank_job / run_rank_job), no collective",
+                                    "bands": "ONE pair, output rows of every eye in N / 2 bands (sharding.plan_band_shards / build_band_job / "
+                                             "run_band_job); every rank holds the whole source eye of its bands (upload not timed), "
+                                             "no collective"}[args.split],
+                       "split": args.split, "kernel_path": paths,
                        "buffer_sets": nsets},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
@@ -487,11 +563,26 @@ def main() -> None:
                          "per_gpu_frac": [round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for ms in per_rank_ms]},
             "cold": {"plan_create_ms": round(plan_create_ms, 3), "first_call_ms": round(first_call_ms, 3)},
         }
+        if cfg["interp"] == 4 and not frames and not single:
+            # INTER_LANCZOS4 is not HBM-bound: 64 taps x 3 channels x 2 eyes = 384 exact integer multiply-accumulates per output
+            # position, one v_perm_b32 + one v_dot2_i32_i16 per two of them (OpenCV's int16 weights admit no cheaper exact form:
+            # DESIGN.md 4.5).  Ceiling = the VALU issue time of the kernel's instruction stream: waves x VALU instructions per wave
+            # (PMC, SQ_INSTS_VALU / SQ_WAVES: profiles/r02f_final/pmc_C4.log) x 4 cycles per wave-instruction on 1024 SIMDs at the
+            # ~2.1 GHz the part sustains.  `frac` stays the HBM fraction (the metric); `valu_int` says how close the launch is to
+            # what actually bounds it.
+            waves = size * size / 256.0  # a wave = 64 lanes x 4 px, both eyes
+            instr, cyc, clk = 2073.0, 4.0, 2.1e9
+            floor_ms = waves * instr * cyc / (1024 * clk) * 1e3
+            line["roofline"]["bound"] = "valu-int"
+            line["roofline"]["valu_int"] = {"floor_ms": round(floor_ms, 4), "frac_of_ceiling": round(floor_ms / kernel_ms_max / max(world, 1) if strong else floor_ms / kernel_ms_max, 4),
+                                            "valu_instr_per_wave": instr, "cycles_per_wave_instr": cyc, "clock_hz": clk,
+                                            "note": "exact int16 tap arithmetic on VALU bounds this launch, not HBM; achieved / peak / frac "
+                                                    "are still the HBM figures of the metric"}
         child = os.environ.get("V1C_BENCH_CHILD") == "1" or "rocprof" in os.environ.get("LD_PRELOAD", "")
         if world == 1 and not child:
             if not frames:
                 torch.cuda.synchronize(dev)
-                gpu_out = sets[0]["sbs"].cpu().numpy()  # set 0 = the numpy-seeded pair
+                gpu_out = sets[0]["sbs"].cpu().numpy()  # set 0 = the numpy-seeded pair (image)
             if args.traffic == "live":
                 t = measure_traffic(args.workload)
                 if t is not None:

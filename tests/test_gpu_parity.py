@@ -1098,6 +1098,38 @@ def test_remap_sharded_on_the_devices_there_are(V, oracle_mod):
         assert np.array_equal(got[f], w), f
 
 
+@pytest.mark.parametrize("split,workload", [("eyes", "C1"), ("bands", "C1"), ("frames", "C1S")])
+def test_bench_split_modes_rehearsal(split, workload):
+    """bench.py --split eyes / bands (ONE pair dealt to the ranks: SURVEY.md 8e) and the single-image workload: 2 ranks
+    sharing the one card of the test box (V1C_BENCH_REHEARSAL=1: gloo for the barrier / MAX, never a measurement) print one
+    JSON line with the right pixel count; at 1 rank the same modes are checked against the oracle by the bench itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {**os.environ, "V1C_BENCH_REHEARSAL": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    common = ["--workload", workload, "--split", split, "--steps", "3", "--warmup", "1", "--traffic", "none", "--no-cold-extra"]
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", *common], env=env, capture_output=True, text=True, timeout=600)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["parity_vs_oracle"]["bytes_differing"] == 0, line["parity_vs_oracle"]
+    assert line["config"]["split"] == split and line["scaling"] == ("weak" if split == "frames" else "strong")
+    if split == "frames":
+        return
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", *common, "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line2["scaling"] == "strong" and "REHEARSAL" in line2["data"]
+    # strong scaling: the job is ONE pair whatever the rank count
+    px = 2 * 2048 * 2048
+    assert abs(line2["value"] * line2["ms_per_step"] * 1e3 - px) / px < 0.02
+
+
 def test_remap_sharded_border_transparent_is_deterministic(V, oracle_mod):
     """BORDER_TRANSPARENT skips pixels: the staging ring of remap_sharded reuses its destination slots across groups, so
     they are zeroed per group like apply()'s destinations (the reference's cv2 leaves such pixels undefined; the engine and

@@ -166,6 +166,64 @@ def test_per_unit_rotations_travel_with_the_units():
     assert r0[3] == _total_checksum(n_frames, True)
 
 
+def _band_worker(rank, world, port, virtual_world, ret):
+    """Two gloo processes play `virtual_world` ranks of a row-band split of ONE pair (rank r of the process takes the virtual
+    ranks r, r + world, ...): the product's partition (plan_band_shards), band lowering and marshalling (build_band_job) and
+    run_band_job with an executor that interprets the marshalled records with the oracle."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from vr180_convert_amd.sharding import build_band_job, plan_band_shards, run_band_job
+        from vr180_convert_amd.synth import noise_disc
+
+        frame = noise_disc(SIZE, 2 * SIZE, frame=0)
+        eyes = {(0, e): torch.from_numpy(np.ascontiguousarray(frame[:, e * SIZE:(e + 1) * SIZE])) for e in (0, 1)}
+        sbs = torch.zeros((SIZE, 2 * SIZE, 3), dtype=torch.uint8)
+        work = plan_band_shards(1, virtual_world, SIZE)
+        mine = [u for v in range(rank, virtual_world, world) for u in work[v]]
+        outputs = {u: sbs[u[2]:u[3], u[1] * SIZE:(u[1] + 1) * SIZE] for u in mine}
+        job = build_band_job(_chain_objects(False), mine, eyes, outputs, radius=SIZE / 2, size_output=(SIZE, SIZE))
+
+        def launch(chain, units, band):
+            f, e, r0, r1 = band
+            u = units[0]
+            src = np.lib.stride_tricks.as_strided(
+                np.ctypeslib.as_array(C.cast(u.src, C.POINTER(C.c_uint8)), shape=(SIZE * u.src_pitch,)),
+                shape=(SIZE, SIZE, 3), strides=(u.src_pitch, 3, 1))
+            dst = np.lib.stride_tricks.as_strided(
+                np.ctypeslib.as_array(C.cast(u.dst, C.POINTER(C.c_uint8)), shape=((r1 - r0) * u.dst_pitch,)),
+                shape=(r1 - r0, SIZE, 3), strides=(u.dst_pitch, 3, 1))
+            xm, ym = O.get_map(O.Chain.from_buffer_copy(bytes(chain)), radius=0, size_input=(SIZE, SIZE), size_output=(SIZE, r1 - r0))
+            O.remap(src, xm, ym, 1, dst=dst)
+
+        assert run_band_job(job, interpolation=1, launch=launch) == ["custom"] * len(mine)
+        want = _expected(frame, 0, False)
+        ok = all(np.array_equal(sbs.numpy()[r0:r1, e * SIZE:(e + 1) * SIZE], want[r0:r1, e * SIZE:(e + 1) * SIZE]) for _, e, r0, r1 in mine)
+        # rows this process did not own stay untouched: the parts add up to the whole frame with no exchange
+        tot = torch.tensor([len(mine), int(sbs.numpy().astype(np.int64).sum()), int(ok)], dtype=torch.int64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        ret[rank] = (mine, int(tot[0]), int(tot[1]), int(tot[2]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("virtual_world", [2, 4])
+def test_single_pair_splits_rows_into_bands_over_ranks(virtual_world):
+    """a single pair on 4 / 8 GPUs = bands of output rows per GPU (what bench.py --split bands times)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_band_worker, args=(2, port, virtual_world, ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert sorted(r0[0] + r1[0]) == [(0, e, a, b) for e in (0, 1) for a, b in ([(0, SIZE)] if virtual_world == 2 else [(0, 16), (16, 32)])]
+    assert r0[1] == r1[1] == len(r0[0]) + len(r1[0]) and r0[3] == 2
+    assert r0[2] == _total_checksum(1, False)
+
+
 @pytest.mark.parametrize("n_frames,world", [(0, 1), (1, 1), (1, 2), (1, 8), (3, 4), (5, 2), (8, 8), (64, 8), (257, 8)])
 def test_plan_shards_partition_exactly(n_frames, world):
     sys.path.insert(0, str(ROOT))

@@ -276,12 +276,71 @@ def remap_sharded(transformer: Any, frames: Sequence[Any], *, size_output: tuple
     return outs
 
 
+@dataclass
+class BandJob:
+    """Host-side description of one rank's share of a row-band split (``plan_band_shards``): per band the lowered chain of
+    that band (``chain.lower_for_get_map(row_band=...)``: the same Normalize with its centre moved up by r0 rows) and the
+    marshalled one-unit ``v1c_unit`` record (whole source eye -> rows r0 .. r1 - 1 of the eye's half of the output)."""
+
+    bands: list        # (frame, eye, r0, r1)
+    chains: list
+    units: list
+    srcs: list
+    src_hw: tuple[int, int]
+    dst_w: int
+    cn: int
+
+
+def build_band_job(transformer: Any, bands: Sequence[tuple[int, int, int, int]], sources: dict, outputs: dict, *, radius: float,
+                   size_output: tuple[int, int], device: Any = None) -> BandJob:
+    """Host logic of one rank of a row-band split (a single pair on 4 / 8 GPUs).  ``sources[(frame, eye)]``: the
+    whole source eye (every rank uploads the eyes of its bands itself; nothing is exchanged); ``outputs[(frame, eye, r0, r1)]``:
+    the (r1 - r0, W, C) view the band is written into.  No device is involved: the gloo tests run exactly this."""
+    from . import remapper as R
+    from .chain import lower_for_get_map
+
+    bands = list(bands)
+    if not bands:
+        return BandJob([], [], [], [], (0, 0), int(size_output[0]), 0)
+    w = int(size_output[0])
+    first = sources[(bands[0][0], bands[0][1])]
+    src_hw = (int(first.shape[0]), int(first.shape[1]))
+    cn = int(first.shape[2])
+    chains, units, srcs = [], [], []
+    for f, e, r0, r1 in bands:
+        src, dst = sources[(f, e)], outputs[(f, e, r0, r1)]
+        if tuple(int(v) for v in src.shape[:2]) != src_hw or tuple(int(v) for v in dst.shape[:2]) != (r1 - r0, w):
+            raise ValueError("band sources must share a shape and band outputs must be (r1 - r0, W, C) views")
+        # (size_input: the shape the Denormalize centre is taken from -- images[0] of the call, remapper.py:385)
+        chains.append(lower_for_get_map(transformer[e] if isinstance(transformer, tuple) else transformer, radius=radius, size_input=src_hw, size_output=tuple(size_output), row_band=(r0, r1)))
+        units.append(R.marshal_units([src], [dst], None, src_hw=src_hw, dst_wh=(w, r1 - r0), cn=cn, device=device))
+        srcs.append(src)
+    return BandJob(bands, chains, units, srcs, src_hw, w, cn)
+
+
+def run_band_job(job: BandJob, *, interpolation: int, boarder_mode: int = 0, boarder_value: Any = 0, launch: Callable | None = None) -> list[str]:
+    """Launch every band of ``job`` on the current device / stream (``launch(chain, units, band)`` replaces the device launch in
+    the CPU tests)."""
+    from . import remapper as R
+
+    paths = []
+    for (f, e, r0, r1), chain, units, src in zip(job.bands, job.chains, job.units, job.srcs):
+        if launch is not None:
+            launch(chain, units, (f, e, r0, r1))
+            paths.append("custom")
+            continue
+        plan = R._plan_for(chain, src_hw=job.src_hw, dst_wh=(job.dst_w, r1 - r0), cn=job.cn, interpolation=interpolation,
+                           border_mode=boarder_mode, border_value=boarder_value, device=src.device)
+        plan.run_units(units, 1)
+        paths.append(plan.path)
+    return paths
+
+
 def _remap_banded(transformer, eyes, radii, outs, devs, *, size_output, interpolation, boarder_mode, boarder_value):
     """Worker per device, each remapping bands of output rows of whole source eyes it uploads itself."""
     import torch
 
     from . import remapper as R
-    from .chain import lower_for_get_map
 
     w, h = size_output
     cn = eyes[0][0].shape[2]
@@ -293,21 +352,19 @@ def _remap_banded(transformer, eyes, radii, outs, devs, *, size_output, interpol
             dev = torch.device("cuda", dev_index)
             torch.cuda.set_device(dev)
             with torch.cuda.stream(torch.cuda.Stream(dev)):
-                uploaded: dict = {}
-                for f, e, r0, r1 in units:
-                    im = eyes[f][e]
-                    if (f, e) not in uploaded:
-                        uploaded[(f, e)] = R._to_device(im, dev)
-                    src = uploaded[(f, e)]
-                    chain = lower_for_get_map(transformer, radius=radii[f], size_input=(int(eyes[f][0].shape[0]), int(eyes[f][0].shape[1])),
-                                              size_output=size_output, row_band=(r0, r1))
-                    plan = R._plan_for(chain, src_hw=(int(im.shape[0]), int(im.shape[1])), dst_wh=(w, r1 - r0), cn=cn,
-                                       interpolation=interpolation, border_mode=boarder_mode, border_value=boarder_value, device=dev)
-                    dst = torch.empty((r1 - r0, w, cn), dtype=torch.uint8, device=dev)
+                by_frame: dict = {}
+                for u in units:
+                    by_frame.setdefault(u[0], []).append(u)
+                for f, bands in by_frame.items():  # (the radius is per frame: remapper.py:474-484)
+                    sources = {(f, e): R._to_device(eyes[f][e], dev) for e in sorted({b[1] for b in bands})}
+                    outputs = {b: torch.empty((b[3] - b[2], w, cn), dtype=torch.uint8, device=dev) for b in bands}
                     if boarder_mode == 5:  # BORDER_TRANSPARENT: skipped pixels must be deterministic
-                        dst.zero_()
-                    plan.run([src], [dst])
-                    np.copyto(outs[f][r0:r1, e * w:(e + 1) * w], dst.cpu().numpy())
+                        for d in outputs.values():
+                            d.zero_()
+                    job = build_band_job(transformer, bands, sources, outputs, radius=radii[f], size_output=size_output, device=dev)
+                    run_band_job(job, interpolation=interpolation, boarder_mode=boarder_mode, boarder_value=boarder_value)
+                    for (_, e, r0, r1), d in outputs.items():
+                        np.copyto(outs[f][r0:r1, e * w:(e + 1) * w], d.cpu().numpy())
         except BaseException as ex:  # noqa: BLE001 - re-raised in the calling thread
             errors.append(ex)
 
