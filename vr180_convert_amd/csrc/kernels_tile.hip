@@ -1364,6 +1364,87 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, uns
 #endif
 }
 
+// ---- one tile of ONE unit that overrides the rotation (per-frame calibration): box reduced in-kernel, table from global memory ----
+// `red`: 16 ints of LDS, `boxw`: kBoxBytes + 16 bytes of LDS (BGRx box)
+template <int VAR_W, int ROT, int K, int OWN, int PAIR, typename WPtr>
+__device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs& ua, int z, int btx, int bty, int* red, uint32_t* boxw, WPtr wtab)
+{
+    constexpr int NT = 256;
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    const int tid = threadIdx.x;
+    const TileIds t = tile_ids(g, z, tid, btx, bty, gridDim.x, NT / kLanesX);
+    const uint8_t* __restrict__ src = ua.u[z].src;
+    const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+    const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
+    RowCol rc;
+    load_rowcol<ROT>(P, t.xc, t.jc, rc);
+    LaneCoords L;
+    // Fast attempt (bilinear, OWN = 0: the host proved that no pixel of these units leaves the
+    // validated part of the radial table): coordinates without any validity logic, bounding box
+    // of all 1024 pixels, and if that box lies inside the source the tile is "interior" --
+    // unpredicated taps, unconditional stores.  Anything else (tiles cut by the destination's
+    // edge, footprints leaving the source) falls through to the general code below.
+    // PAIR doubles as "the m-polynomial table is valid for every unit of this launch" here.
+    const bool tile_full = ((btx + 1) * kTW <= g.dst_w) & ((bty + 1) * (NT / kLanesX) <= g.dst_h);
+    if (K == 2 && OWN == 0 && tile_full) {
+        if (PAIR)
+            lane_coords<VAR_W, ROT, K, 0, 2, 1>(c, ua, z, rc, kPX, P.radial_m, 0, P.n_int, L);
+        else
+            lane_coords<VAR_W, ROT, K, 0, 2, 0>(c, ua, z, rc, kPX, P.radial, 0, P.n_int, L);
+        const BoxAll ba = reduce_box_all<NT / 64>(L, red, tid);
+        if ((ba.xmin >= 0) & (ba.xmax < g.src_w - 2) & (ba.ymin >= 0) & (ba.ymax < g.src_h - 1)) {
+            TileBox fb;
+            fb.x0 = ba.xmin & ~3, fb.y0 = ba.ymin;
+            fb.cpr = (ba.xmax + 2 - fb.x0 + 3) >> 2, fb.nrows = ba.ymax - ba.ymin + 2;
+            fb.idx0 = fb.nidx = 0, fb.interior = 1;
+            fb.magic = kChunkMagic.v[min(fb.cpr, kMaxCpr)];  // (cpr > kMaxCpr: the box does not fit, magic unused)
+            if (box_fits(fb, src, spitch, 4 * NT, kBoxBytes / 4)) {
+                ChunkMap M;
+                Staged S;
+                // (this kernel is VALU-bound: boxes of at most two chunks per thread -- nearly all --
+                // skip the other two slots with a scalar branch)
+                if (fb.nrows * fb.cpr <= 2 * NT && !box_touches_image_end(fb, g)) {
+                    make_chunk_map<NT, 2>(fb, tid, M);
+                    stage_load<false, false, 2>(M, src, spitch, src_bytes, S);
+                    stage_store<2>(M, S, boxw);
+                } else {
+                    make_chunk_map<NT>(fb, tid, M);
+                    if (box_touches_image_end(fb, g))
+                        stage_load<true, false>(M, src, spitch, src_bytes, S);
+                    else
+                        stage_load<false, false>(M, src, spitch, src_bytes, S);
+                    stage_store(M, S, boxw);
+                }
+                __syncthreads();
+                Taps2 T;
+                uint32_t pix[kPX];
+                read_taps_lds<true>(L, fb, boxw, T);
+                blend_taps(T, L, pix);
+                store_interior(ua, z, t, pix);
+            } else {  // box too large for LDS (strong minification): gather from global memory
+                sample_and_store<K>(c, ua, z, t, L, fb, false, boxw, wtab, src, spitch);
+            }
+            return;
+        }
+        __syncthreads();  // `red` is reused below
+    }
+    lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+    const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
+    const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
+    if (use_lds) {
+        ChunkMap M;
+        make_chunk_map<NT>(b, tid, M);
+        Staged S;
+        stage_load<true, true>(M, src, spitch, src_bytes, S);
+        stage_store(M, S, boxw);
+    }
+    __syncthreads();
+    if (L.ok != (1u << t.npx) - 1)
+        c.tile_flags[t.flag_tile] = 1;
+    sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, wtab, src, spitch);
+}
+
 // BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes, coordinates shared by `upb` units.
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
@@ -1395,84 +1476,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
                                                          half_dwords, tabw, wtab);
     } else {
         __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
-        const Geom& g = c.g;
-        const RayParams& P = c.ray;
-        const int tid = threadIdx.x;
-        const int z = blockIdx.z;
         // (natural tile order unless the host passes strips: with one block of tiles per XCD the swizzle measured 6 % slower on C5)
         int btx = blockIdx.x, bty = blockIdx.y;
         if (strip_len)
             xcd_tile(tiles_x_magic, strip_len, strip_magic, btx, bty);
-        const TileIds t = tile_ids(g, z, tid, btx, bty, gridDim.x, NT / kLanesX);
-        const uint8_t* __restrict__ src = ua.u[z].src;
-        const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
-        const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
-        RowCol rc;
-        load_rowcol<ROT>(P, t.xc, t.jc, rc);
-        LaneCoords L;
-        // Fast attempt (bilinear, OWN = 0: the host proved that no pixel of these units leaves the
-        // validated part of the radial table): coordinates without any validity logic, bounding box
-        // of all 1024 pixels, and if that box lies inside the source the tile is "interior" --
-        // unpredicated taps, unconditional stores.  Anything else (tiles cut by the destination's
-        // edge, footprints leaving the source) falls through to the general code below.
-        // PAIR doubles as "the m-polynomial table is valid for every unit of this launch" here.
-        const bool tile_full = ((btx + 1) * kTW <= g.dst_w) & ((bty + 1) * (NT / kLanesX) <= g.dst_h);
-        if (K == 2 && OWN == 0 && tile_full) {
-            if (PAIR)
-                lane_coords<VAR_W, ROT, K, 0, 2, 1>(c, ua, z, rc, kPX, P.radial_m, 0, P.n_int, L);
-            else
-                lane_coords<VAR_W, ROT, K, 0, 2, 0>(c, ua, z, rc, kPX, P.radial, 0, P.n_int, L);
-            const BoxAll ba = reduce_box_all<NT / 64>(L, red, tid);
-            if ((ba.xmin >= 0) & (ba.xmax < g.src_w - 2) & (ba.ymin >= 0) & (ba.ymax < g.src_h - 1)) {
-                TileBox fb;
-                fb.x0 = ba.xmin & ~3, fb.y0 = ba.ymin;
-                fb.cpr = (ba.xmax + 2 - fb.x0 + 3) >> 2, fb.nrows = ba.ymax - ba.ymin + 2;
-                fb.idx0 = fb.nidx = 0, fb.interior = 1;
-                fb.magic = kChunkMagic.v[min(fb.cpr, kMaxCpr)];  // (cpr > kMaxCpr: the box does not fit, magic unused)
-                if (box_fits(fb, src, spitch, 4 * NT, kBoxBytes / 4)) {
-                    ChunkMap M;
-                    Staged S;
-                    // (this kernel is VALU-bound: boxes of at most two chunks per thread -- nearly all --
-                    // skip the other two slots with a scalar branch)
-                    if (fb.nrows * fb.cpr <= 2 * NT && !box_touches_image_end(fb, g)) {
-                        make_chunk_map<NT, 2>(fb, tid, M);
-                        stage_load<false, false, 2>(M, src, spitch, src_bytes, S);
-                        stage_store<2>(M, S, boxw);
-                    } else {
-                        make_chunk_map<NT>(fb, tid, M);
-                        if (box_touches_image_end(fb, g))
-                            stage_load<true, false>(M, src, spitch, src_bytes, S);
-                        else
-                            stage_load<false, false>(M, src, spitch, src_bytes, S);
-                        stage_store(M, S, boxw);
-                    }
-                    __syncthreads();
-                    Taps2 T;
-                    uint32_t pix[kPX];
-                    read_taps_lds<true>(L, fb, boxw, T);
-                    blend_taps(T, L, pix);
-                    store_interior(ua, z, t, pix);
-                } else {  // box too large for LDS (strong minification): gather from global memory
-                    sample_and_store<K>(c, ua, z, t, L, fb, false, boxw, wtab, src, spitch);
-                }
-                return;
-            }
-            __syncthreads();  // `red` is reused below
-        }
-        lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
-        const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
-        const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
-        if (use_lds) {
-            ChunkMap M;
-            make_chunk_map<NT>(b, tid, M);
-            Staged S;
-            stage_load<true, true>(M, src, spitch, src_bytes, S);
-            stage_store(M, S, boxw);
-        }
-        __syncthreads();
-        if (L.ok != (1u << t.npx) - 1)
-            c.tile_flags[t.flag_tile] = 1;
-        sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, wtab, src, spitch);
+        rot_unit_tile<VAR_W, ROT, K, OWN, PAIR>(c, ua, (int)blockIdx.z, btx, bty, red, boxw, wtab);
     }
 }
 
@@ -2153,6 +2161,158 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     }
 }
 
+// ---- units that override the rotation (per-frame calibration, BASELINE config 5): two units per workgroup, boxes by LDS-DMA ----
+// k_ray_lin3_tile<..., BOXES = 0> serves such a unit with one workgroup per tile: coordinates -> box (reduction) -> register-staged
+// box -> barrier -> taps, a serial chain whose loads nothing of its own overlaps, with 60 VALU instructions of staging per lane
+// (chunk map, v_perm expansion to BGRx, ds_write_b128).  Here a workgroup serves the tile for TWO units (the two eyes of a
+// frame: units 2 z, 2 z + 1 of the launch) and brings the boxes in by LDS-DMA as they are in memory:
+//   coordinates A -> box A -> request A | coordinates B -> box B -> request B | taps + blend + store A | taps + blend + store B
+// so A's box flies behind B's coordinates and B's behind A's sampling; the row / column table values and the prologue are
+// paid once for the two.  Bilinear, OWN = 0 (the host proved that no ray of these units leaves the validated part of the radial
+// table), full tiles whose box lies inside the source and fits a buffer; every other (unit, tile) goes through rot_unit_tile.
+// Waits: a box is followed by at least the other unit's requests / by the first unit's store (lower bounds: loads the
+// coordinates make in between only make a wait longer).
+#ifndef V1C_ROTPAIR_WAVES
+#define V1C_ROTPAIR_WAVES 5
+#endif
+constexpr int kRotPairRedInts = 32;
+
+struct RawBox {  // a TileBox's geometry for raw_box_dma / the gather
+    int x0, y0, cpr, nrows;
+};
+
+// reduce_box_all without __syncthreads()' fence (which waits for every request in flight): LDS writes are waited for, then a bare barrier
+template <int NW>
+__device__ __forceinline__ BoxAll reduce_box_all_nofence(const LaneCoords& L, int* red, int tid)
+{
+    const int a = min(min(L.sx[0], L.sx[1]), min(L.sx[2], L.sx[3]));
+    const int b = min(min(L.sy[0], L.sy[1]), min(L.sy[2], L.sy[3]));
+    const int c = -max(max(L.sx[0], L.sx[1]), max(L.sx[2], L.sx[3]));
+    const int d = -max(max(L.sy[0], L.sy[1]), max(L.sy[2], L.sy[3]));
+    const auto ab = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    const auto cd = __builtin_amdgcn_permlane32_swap((unsigned)c, (unsigned)d, false, false);
+    const int pab = min((int)ab[0], (int)ab[1]), pcd = min((int)cd[0], (int)cd[1]);
+    const auto q = __builtin_amdgcn_permlane16_swap((unsigned)pab, (unsigned)pcd, false, false);
+    int v = min((int)q[0], (int)q[1]);
+    v = row_min_step<0x121>(v);
+    v = row_min_step<0x122>(v);
+    v = row_min_step<0x124>(v);
+    v = row_min_step<0x128>(v);
+    if ((tid & 15) == 0)
+        red[(tid >> 6) * 4 + ((tid >> 4) & 3)] = v;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int m0 = red[0], m1 = red[1], m2 = red[2], m3 = red[3];
+#pragma unroll
+    for (int w = 1; w < NW; w++)
+        m0 = min(m0, red[4 * w]), m1 = min(m1, red[4 * w + 1]), m2 = min(m2, red[4 * w + 2]), m3 = min(m3, red[4 * w + 3]);
+    BoxAll r;
+    r.xmin = __builtin_amdgcn_readfirstlane(m0) >> 5;
+    r.xmax = (-__builtin_amdgcn_readfirstlane(m1)) >> 5;
+    r.ymin = __builtin_amdgcn_readfirstlane(m2) >> 5;
+    r.ymax = (-__builtin_amdgcn_readfirstlane(m3)) >> 5;
+    return r;
+}
+
+// taps of a lane's 4 pixels from ONE raw box at LDS byte address `raw`
+__device__ __forceinline__ void gather_one_raw(const TileBox& b, uint32_t raw, const int (&sx)[kPX], const int (&sy)[kPX], uint32_t (&pix)[kPX])
+{
+    const uint32_t pitch = (uint32_t)raw_units_per_row(b.cpr) * 16u;
+    const uint32_t base0 = raw - ((uint32_t)b.y0 * pitch + (uint32_t)b.x0 * 3u);
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        const uint32_t ix = (uint32_t)sx[k] >> 5;
+        const uint32_t a = __umul24((uint32_t)(sy[k] >> 5), pitch) + (ix * 2u + ix) + base0;
+        const uint32_t d = a & ~3u;
+        const lds_u32_ptr r0 = (lds_u32_ptr)(uintptr_t)d, r1 = (lds_u32_ptr)(uintptr_t)(d + pitch);
+        const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+        pix[k] = blend3<3>(__builtin_amdgcn_alignbyte(a1, a0, a), __builtin_amdgcn_alignbyte(a2, a1, a), __builtin_amdgcn_alignbyte(b1, b0, a),
+                           __builtin_amdgcn_alignbyte(b2, b1, a), blend_weights(sx[k], sy[k]));
+    }
+}
+
+template <int VAR_W, int MP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR_WAVES, 8))) void k_ray_lin3_rot_pair_raw(
+    KernelCtx c, UnitArgs ua, int n_units, int slot_bytes, unsigned tiles_x_magic, unsigned strip_len, unsigned strip_magic)
+{
+    constexpr int NT = 256;
+    // dynamic LDS: two box buffers of slot_bytes (rot_unit_tile: its BGRx box of kBoxBytes + 16) | kRotPairRedInts ints
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    const int tid = threadIdx.x;
+    int btx = blockIdx.x, bty = blockIdx.y;
+    if (strip_len)
+        xcd_tile(tiles_x_magic, strip_len, strip_magic, btx, bty);
+    const int zA = 2 * (int)blockIdx.z, zB = zA + 1;
+    const bool hasB = zB < n_units;
+    const uint32_t red_off = (uint32_t)max(2 * slot_bytes, kBoxBytes + 16);
+    int* red = (int*)((uint8_t*)dyn_box + red_off);
+    const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
+    const bool tile_full = ((btx + 1) * kTW <= g.dst_w) & ((bty + 1) * (NT / kLanesX) <= g.dst_h);
+    if (!tile_full) {
+        rot_unit_tile<VAR_W, 1, 2, 0, MP>(c, ua, zA, btx, bty, red, dyn_box, wtab);
+        if (hasB) {
+            __syncthreads();
+            rot_unit_tile<VAR_W, 1, 2, 0, MP>(c, ua, zB, btx, bty, red, dyn_box, wtab);
+        }
+        return;
+    }
+    const TileIds t = tile_ids(g, zA, tid, btx, bty, gridDim.x, NT / kLanesX);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box;
+    RowCol rc;
+    load_rowcol<1>(P, t.xc, t.jc, rc);
+    // box of all 1024 pixels of a unit -> is the tile interior, does its raw box fit a buffer
+    auto raw_box = [&](const BoxAll& ba, int z, TileBox& b) -> bool {
+        b.x0 = ba.xmin & ~3, b.y0 = ba.ymin;
+        b.cpr = (ba.xmax + 2 - b.x0 + 3) >> 2, b.nrows = ba.ymax - ba.ymin + 2;
+        b.idx0 = b.nidx = 0, b.interior = 1, b.magic = 0;
+        const int upr = raw_units_per_row(b.cpr);
+        const bool inside = (ba.xmin >= 0) & (ba.xmax < g.src_w - 2) & (ba.ymin >= 0) & (ba.ymax < g.src_h - 1);
+        const bool aligned = ((((uintptr_t)ua.u[z].src) | (uintptr_t)ua.u[z].src_pitch) & 3u) == 0;
+        return inside & aligned & (b.cpr <= kMaxCpr) & (b.nrows * upr * 16 <= slot_bytes) &
+               !((b.y0 + b.nrows >= g.src_h) & (b.x0 * 3 + upr * 16 > g.src_w * 3));
+    };
+    LaneCoords LA, LB;
+    TileBox bA, bB;
+    bool fastA, fastB = false;
+    int nB = 0;
+    lane_coords<VAR_W, 1, 2, 0, 2, MP>(c, ua, zA, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LA);
+    fastA = raw_box(reduce_box_all_nofence<NT / 64>(LA, red, tid), zA, bA);
+    if (fastA) {
+        const RawLanes m = raw_lanes(bA.cpr, lane);
+        raw_box_dma(bA, m, ua.u[zA].src, (uint32_t)ua.u[zA].src_pitch, lane, wave, lds0);
+    }
+    if (hasB) {
+        lane_coords<VAR_W, 1, 2, 0, 2, MP>(c, ua, zB, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
+        fastB = raw_box(reduce_box_all_nofence<NT / 64>(LB, red + 16, tid), zB, bB);
+        if (fastB) {
+            const RawLanes m = raw_lanes(bB.cpr, lane);
+            nB = raw_box_dma(bB, m, ua.u[zB].src, (uint32_t)ua.u[zB].src_pitch, lane, wave, lds0 + (uint32_t)slot_bytes);
+        }
+    }
+    uint32_t pix[kPX];
+    if (fastA) {
+        wait_vm_barrier(nB);  // A's box: behind it at least B's requests
+        gather_one_raw(bA, lds0, LA.sx, LA.sy, pix);
+        store_interior(ua, zA, t, pix);
+    }
+    if (fastB) {
+        wait_vm_barrier(fastA ? 1 : 0);  // B's box: behind it at least A's store
+        gather_one_raw(bB, lds0 + (uint32_t)slot_bytes, LB.sx, LB.sy, pix);
+        store_interior(ua, zB, t, pix);
+    }
+    // the rest (rare: rays leaving the source, boxes beyond a buffer): one unit at a time through the general code
+    if (!fastA) {
+        __syncthreads();
+        rot_unit_tile<VAR_W, 1, 2, 0, MP>(c, ua, zA, btx, bty, red, dyn_box, wtab);
+    }
+    if (hasB && !fastB) {
+        __syncthreads();
+        rot_unit_tile<VAR_W, 1, 2, 0, MP>(c, ua, zB, btx, bty, red, dyn_box, wtab);
+    }
+}
+
 static int taps_of(int interp)
 {
     return interp == V1C_INTER_LINEAR ? 2 : interp == V1C_INTER_CUBIC ? 4 : interp == V1C_INTER_LANCZOS4 ? 8 : 0;
@@ -2571,6 +2731,36 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     const unsigned slen = bx ? (strip_len > 0 && (unsigned)strip_len < ((grid.x * grid.y) >> 3) ? (unsigned)strip_len : 0u)
                              : (nobox_strip_rows * grid.x < ((grid.x * grid.y) >> 3) ? nobox_strip_rows * grid.x : 0u);
     const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    // units that override the rotation, bilinear, OWN = 0: two units per workgroup with their boxes by LDS-DMA (V1C_ROT_PAIR=0: A/B
+    // switch, the one-unit-per-workgroup kernel)
+    static const bool rot_pair_off = [] {
+        const char* e = tuning_env("V1C_ROT_PAIR");
+        return e && e[0] == '0';
+    }();
+    static const int rot_pair_slot = [] {  // V1C_ROT_PAIR_SLOT=<bytes>: box buffer size (A/B)
+        const char* e = tuning_env("V1C_ROT_PAIR_SLOT");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 1024 ? (v & ~15) : 12288;
+    }();
+    if constexpr (K == 2) {
+        if (!bx && shared_entry && !rot_pair_off) {
+            const dim3 pgrid(grid.x, grid.y, (unsigned)((n_units + 1) / 2));
+            const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int);
+            const bool mp = mpoly_all && c.ray.radial_m != nullptr;
+            if (c.ray.var_is_w) {
+                if (mp)
+                    hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<1, 1>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic);
+                else
+                    hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<1, 0>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic);
+            } else {
+                if (mp)
+                    hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<0, 1>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic);
+                else
+                    hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<0, 0>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic);
+            }
+            return;
+        }
+    }
     // Only combinations a plan can select are instantiated: the lean batch kernel and the tile-list form exist for
     // bilinear plans with boxes; launches without boxes (units that override the rotation) always rotate.
 #define V1C_TILE_P(VW, RT, BX, OW, PR)                                                                                                \
