@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/vr180_remap.h"
@@ -183,6 +184,32 @@ inline bool solve_vandermonde(int n, const long double* z, const long double* y,
     return true;
 }
 
+// The intervals of a table are fitted independently (long-double Vandermonde solve + validation of the double Horner: ~40 us
+// each, 1024 of them, up to three tables per plan = the 50 ms a first call used to cost): intervals dealt to up to 16 host
+// threads.  The result does not depend on the thread count (no interval reads another's).
+template <typename F>
+inline void fit_parallel_for(int n, F&& body)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::min<unsigned>(std::min<unsigned>(hw ? hw : 1u, 16u), (unsigned)std::max(n / 32, 1));
+    if (nt <= 1) {
+        for (int i = 0; i < n; i++)
+            body(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nt - 1);
+    auto run = [&](int t) {
+        for (int i = t; i < n; i += nt)  // (interleaved: the intervals that need three attempts cluster)
+            body(i);
+    };
+    for (int t = 1; t < nt; t++)
+        pool.emplace_back(run, t);
+    run(0);
+    for (auto& th : pool)
+        th.join();
+}
+
 // Fit one table.  Every interval i (table variable u in [i, i+1) * step, z = u / step - (i + 0.5))
 // gets the polynomial of the WIDEST range that validates:
 //   level 2: |z| <= 2.5   level 1: |z| <= 1.5   level 0: |z| <= 0.5 (its own interval only)
@@ -208,7 +235,8 @@ inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w,
     for (int k = 0; k < n; k++)
         cheb[k] = cosl(M_PIl * (2 * k + 1) / (2.0L * n));  // Chebyshev nodes on [-1, 1]
     const double tol = 1.5e-15;
-    for (int i = 0; i < T.n_int; i++) {
+    std::vector<signed char> levels(T.n_int, -1);
+    fit_parallel_for(T.n_int, [&](int i) {
         const long double a = i * step;
         double cd[16];
         int level = -1;
@@ -247,16 +275,20 @@ inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w,
             if (good)
                 level = lv;
         }
+        levels[i] = (signed char)level;
+        if (level >= 0)
+            for (int k = 0; k < n; k++)
+                T.coef[(size_t)i * n + k] = cd[k];
+    });
+    for (int i = 0; i < T.n_int; i++) {
+        const int level = levels[i];
         for (int lv = 0; lv < 3; lv++)
             if (level < lv && T.first_below_level[lv] == T.n_int)
                 T.first_below_level[lv] = i;
-        if (level >= 0) {
-            for (int k = 0; k < n; k++)
-                T.coef[(size_t)i * n + k] = cd[k];
+        if (level >= 0)
             T.n_extended += level >= 1;
-        } else {
+        else
             T.n_invalid++;
-        }
     }
     T.first_invalid = T.first_below_level[0];
     return T;
@@ -289,7 +321,7 @@ inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTab
     const double tol = 1.5e-15;
     // table variable u (w or m) -> m
     auto m_of_u = [&](long double u) { return T.var_is_w ? 2 * u * u : u; };
-    for (int i = 0; i < n_int; i++) {
+    fit_parallel_for(n_int, [&](int i) {
         const long double uc = (i + 0.5L) * step;
         const double mc = (double)m_of_u(uc);  // the double the kernel subtracts
         for (int lv = 2; lv >= 0 && M.level[i] < 0; lv--) {
@@ -340,7 +372,7 @@ inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTab
                 M.coef[(size_t)i * kRadialCoefs + kRadialCoefs - 1] = mc;
             }
         }
-    }
+    });
     return M;
 }
 
