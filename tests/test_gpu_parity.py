@@ -1180,6 +1180,27 @@ def test_mirror_pair_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radiu
         assert np.array_equal(got, want), (spec, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("src_hw,out_wh,radius", [((300, 300), (256, 96), 150.0), ((512, 640), (320, 352), 250.0),
+                                                  ((1000, 1000), (1028, 512), 470.0), ((700, 700), (512, 480), 350.0),
+                                                  ((1800, 1800), (256, 256), 900.0), ((120, 120), (1024, 512), 60.0)])
+def test_mirror_single_image_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radius):
+    """apply() of ONE image of an unrotated bilinear chain (BASELINE config 1) takes the one-eye instantiation of
+    k_ray_lin3_pair_mirror_raw (tile + mirror image from one set of coordinates, two boxes by LDS-DMA): every byte vs the
+    oracle on the pair launch's geometries, m-table and w-table chains, a pitched source view."""
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    wide = noise_disc(src_hw[0], src_hw[1] + 8, 23)
+    img = wide[:, 4:4 + src_hw[1]]  # a column slice: pitch != 3 * width, rows dword-aligned (12-byte shift)
+    for spec in ([("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]):
+        want = O.apply(spec, [np.ascontiguousarray(img)], size_output=out_wh, interpolation=1, radius=radius, border_value=(5, 6, 7))[0]
+        src = torch.from_numpy(wide).to(dev)[:, 4:4 + src_hw[1]]
+        dst = torch.empty((out_wh[1], out_wh[0], 3), dtype=torch.uint8, device=dev)
+        V.remap_tensors(CS.to_product(spec), [src], [dst], radius=radius, interpolation=1, boarder_value=(5, 6, 7))
+        got = dst.cpu().numpy()
+        assert np.array_equal(got, want), (spec, int((got != want).sum()))
+
+
 def test_remap_sharded_splits_rows_when_devices_outnumber_eyes(V, oracle_mod):
     """a single pair on 4 / 8 GPUs = bands of output rows per GPU (each needs the whole source eye, no
     exchange).  Eight workers on the one card of the test box: 2 eyes x 4 bands, assembled rows equal the oracle's."""

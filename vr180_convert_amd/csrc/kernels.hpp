@@ -55,7 +55,8 @@ int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, cons
 // `pipe_tab` > 0: k_ray_lin3_pair_mirror_pipe (two tile rows per workgroup, the second pair's boxes requested while the first is
 // sampled), tile_mirror_pipe_tab() table entries per pair in LDS
 hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
-                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream);
+                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream,
+                                       int n_eyes = 2);  // n_eyes = 1 (raw_nwp > 0): a single image through the same workgroups
 int tile_mirror_pipe_tab(const void* host_boxes, const void* host_mboxes, const Geom& g, int raw_nwp);
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,

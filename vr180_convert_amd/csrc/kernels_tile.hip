@@ -1771,7 +1771,11 @@ __device__ __forceinline__ void store_pair_row(const UnitArgs& ua, const TileIds
     store4(ua.u[1].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix1, 0xFu, dst_rows_dword_aligned(ua, 1));
 }
 
-template <int VAR_W>
+// NE = number of eyes (units) of the launch: 2 = apply_lr's pair; 1 = a single image (apply() of one image, BASELINE config 1):
+// the same workgroup with two boxes instead of four
+__device__ __forceinline__ void gather_one_raw(const TileBox& b, uint32_t raw, const int (&sx)[kPX], const int (&sy)[kPX], uint32_t (&pix)[kPX]);
+
+template <int VAR_W, int NE = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAVES, 8))) void k_ray_lin3_pair_mirror_raw(
     KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
     unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp,
@@ -1788,7 +1792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
         if (lin >= (unsigned)n_rest)
             return;
         const uint32_t v = rest_list[lin];
-        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
+        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, NE, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
                                                   tabw, (glb_u32_ptr)c.itab);
         return;
     }
@@ -1802,8 +1806,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     RowCol rc;
     load_rowcol<0>(P, t.xc, t.jc, rc);
     const uint8_t* __restrict__ src0 = ua.u[0].src;
-    const uint8_t* __restrict__ src1 = ua.u[1].src;
-    const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[1].src_pitch;
+    const uint8_t* __restrict__ src1 = ua.u[NE - 1].src;
+    const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[NE - 1].src_pitch;
     const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
     if (!mirror_raw_static_ok(b, q, nwp, g.src_h, g.src_w))
         return;
@@ -1816,7 +1820,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     asm volatile("" ::"v"(rc.sl), "v"(rc.cl), "v"(rc.hl));
     const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
     const uint32_t box_bytes = (uint32_t)nwp * 1024u;
-    const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + 2u * box_bytes;
+    const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + (uint32_t)NE * box_bytes;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {  // table slice: nidx * 4 units of 16 bytes, one pass (units past the slice: clamped, they land in the unused tail of tabw)
         const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
@@ -1825,25 +1829,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     }
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
     const int nb = raw_box_dma(b, mb, src0, pitch0, lane, wave, raw_b);  // this wave's requests per box of the tile ...
-    raw_box_dma(b, mb, src1, pitch1, lane, wave, raw_b + box_bytes);
+    if (NE == 2)
+        raw_box_dma(b, mb, src1, pitch1, lane, wave, raw_b + box_bytes);
     const int nq = raw_box_dma(q, mq, src0, pitch0, lane, wave, raw_q);  // ... and of the mirrored band
-    raw_box_dma(q, mq, src1, pitch1, lane, wave, raw_q + box_bytes);
+    if (NE == 2)
+        raw_box_dma(q, mq, src1, pitch1, lane, wave, raw_q + box_bytes);
     // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
     // what the barrier publishes -- vmcnt counts in issue order -- then joins.
-    wait_vm_barrier(2 * nb + 2 * nq);  // table slice landed (this wave's box loads may still be in flight)
+    wait_vm_barrier(NE * (nb + nq));  // table slice landed (this wave's box loads may still be in flight)
     LaneCoords L;
     if (mpoly)
         lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     else
         lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
-    wait_vm_barrier(2 * nq);  // the tile's two boxes
+    wait_vm_barrier(NE * nq);  // the tile's boxes
     uint32_t p0[kPX], p1[kPX];
-    gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
-    // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
-    wait_vm_barrier(0);
-    store_pair_row(ua, t, t.j, p0, p1);
-    gather_pair_raw(q, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
-    store_pair_row(ua, t, mirror_h - t.j, p0, p1);
+    if constexpr (NE == 2) {
+        gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
+        // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
+        wait_vm_barrier(0);
+        store_pair_row(ua, t, t.j, p0, p1);
+        gather_pair_raw(q, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
+        store_pair_row(ua, t, mirror_h - t.j, p0, p1);
+    } else {
+        const uint32_t row_off = (uint32_t)t.x0 * 3u;
+        gather_one_raw(b, raw_b, L.sx, L.sy, p0);
+        wait_vm_barrier(0);
+        store4(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), p0, 0xFu, dst_rows_dword_aligned(ua, 0));
+        gather_one_raw(q, raw_q, L.sx, L.sy2, p1);
+        store4(ua.u[0].dst + (__umul24((uint32_t)(mirror_h - t.j), (uint32_t)ua.u[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(ua, 0));
+    }
 }
 
 // ---- two tile pairs per workgroup: the second pair's boxes are in flight while the first one is sampled ----
@@ -2422,7 +2437,8 @@ int tile_mirror_pipe_tab(const void* host_boxes, const void* host_mboxes, const 
 
 // `pipe_tab` > 0 (with raw_nwp > 0): k_ray_lin3_pair_mirror_pipe, two tile rows per workgroup, pipe_tab table entries per pair in LDS
 hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
-                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream)
+                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream,
+                                       int n_eyes)
 {
     const dim3 full = tile_grid(c.g, 256, 1);
     const dim3 grid(full.x, full.y / 2 - 1, 2), block(256, 1, 1);
@@ -2441,6 +2457,17 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     }();
     if (block_rows && grid.x % 8 == 0 && raw_nwp > 0)
         slen = 0x80000000u | std::min(block_rows, 0xffffu);
+    if (raw_nwp > 0 && n_eyes == 1) {  // a single image: the LDS-DMA kernel's one-eye instantiation
+        const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
+        const dim3 rgrid(full.x, grid.y + rest_rows, 1);
+        if (c.ray.var_is_w)
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1, 1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);
+        else
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0, 1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);
+        return hipGetLastError();
+    }
     if (raw_nwp > 0 && pipe_tab > 0) {
         // group rows: rows2 of them serve two tile rows, the last n1 one tile row each -- by default about one round of resident
         // workgroups (6 per CU), so that the launch ends on short workgroups; V1C_PIPE_SINGLE_ROWS=<n>: A/B override

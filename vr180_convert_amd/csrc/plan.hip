@@ -661,12 +661,14 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                     HIP_TRY(hipStreamWaitEvent(st, p->flags_ev, 0));
             }
             // a pair (apply_lr) of an unrotated chain: the tile + mirror-image launch
-            bool mirror = fast && n == 2 && !any_rot && p->mirror_boxes != nullptr && shared_entry && !p->disable_shared_entry;
+            // (a single image -- apply() of one image, BASELINE config 1 -- takes the LDS-DMA form's one-eye instantiation)
+            bool mirror = fast && (n == 2 || (n == 1 && p->mirror_raw_nwp > 0)) && !any_rot && p->mirror_boxes != nullptr && shared_entry &&
+                          !p->disable_shared_entry;
             for (int k = 0; k < n && mirror; k++)
                 mirror = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
             if (mirror) {
                 HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h, p->mirror_rest,
-                                                    p->n_mirror_rest, p->mirror_raw_nwp, p->mirror_pipe_tab, st));
+                                                    p->n_mirror_rest, p->mirror_raw_nwp, p->mirror_pipe_tab, st, n));
             } else if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
