@@ -69,6 +69,9 @@ WORKLOADS = {
     # (not a BASELINE config: a rotated bilinear pair -- the pair kernels the unrotated configs above do not reach; tools/ab.sh)
     "C2R": dict(size=4096, poly=[0, 1, -0.1], rot="ry45", interp=1,
                 desc="L+R 4096x4096 -> 8192x4096 SBS, Euler rotation + PolynomialScaler, bilinear (A/B only)"),
+    "C2NN": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=0,
+                 desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_NEAREST (not a BASELINE config: the bilinear tile kernels "
+                      "with coordinates 32 * cvRound(x))"),
     "C2N": dict(size=4080, poly=[0, 1, -0.1], rot=None, interp=1,
                 desc="L+R 4080x4080 -> 8160x4080 SBS (rows do not mirror about a tile boundary), bilinear (A/B only)"),
     # batch shapes: `frames` SBS frames per GPU per step (BASELINE configs 3 and 5 shard 8 resp. 32 per GPU)

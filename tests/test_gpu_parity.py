@@ -143,10 +143,11 @@ def test_fused_apply_bit_exact_vs_oracle(V, oracle_mod, dev, name):
 
 
 @pytest.mark.parametrize("border", [1, 2, 3, 4])
-@pytest.mark.parametrize("interp", [1, 2, 4])
+@pytest.mark.parametrize("interp", [0, 1, 2, 4])
 def test_tile_kernels_other_border_modes(V, oracle_mod, dev, interp, border):
     """REPLICATE / REFLECT / WRAP / REFLECT_101 run the tile kernels too (the border only matters to
-    pixels whose footprint leaves the source): a zoomed-out chain puts a third of the output outside."""
+    pixels whose footprint leaves the source): a zoomed-out chain puts a third of the output outside.
+    INTER_NEAREST (0) rides the bilinear tile kernels with coordinates 32 * cvRound(x) (lane_coords<..., NN = 1>)."""
     from vr180_convert_amd.synth import noise_disc
 
     size = 200
@@ -159,6 +160,43 @@ def test_tile_kernels_other_border_modes(V, oracle_mod, dev, interp, border):
     want = oracle_mod.apply(spec, imgs, size_output=(277, 231), interpolation=interp, border_mode=border, radius=size / 2)
     for d, w in zip(dsts, want):
         assert np.array_equal(d.cpu().numpy(), w), (interp, border, int((d.cpu().numpy() != w).sum()))
+
+
+def test_nearest_through_the_tile_kernels(V, oracle_mod, dev):
+    """INTER_NEAREST on the fused path: pairs (apply_lr), a batch sharing one map, per-unit rotations, a pitched view and a
+    half-pixel-exact identity map (ties go to even) -- every byte against the oracle's remapNearest."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    n = 448
+    left, right = noise_disc(n, n, 51), noise_disc(n, n, 52)
+    for spec in ([("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI],
+                 [("equirect_enc", True), ("rot", CS.ry(0.3)), ("poly", [0, 1, -0.1]), CS.EQUI]):
+        for border, bval in ((0, (9, 8, 7)), (1, 0)):
+            want = O.apply_lr(spec, left, right, size_output=(512, 384), interpolation=0, radius="max", border_mode=border, border_value=bval)
+            got = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev), size_output=(512, 384),
+                                     interpolation=0, radius="max", boarder_mode=border, boarder_value=bval).cpu().numpy()
+            assert np.array_equal(got, want), (spec, border, int((got != want).sum()))
+    # a batch of 5 units sharing the map (general batch loop), sources = halves of SBS frames (pitched views)
+    frames = [noise_disc(200, 400, 60 + f) for f in range(3)]
+    imgs = [fr[:, e * 200:(e + 1) * 200] for fr in frames for e in (0, 1)][:5]
+    spec = [("equirect_enc", True), CS.EQUI]
+    dev_frames = [torch.from_numpy(fr).to(dev) for fr in frames]
+    srcs = [dev_frames[k // 2][:, (k % 2) * 200:(k % 2 + 1) * 200] for k in range(5)]
+    dsts = [torch.empty((192, 256, 3), dtype=torch.uint8, device=dev) for _ in range(5)]
+    assert V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=100.0, interpolation=0) == ["ray"]
+    want = O.apply(spec, [np.ascontiguousarray(i) for i in imgs], size_output=(256, 192), interpolation=0, radius=100.0)
+    for k in range(5):
+        assert np.array_equal(dsts[k].cpu().numpy(), want[k]), k
+    # per-unit calibration rotations (units that override the rotation)
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    quats = [CS.c5_spec(f // 2, f % 2)[1][1] for f in range(4)]
+    dsts = [torch.empty((200, 200, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
+    V.remap_tensors(base, srcs[:4], dsts, radius=100.0, interpolation=0, rotations=quats)
+    for f in range(4):
+        want = O.apply(CS.c5_spec(f // 2, f % 2), [np.ascontiguousarray(imgs[f])], size_output=(200, 200), interpolation=0, radius=100.0)[0]
+        assert np.array_equal(dsts[f].cpu().numpy(), want), f
 
 
 def test_seeded_random_cases_bit_exact(V, oracle_mod, dev):

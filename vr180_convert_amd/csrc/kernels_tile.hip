@@ -183,7 +183,13 @@ __device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, 
 // about the equator (row 2 * norm_cy - j): there sin(lat) changes sign and nothing else does (the host's row tables
 // are exactly antisymmetric / symmetric), so m, G and x are the same numbers and y32' = fma(G, -ky, cy32) -- bit for
 // bit what the mirrored row's own evaluation gives.
-template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, int MPOLY, int MIRROR = 0, typename TabPtr>
+// NN = 1: INTER_NEAREST through the bilinear machinery.  cv2's remapNearest reads the ONE pixel (cvRound(x), cvRound(y)) of the float32
+// coordinates (half to even, saturated to short); the kernels' fixed point is cvRound(32 x), so the lane's coordinates become
+// 32 * cvRound(x): fractions zero, for which the bilinear blend returns its top-left tap exactly ((65535 p + 32768) >> 16 == p,
+// (1024 p + 512) >> 10 == p in the border-aware sampler, whose other three taps -- pixels or border values -- carry weight 0, and whose
+// top-left tap follows borderInterpolate like remapNearest's).  The rounded pixel lies inside the bilinear footprint of the same
+// coordinate, so boxes computed with NN = 1 (k_tile_boxes) bound it.
+template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, int MPOLY, int MIRROR = 0, int NN = 0, typename TabPtr>
 __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, const RowCol& rc, int npx, TabPtr tab,
                                             int tab0, int tabn, LaneCoords& L)
 {
@@ -329,6 +335,11 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
             // pixels and redoes the tile with INTERIOR = 0 when it is not.
             const float ax = INTERIOR == 2 ? __builtin_amdgcn_fmed3f(fxk, -4194303.0f, 4194303.0f) : fxk;
             const float ay = INTERIOR == 2 ? __builtin_amdgcn_fmed3f(fyk, -4194303.0f, 4194303.0f) : fyk;
+            if (NN) {  // 32 * cvRound(x): x = fxk / 32 exactly (a power of two)
+                L.sx[k] = (__float_as_int(ax * 0.03125f + 12582912.0f) - 0x4B400000) * 32;
+                L.sy[k] = (__float_as_int(ay * 0.03125f + 12582912.0f) - 0x4B400000) * 32;
+                continue;
+            }
             L.sx[k] = __float_as_int(ax + 12582912.0f) - 0x4B400000;
             L.sy[k] = __float_as_int(ay + 12582912.0f) - 0x4B400000;
             if (MIRROR && !ROT)
@@ -341,8 +352,13 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
         L.ok |= okk ? 1u << k : 0u;
         // branch-free: the conversion always sees an in-range float (NaN -> clamped by med3);
         // pixels that are not `good` are never used
-        L.sx[k] = __float2int_rn(__builtin_amdgcn_fmed3f(fxk, -1073741824.0f, 1073741824.0f));
-        L.sy[k] = __float2int_rn(__builtin_amdgcn_fmed3f(fyk, -1073741824.0f, 1073741824.0f));
+        if (NN) {  // saturate_cast<short>(cvRound(x)) * 32
+            L.sx[k] = __float2int_rn(__builtin_amdgcn_fmed3f(fxk * 0.03125f, -32768.0f, 32767.0f)) * 32;
+            L.sy[k] = __float2int_rn(__builtin_amdgcn_fmed3f(fyk * 0.03125f, -32768.0f, 32767.0f)) * 32;
+        } else {
+            L.sx[k] = __float2int_rn(__builtin_amdgcn_fmed3f(fxk, -1073741824.0f, 1073741824.0f));
+            L.sy[k] = __float2int_rn(__builtin_amdgcn_fmed3f(fyk, -1073741824.0f, 1073741824.0f));
+        }
         const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
         // whole footprint inside the source (remapBilinear / remapBicubic / remapLanczos4 inlier
         // test); the bilinear path additionally wants 8 readable bytes per row for its global-memory
@@ -787,7 +803,7 @@ __device__ __forceinline__ bool box_touches_image_end(const TileBox& b, const Ge
 // OWN as in the kernel that will consume the boxes: with OWN = 0 a pixel is evaluated with pixel 1's
 // table entry, with OWN = 1 possibly with its own -- both within tolerance, but the box must
 // bound the coordinates the consumer will actually compute.
-template <int VAR_W, int ROT, int K, int NT, int OWN>
+template <int VAR_W, int ROT, int K, int NT, int OWN, int NN = 0>
 // `mirror_h` > 0: the boxes of the MIRRORED bands instead -- entry (tx, ty) describes output rows mirror_h - j for
 // the rows j of tile (tx, ty) (k_ray_lin3_pair_mirror evaluates a tile and its mirror image from one set of coordinates).
 __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes, int mirror_h)
@@ -800,7 +816,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, mirror_h > 0 ? min(max(mirror_h - t.j, 0), c.g.dst_h - 1) : t.jc, rc);
     LaneCoords L;
-    lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
+    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
     TileBox b = reduce_box<K, NW>(L, red, tid);
     int interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L.ok == 0xFu) & (L.inside == 0xFu))) ? 1 : 0;
     const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
@@ -819,7 +835,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     if (mpoly) {
         __syncthreads();  // red / red2 are reused
         LaneCoords L2;
-        lane_coords<VAR_W, ROT, K, 0, 0, 1>(c, ua, 0, rc, t.npx, c.ray.radial_m, 0, c.ray.n_int, L2);
+        lane_coords<VAR_W, ROT, K, 0, 0, 1, 0, NN>(c, ua, 0, rc, t.npx, c.ray.radial_m, 0, c.ray.n_int, L2);
         b = reduce_box<K, NW>(L2, red, tid);
         interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L2.ok == 0xFu) & (L2.inside == 0xFu)));
         interior = interior ? 3 : 0;  // (not interior any more: an ordinary tile, evaluated through w)
@@ -998,7 +1014,7 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
 // LEAN = 1 (k_ray_lin3_batch_lean): only the lean batch path below is compiled and tiles that are
 // not eligible for it (lean_static_ok) exit at once; the host launches the general kernel on the list
 // of exactly those tiles (launch_tile_k).
-template <int VAR_W, int ROT, int K, int OWN, int PAIR, int NT, int LEAN, typename WPtr>
+template <int VAR_W, int ROT, int K, int OWN, int PAIR, int NT, int LEAN, int NN = 0, typename WPtr>
 __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitArgs& ua, const TileBox* __restrict__ boxes, int n_units,
                                                 int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw, int half_dwords,
                                                 double* tabw, WPtr wtab)
@@ -1092,9 +1108,9 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
             {
                 LaneCoords L;
                 if (OWN == 0 && mpoly)
-                    lane_coords<VAR_W, ROT, K, 0, 1, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+                    lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
                 else
-                    lane_coords<VAR_W, ROT, K, OWN, 1, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+                    lane_coords<VAR_W, ROT, K, OWN, 1, 0, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
 #pragma unroll
                 for (int k = 0; k < kPX; k++) {
                     ta[k] = __umul24((L.sy[k] >> 5) - b.y0, lpw4) + (uint32_t)((L.sx[k] >> 5) - b.x0) * 4u;  // byte offset in a box buffer
@@ -1153,13 +1169,13 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         return;
     LaneCoords L;
     if (OWN == 0 && interior && mpoly)
-        lane_coords<VAR_W, ROT, K, 0, 1, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (interior)
-        lane_coords<VAR_W, ROT, K, OWN, 1, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, OWN, 1, 0, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (tab_lds)
-        lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else
-        lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
     const bool incomplete = L.ok != (1u << t.npx) - 1;
     V1C_STAMP(3);  // coordinates
 
@@ -1366,7 +1382,7 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, uns
 
 // ---- one tile of ONE unit that overrides the rotation (per-frame calibration): box reduced in-kernel, table from global memory ----
 // `red`: 16 ints of LDS, `boxw`: kBoxBytes + 16 bytes of LDS (BGRx box)
-template <int VAR_W, int ROT, int K, int OWN, int PAIR, typename WPtr>
+template <int VAR_W, int ROT, int K, int OWN, int PAIR, int NN = 0, typename WPtr>
 __device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs& ua, int z, int btx, int bty, int* red, uint32_t* boxw, WPtr wtab)
 {
     constexpr int NT = 256;
@@ -1389,9 +1405,9 @@ __device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs
     const bool tile_full = ((btx + 1) * kTW <= g.dst_w) & ((bty + 1) * (NT / kLanesX) <= g.dst_h);
     if (K == 2 && OWN == 0 && tile_full) {
         if (PAIR)
-            lane_coords<VAR_W, ROT, K, 0, 2, 1>(c, ua, z, rc, kPX, P.radial_m, 0, P.n_int, L);
+            lane_coords<VAR_W, ROT, K, 0, 2, 1, 0, NN>(c, ua, z, rc, kPX, P.radial_m, 0, P.n_int, L);
         else
-            lane_coords<VAR_W, ROT, K, 0, 2, 0>(c, ua, z, rc, kPX, P.radial, 0, P.n_int, L);
+            lane_coords<VAR_W, ROT, K, 0, 2, 0, 0, NN>(c, ua, z, rc, kPX, P.radial, 0, P.n_int, L);
         const BoxAll ba = reduce_box_all<NT / 64>(L, red, tid);
         if ((ba.xmin >= 0) & (ba.xmax < g.src_w - 2) & (ba.ymin >= 0) & (ba.ymax < g.src_h - 1)) {
             TileBox fb;
@@ -1429,7 +1445,7 @@ __device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs
         }
         __syncthreads();  // `red` is reused below
     }
-    lane_coords<VAR_W, ROT, K, OWN, 0, 0>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
     const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
     const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
     if (use_lds) {
@@ -1448,7 +1464,7 @@ __device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs
 // BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes, coordinates shared by `upb` units.
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
-template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR, int LIST = 0>
+template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR, int LIST = 0, int NN = 0>
 // LIST = 1 (BOXES = 1): blockIdx.x indexes `tile_list` (ty << 16 | tx) instead of the tile grid;
 // `tiles_x` = tile columns of the full grid then.  (A template switch rather than a null test: the
 // test split the kernel-argument loads of the prologue over two more dependent waits.)
@@ -1472,7 +1488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
         }
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
         extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT, 0>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, tiles_x, dyn_box,
+        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT, 0, NN>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, tiles_x, dyn_box,
                                                          half_dwords, tabw, wtab);
     } else {
         __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
@@ -1480,7 +1496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
         int btx = blockIdx.x, bty = blockIdx.y;
         if (strip_len)
             xcd_tile(tiles_x_magic, strip_len, strip_magic, btx, bty);
-        rot_unit_tile<VAR_W, ROT, K, OWN, PAIR>(c, ua, (int)blockIdx.z, btx, bty, red, boxw, wtab);
+        rot_unit_tile<VAR_W, ROT, K, OWN, PAIR, NN>(c, ua, (int)blockIdx.z, btx, bty, red, boxw, wtab);
     }
 }
 
@@ -2330,7 +2346,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
 
 static int taps_of(int interp)
 {
-    return interp == V1C_INTER_LINEAR ? 2 : interp == V1C_INTER_CUBIC ? 4 : interp == V1C_INTER_LANCZOS4 ? 8 : 0;
+    // (INTER_NEAREST rides the bilinear kernels: lane_coords<..., NN = 1>)
+    return (interp == V1C_INTER_LINEAR || interp == V1C_INTER_NEAREST) ? 2 : interp == V1C_INTER_CUBIC ? 4 : interp == V1C_INTER_LANCZOS4 ? 8 : 0;
 }
 
 bool tile_kernel_supports(const Geom& g)
@@ -2661,8 +2678,18 @@ static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxe
 {
     const dim3 block(NT, 1, 1), grid = tile_grid(c.g, NT, 1);
     const bool rot = c.ray.has_rot != 0;
+    const bool nn = c.g.interp == V1C_INTER_NEAREST;
 #define V1C_BOXES(VW, RT)                                                                                         \
     do {                                                                                                          \
+        if constexpr (K == 2) {                                                                                   \
+            if (nn) {                                                                                             \
+                if (shared_entry)                                                                                 \
+                    hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0, 1>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
+                else                                                                                              \
+                    hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1, 1>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
+                break;                                                                                            \
+            }                                                                                                     \
+        }                                                                                                         \
         if (shared_entry)                                                                                         \
             hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
         else                                                                                                      \
@@ -2731,7 +2758,8 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
         const char* e = tuning_env("V1C_LEAN_PAIR");
         return e && e[0] == '1';
     }();
-    bool lean = bx && K == 2 && !lean_off && rest_list != nullptr &&
+    const bool nn = c.g.interp == V1C_INTER_NEAREST;  // through k_ray_lin3_tile<..., NN = 1> only
+    bool lean = bx && K == 2 && !nn && !lean_off && rest_list != nullptr &&
                 (lean_pair ? (upb >= 2 && n_units % upb != 1) : (upb > 2 && (n_units % upb == 0 || n_units % upb > 2)));
     for (int k = 0; k < n_units && lean; k++)
         lean = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
@@ -2770,7 +2798,7 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
         return v >= 1024 ? (v & ~15) : 12288;
     }();
     if constexpr (K == 2) {
-        if (!bx && shared_entry && !rot_pair_off) {
+        if (!bx && shared_entry && !rot_pair_off && !nn) {
             const dim3 pgrid(grid.x, grid.y, (unsigned)((n_units + 1) / 2));
             const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int);
             const bool mp = mpoly_all && c.ray.radial_m != nullptr;
@@ -2808,6 +2836,13 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
                 if (n_rest > 0 && !merged)                                                                                            \
                     hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K, OW, 1, 1>), rest_grid, block, lds, stream, c, ua, bx, n_units,  \
                                        2, half_dwords, xmagic, rest_list, (int)grid.x, 0u, 0u);                                      \
+                break;                                                                                                                \
+            }                                                                                                                         \
+        }                                                                                                                             \
+        if constexpr (K == 2) {                                                                                                       \
+            if (nn) {                                                                                                                 \
+                hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR, 0, 1>), grid, block, lds, stream, c, ua, bx, n_units, upb, \
+                                   half_dwords, xmagic, (const uint32_t*)nullptr, (int)grid.x, slen, smagic);                        \
                 break;                                                                                                                \
             }                                                                                                                         \
         }                                                                                                                             \
