@@ -3,15 +3,15 @@ rules of the reference's typer app (reference cli.py:116-559; entry points ``vr1
 pyproject.toml:25-27), so that ``v1c lr left.jpg right.jpg --transformer "..."`` runs unchanged -- the remap
 itself happens on the MI355X through ``apply`` / ``apply_lr``.
 
-What needs OpenCV beyond image codecs -- AKAZE feature matching (``--automatch fm``, cli.py:255-262) and the
-point-picking window (``--automatch gui``, cli.py:82-113) -- is available when ``cv2`` is importable and reports
-a clear error otherwise; explicit points (``--automatch "x,y;x,y;..."``) need nothing.
+What needs OpenCV or libxmp beyond image codecs -- AKAZE feature matching (``--automatch fm``, cli.py:255-262), the
+point-picking window (``--automatch gui``, cli.py:82-113) and the ``xmp`` command (cli.py:439-540) -- is not mirrored (no box
+of this engine's pool could ever execute it): those options report a clear error; explicit points
+(``--automatch "x,y;x,y;..."``) need nothing.
 """
 from __future__ import annotations
 
 import hashlib
 import logging
-import re
 from datetime import datetime, timezone
 from pathlib import Path
 from typing import Any, List, Optional, Sequence
@@ -23,7 +23,7 @@ from typing_extensions import Annotated
 from . import _abi, _io
 from . import quat as _quat
 from . import transformer as _T
-from .calibration import calibration_rotators, match_lr, rotation_match, rotation_match_robust
+from .calibration import calibration_rotators, match_lr, rotation_match
 from .chain import MultiTransformer
 
 LOG = logging.getLogger(__name__)
@@ -119,48 +119,25 @@ def split_at_first_encoder(t: Any) -> tuple[MultiTransformer, MultiTransformer]:
 
 
 def _points_from_option(automatch: str, left: Path, right: Path):
-    """Matched pixel positions of the two eyes for ``--automatch``; returns (points_l, points_r, robust, extras)."""
+    """Matched pixel positions of the two eyes for ``--automatch``; returns (points_l, points_r).  The reference's ``fm`` (AKAZE
+    feature matching, remapper.py:194-248) and ``gui`` (click window, cli.py:82-113) front ends are pure OpenCV calls; no box of
+    this engine's pool has cv2 or a display, so they are not mirrored: the points are passed explicitly."""
     if automatch.startswith("fm") or automatch.startswith("gui"):
-        try:
-            import cv2 as cv  # noqa: F401
-        except Exception as e:  # noqa: BLE001
-            raise typer.BadParameter("--automatch fm / gui need OpenCV (cv2 is not installed): pass the matched "
-                                     'points explicitly, e.g. --automatch "xl,yl;xr,yr;xl,yl;xr,yr"') from e
-    if automatch.startswith("fm"):
-        from .calibration_cv import match_points  # pragma: no cover - needs cv2
-
-        m = re.match(r"fm([\d\.]+)", automatch)  # pragma: no cover
-        pl, pr, extras = match_points(_io.imread(left), _io.imread(right), scale=float(m.group(1)) if m else 1.0)  # pragma: no cover
-        return pl, pr, True, extras  # pragma: no cover
-    if automatch.startswith("gui"):
-        from .calibration_cv import pick_points  # pragma: no cover - needs cv2 and a display
-
-        m = re.match(r"gui(\d+)", automatch)  # pragma: no cover
-        flat = pick_points([left, right] * (int(m.group(1)) if m else 2))  # pragma: no cover
-    else:
-        flat = [(int(c.split(",")[0]), int(c.split(",")[1])) for c in automatch.split(";")]
-    return flat[::2], flat[1::2], False, None  # even entries: left eye, odd entries: right eye
+        raise typer.BadParameter("--automatch fm / gui need OpenCV (AKAZE matching / a click window), which this engine does not ship: "
+                                 'pass the matched points explicitly, e.g. --automatch "xl,yl;xr,yr;xl,yl;xr,yr"')
+    flat = [(int(c.split(",")[0]), int(c.split(",")[1])) for c in automatch.split(";")]
+    return flat[::2], flat[1::2]  # even entries: left eye, odd entries: right eye
 
 
-def calibrated_pair(transformer: Any, automatch: str, left: Path, right: Path, radius: Any, match_image: Path | None = None) -> tuple[Any, Any]:
+def calibrated_pair(transformer: Any, automatch: str, left: Path, right: Path, radius: Any) -> tuple[Any, Any]:
     """``--automatch``: estimate the rotation between the eyes from matched points and give each eye half of it
-    (cli.py:234-319): (left chain, right chain).  ``match_image``: where to save the picture of 100 of the kept
-    feature matches (``--savematch``, feature matching only)."""
+    (cli.py:234-319): (left chain, right chain).  A point list of the reference's ``--automatch "xl,yl;xr,yr;..."`` form takes the
+    plain least-squares fit (``rotation_match``); the robust fit (``rotation_match_robust``) belongs to the feature matcher's
+    outlier-ridden points and is available to callers of the Python API."""
     head, tail = split_at_first_encoder(transformer)
-    points_l, points_r, robust, extras = _points_from_option(automatch, left, right)
+    points_l, points_r = _points_from_option(automatch, left, right)
     vl, vr = match_lr(tail, points_l, points_r, in_paths=[left, right], radius=radius)
-    if robust:
-        q, dropped = rotation_match_robust(vl, vr)
-        if match_image is not None and extras is not None:  # pragma: no cover - needs cv2
-            import random
-
-            import cv2 as cv
-
-            kept = [m for m, bad in zip(extras["matches"], dropped) if not bad]
-            cv.imwrite(match_image.as_posix(), cv.drawMatches(extras["image_l"], extras["kp_l"], extras["image_r"], extras["kp_r"],
-                                                              random.sample(kept, min(100, len(kept))), None))
-    else:
-        q = rotation_match(vl, vr)
+    q = rotation_match(vl, vr)
     LOG.info(f"Automatched quaternion: {q}")
     q_left, q_right = calibration_rotators(q)
     return head * _T.Euclidean3DRotator(q_left) * tail, head * _T.Euclidean3DRotator(q_right) * tail
@@ -216,8 +193,7 @@ def lr(
                         r_earlier_l, swap) if name_unique else ""
     out = output_path(out_path, left_path, right_path, tag)
     if automatch != "":
-        chain = calibrated_pair(chain, automatch, left_path, right_path, radius_,
-                                out.with_suffix(f".match{out.suffix}") if savematch and automatch.startswith("fm") else None)
+        chain = calibrated_pair(chain, automatch, left_path, right_path, radius_)
         LOG.info(f"Automatched transformer: {chain}")
     apply_lr(chain, left_path=left_path, right_path=right_path, out_path=out, radius=radius_, size_output=parse_size(size),
              interpolation=interp, boarder_mode=border, boarder_value=border_value, merge=merge)
@@ -271,44 +247,8 @@ def xmp(
 ) -> None:
     """Write the left half as <name>.xmp<ext> with the right half embedded as Google VR180 photo metadata
     (GPano / GImage XMP, cli.py:439-540).  Needs python-xmp-toolkit (libxmp / exempi)."""
-    try:
-        from libxmp import XMPFiles, XMPMeta
-    except Exception as e:  # noqa: BLE001
-        raise typer.BadParameter("the xmp command needs python-xmp-toolkit (libxmp) and the exempi library") from e
-    import base64
-    import subprocess
-    import tempfile
-
-    ns_gimage, ns_gpano, ns_note = ("http://ns.google.com/photos/1.0/image/", "http://ns.google.com/photos/1.0/panorama/",
-                                    "http://ns.adobe.com/xmp/note/")
-    for p in in_paths:  # pragma: no cover - libxmp is not in the image
-        if wslpath:
-            p = Path(subprocess.run(["wslpath", "-u", "-a", str(p)], capture_output=True, check=True).stdout.decode().strip())  # noqa: S603,S607
-        image = _io.imread(p)
-        height, width = image.shape[:2]
-        left_file = p.with_suffix(f".xmp{p.suffix}")
-        _io.imwrite(left_file, image[:, : width // 2])
-        with tempfile.NamedTemporaryFile(suffix=p.suffix) as right_file:
-            _io.imwrite(right_file.name, image[:, width // 2:])
-            right_bytes = Path(right_file.name).read_bytes()
-        for ns, prefix in ((ns_gimage, "GImage"), (ns_gpano, "GPano"), (ns_note, "xmpNote")):
-            XMPMeta.register_namespace(ns, prefix)
-        meta = XMPMeta()
-        meta.set_property(ns_gpano, "UsePanoramaViewer", "True")
-        meta.set_property(ns_gpano, "ProjectionType", "equirectangular")
-        for key, value in (("CroppedAreaImageWidthPixels", width // 2), ("CroppedAreaImageHeightPixels", height),
-                           ("CroppedAreaLeftPixels", width // 4), ("CroppedAreaTopPixels", 0), ("FullPanoWidthPixels", width),
-                           ("FullPanoHeightPixels", height), ("PosePitchDegrees", 0), ("PoseRollDegrees", 0),
-                           ("InitialViewHeadingDegrees", 180)):
-            meta.set_property_int(ns_gpano, key, int(value))
-        meta.set_property(ns_gimage, "Mime", "image/jpeg")
-        meta.set_property(ns_gimage, "Data", base64.b64encode(right_bytes).decode())
-        meta.set_property(ns_note, "HasExtendedXMP", "06A56CB0A1A7FAFDA459CA3FAA14B474")
-        f = XMPFiles(file_path=left_file.as_posix(), open_forupdate=True)
-        if not f.can_put_xmp(meta):
-            raise ValueError(f"Cannot put XMP to {p}")
-        f.put_xmp(meta)
-        f.close_file()
+    raise typer.BadParameter("the xmp command writes Google VR180 photo metadata through python-xmp-toolkit (libxmp + the exempi library), "
+                             "which this engine does not ship: run the reference's `vr180-convert xmp` on the output of `lr`")
 
 
 def main(argv: Optional[Sequence[str]] = None) -> None:
