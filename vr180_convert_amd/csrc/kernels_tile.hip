@@ -1743,18 +1743,46 @@ __device__ __forceinline__ int raw_box_dma(const TileBox& b, const RawLanes& m, 
     return n;
 }
 
-// s_waitcnt vmcnt(n) + s_barrier for a wave-uniform n (the count is an immediate); no fence: see the kernels
+// s_waitcnt vmcnt(n) + s_barrier for a wave-uniform n; no fence: see the kernels.  The count is an immediate, so n selects one of
+// 21 sixteen-byte blocks (s_waitcnt | s_barrier | s_branch end | pad) by a computed jump: 6 scalar instructions and two jumps.
+// (As a switch the compiler structurised the 21 cases -- each holds a convergent barrier -- into a cascade of flag tests: ~30
+// scalar instructions and ~10 taken branches per wait, as many scalar as vector instructions in the unit loop of the batch kernel.)
+// n > 20 waits for vmcnt(20): a smaller count only waits longer.
+#define V1C_WAIT_BLOCK(i, extra) "s_waitcnt vmcnt(" #i ")" extra "\n\ts_barrier\n\ts_branch 1f\n\ts_nop 0\n\t"
+#define V1C_WAIT_TABLE(extra)                                                                                                      \
+    V1C_WAIT_BLOCK(0, extra) V1C_WAIT_BLOCK(1, extra) V1C_WAIT_BLOCK(2, extra) V1C_WAIT_BLOCK(3, extra) V1C_WAIT_BLOCK(4, extra)    \
+    V1C_WAIT_BLOCK(5, extra) V1C_WAIT_BLOCK(6, extra) V1C_WAIT_BLOCK(7, extra) V1C_WAIT_BLOCK(8, extra) V1C_WAIT_BLOCK(9, extra)    \
+    V1C_WAIT_BLOCK(10, extra) V1C_WAIT_BLOCK(11, extra) V1C_WAIT_BLOCK(12, extra) V1C_WAIT_BLOCK(13, extra)                         \
+    V1C_WAIT_BLOCK(14, extra) V1C_WAIT_BLOCK(15, extra) V1C_WAIT_BLOCK(16, extra) V1C_WAIT_BLOCK(17, extra)                         \
+    V1C_WAIT_BLOCK(18, extra) V1C_WAIT_BLOCK(19, extra) V1C_WAIT_BLOCK(20, extra)
+#define V1C_WAIT_JUMP(extra)                                                                                                       \
+    uint32_t off_;                                                                                                                 \
+    asm volatile("s_getpc_b64 vcc\n\t"          /* vcc = address of the next instruction */                                     \
+                 "s_lshl_b32 %0, %1, 4\n\t"     /* 16 bytes per block ... */                                                    \
+                 "s_add_u32 %0, %0, 20\n\t"     /* ... behind these five 4-byte instructions */                                  \
+                 "s_add_u32 vcc_lo, vcc_lo, %0\n\t"                                                                              \
+                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"                                                                              \
+                 "s_setpc_b64 vcc\n\t" V1C_WAIT_TABLE(extra) "1:"                                                                \
+                 : "=&s"(off_)                                                                                                     \
+                 : "s"(__builtin_amdgcn_readfirstlane((int)min((uint32_t)max(n, 0), 20u)))                                                                            \
+                 : "vcc", "scc", "memory")
+
 __device__ __forceinline__ void wait_vm_barrier(int n)
 {
-#define V1C_WAIT_CASE(i) \
-    case i: asm volatile("s_waitcnt vmcnt(" #i ")\n\ts_barrier" ::: "memory"); break;
-    switch (n) {
-        V1C_WAIT_CASE(0) V1C_WAIT_CASE(1) V1C_WAIT_CASE(2) V1C_WAIT_CASE(3) V1C_WAIT_CASE(4) V1C_WAIT_CASE(5) V1C_WAIT_CASE(6)
-        V1C_WAIT_CASE(7) V1C_WAIT_CASE(8) V1C_WAIT_CASE(9) V1C_WAIT_CASE(10) V1C_WAIT_CASE(11) V1C_WAIT_CASE(12) V1C_WAIT_CASE(13)
-        V1C_WAIT_CASE(14) V1C_WAIT_CASE(15) V1C_WAIT_CASE(16) V1C_WAIT_CASE(17) V1C_WAIT_CASE(18) V1C_WAIT_CASE(19)
-    default: asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory"); break;  // (a smaller count only waits longer)
-    }
-#undef V1C_WAIT_CASE
+    V1C_WAIT_JUMP("");
+}
+
+// ... for a count known at compile time
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier_imm()
+{
+    static_assert(N >= 0 && N <= 2, "add the case");
+    if (N == 0)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (N == 1)
+        asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
 }
 
 // taps of both eyes of a lane's 4 pixels from the raw boxes at LDS byte addresses `raw` (eye 0) and `raw + eye_off` (eye 1)
@@ -1863,14 +1891,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     if constexpr (NE == 2) {
         gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
         // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
-        wait_vm_barrier(0);
+        wait_vm_barrier_imm<0>();
         store_pair_row(ua, t, t.j, p0, p1);
         gather_pair_raw(q, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
         store_pair_row(ua, t, mirror_h - t.j, p0, p1);
     } else {
         const uint32_t row_off = (uint32_t)t.x0 * 3u;
         gather_one_raw(b, raw_b, L.sx, L.sy, p0);
-        wait_vm_barrier(0);
+        wait_vm_barrier_imm<0>();
         store4(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), p0, 0xFu, dst_rows_dword_aligned(ua, 0));
         gather_one_raw(q, raw_q, L.sx, L.sy2, p1);
         store4(ua.u[0].dst + (__umul24((uint32_t)(mirror_h - t.j), (uint32_t)ua.u[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(ua, 0));
@@ -1901,15 +1929,7 @@ constexpr int kPipeColBytes = 2 * kTW * 8, kPipeRowBytes = 3 * 32 * 8;  // colum
 // buffers they read to the next DMA requests)
 __device__ __forceinline__ void wait_vm_lgkm_barrier(int n)
 {
-#define V1C_WAIT_CASE(i) \
-    case i: asm volatile("s_waitcnt vmcnt(" #i ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    switch (n) {
-        V1C_WAIT_CASE(0) V1C_WAIT_CASE(1) V1C_WAIT_CASE(2) V1C_WAIT_CASE(3) V1C_WAIT_CASE(4) V1C_WAIT_CASE(5) V1C_WAIT_CASE(6)
-        V1C_WAIT_CASE(7) V1C_WAIT_CASE(8) V1C_WAIT_CASE(9) V1C_WAIT_CASE(10) V1C_WAIT_CASE(11) V1C_WAIT_CASE(12) V1C_WAIT_CASE(13)
-        V1C_WAIT_CASE(14) V1C_WAIT_CASE(15) V1C_WAIT_CASE(16) V1C_WAIT_CASE(17) V1C_WAIT_CASE(18) V1C_WAIT_CASE(19)
-    default: asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    }
-#undef V1C_WAIT_CASE
+    V1C_WAIT_JUMP(" lgkmcnt(0)");
 }
 
 // the lane's row / column values from the workgroup's LDS copy (`rows` = [3][32] doubles: sin, cos, 1 - cos of the latitude of the
@@ -2028,7 +2048,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_PIPE_WA
     gather_pair_raw(b0, raw_b, box_bytes, L.sx, L.sy, p0, p1);
     // the mirrored band's boxes (waited for before the tile's stores are issued: stores count in vmcnt too); every wave has
     // read its taps of the tile's boxes: their buffers take the tile of pair 1
-    wait_vm_lgkm_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int nb = 0;
     if (second) {
         const RawLanes mb1 = raw_lanes(b1.cpr, lane);
@@ -2060,7 +2080,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_PIPE_WA
     // behind the boxes of tile 1: store a, the band's 2 nq requests, store a'
     wait_vm_barrier(2 * nq + 2 * kStoresPerPairRow);
     gather_pair_raw(b1, raw_b, box_bytes, L.sx, L.sy, p0, p1);
-    wait_vm_barrier(kStoresPerPairRow);  // behind the band's boxes: store a'
+    wait_vm_barrier_imm<kStoresPerPairRow>();  // behind the band's boxes: store a'
     const int j1 = jbase + 16;
     store_pair_row(ua, t, j1, p0, p1);
     gather_pair_raw(q1, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
