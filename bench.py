@@ -72,6 +72,13 @@ WORKLOADS = {
     "C2NN": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=0,
                  desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_NEAREST (not a BASELINE config: the bilinear tile kernels "
                       "with coordinates 32 * cvRound(x))"),
+    # the generic kernel's configurations (k_remap: coordinates fused, taps from global memory) -- A/B / reporting only
+    "C2G": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=1,
+                desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, bilinear (generic kernel; not a BASELINE config)"),
+    "C2A": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=4,
+                desc="L+R 4096x4096 BGRA -> 8192x4096 SBS, PolynomialScaler, bilinear (generic kernel; not a BASELINE config)"),
+    "C2T": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, border=5,
+                desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, bilinear, BORDER_TRANSPARENT (generic kernel; not a BASELINE config)"),
     "C2N": dict(size=4080, poly=[0, 1, -0.1], rot=None, interp=1,
                 desc="L+R 4080x4080 -> 8160x4080 SBS (rows do not mirror about a tile boundary), bilinear (A/B only)"),
     # batch shapes: `frames` SBS frames per GPU per step (BASELINE configs 3 and 5 shard 8 resp. 32 per GPU)
@@ -165,18 +172,19 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
     # output buffers are allocated (and touched) once: the timed passes measure arithmetic, not
     # first-touch page faults of 100 MB of fresh memory per call
     xm, ym = np.zeros((size, size), np.float32), np.zeros((size, size), np.float32)
-    out = np.zeros((size, eyes * size, 3), np.uint8)
-    halves = [np.zeros((size, size, 3), np.uint8), np.zeros((size, size, 3), np.uint8)]
+    cn = left.shape[2]
+    out = np.zeros((size, eyes * size, cn), np.uint8)
+    halves = [np.zeros((size, size, cn), np.uint8), np.zeros((size, size, cn), np.uint8)]
 
     def one_pass():
         # apply_lr with a shared transformer: ONE map (remapper.py:381-386), remap per eye (:388-398),
         # concatenate (:518); apply() of one image: the map and one remap
         O.get_map(spec, radius=size / 2, size_input=(size, size), size_output=(size, size), out=(xm, ym))
-        O.remap(left, xm, ym, cfg["interp"], dst=halves[0])
+        O.remap(left, xm, ym, cfg["interp"], cfg.get("border", 0), dst=halves[0])
         if single:
             out[:] = halves[0]
             return
-        O.remap(right, xm, ym, cfg["interp"], dst=halves[1])
+        O.remap(right, xm, ym, cfg["interp"], cfg.get("border", 0), dst=halves[1])
         out[:, :size], out[:, size:] = halves[0], halves[1]
 
     one_pass()  # warm (table build, thread pool)
@@ -204,7 +212,7 @@ def cpu_baseline(cfg, left: np.ndarray, right: np.ndarray, gpu_out: np.ndarray |
         with np.errstate(all="ignore"):
             xm, ym = chain_numpy.get_map(spec, radius=size / 2, size_input=(size, size), size_output=(size, band))
         t_np = time.perf_counter() - t0
-        bd = [np.zeros((band, size, 3), np.uint8), np.zeros((band, size, 3), np.uint8)]
+        bd = [np.zeros((band, size, cn), np.uint8), np.zeros((band, size, cn), np.uint8)]
         O.remap(left, xm, ym, cfg["interp"], dst=bd[0])  # warm
         t0 = time.perf_counter()
         O.remap(left, xm, ym, cfg["interp"], dst=bd[0])
@@ -389,7 +397,8 @@ def main() -> None:
     if strong and (frames or single):
         raise SystemExit("--split eyes / bands divide ONE L+R pair: use a pair workload (C2, C4, C1, C2R, C2N)")
     units = 1 if single else 2 * max(frames, 1)
-    set_bytes = units * 3 * (size * size + size * size)
+    cn, border = int(cfg.get("cn", 3)), int(cfg.get("border", 0))
+    set_bytes = units * cn * (size * size + size * size)
     my_units: list = []
     if strong:
         # ONE pair for the whole job (strong scaling): this rank's part of it by the product's partition
@@ -462,18 +471,19 @@ def main() -> None:
     else:
         # seeded noise-disc frames; frame index = rank so ranks hold different pixels;
         # set 0 is the numpy-seeded pair the CPU baseline / parity check uses, the others are generated on the device
-        left_h, right_h = noise_disc(size, size, 2 * rank), noise_disc(size, size, 2 * rank + 1)
+        left_h, right_h = noise_disc(size, size, 2 * rank, cn), noise_disc(size, size, 2 * rank + 1, cn)
         for k in range(nsets):
             if k == 0:
                 left, right = torch.from_numpy(left_h).to(dev), torch.from_numpy(right_h).to(dev)
             else:
-                left, right = (noise_disc_torch(size, size, 2 * rank + e + 100003 * k, dev) for e in (0, 1))
-            sets.append(dict(left=left, right=right, sbs=torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)))
+                left, right = (noise_disc_torch(size, size, 2 * rank + e + 100003 * k, dev, cn) for e in (0, 1))
+            # (zeros: BORDER_TRANSPARENT leaves skipped pixels as they are -- the oracle starts from zeros too)
+            sets.append(dict(left=left, right=right, sbs=torch.zeros((size, 2 * size, cn), dtype=torch.uint8, device=dev)))
 
         def step(i: int):
             b = sets[i % nsets]
             V.apply_lr_tensors(transformer, b["left"], b["right"], out=b["sbs"], size_output=(size, size),
-                               interpolation=cfg["interp"], radius="max")
+                               interpolation=cfg["interp"], radius="max", boarder_mode=border)
 
     def barrier():
         if world > 1:
@@ -536,7 +546,7 @@ def main() -> None:
 
     px_per_step = 2 * size * size if strong else units * size * size * world
     value = px_per_step * args.steps / elapsed / 1e6
-    # all eyes of a step: source read once + destination written once (a batch is ceil(units/16) launches:
+    # all eyes of a step: source read once + destination written once, cn bytes per pixel (a batch is ceil(units/16) launches:
     # the figure is per step, i.e. per group of launches, for batch workloads)
     alg_bytes = set_bytes
     achieved = alg_bytes / (kernel_ms_max * 1e-3) / 1e9

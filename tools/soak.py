@@ -35,7 +35,41 @@ def batch(n, frames, steps):
     for i in range(steps):
         bad += int(not torch.equal(run(), ref))
     return bad
+def single(n, steps):
+    """one image: the one-eye instantiation of k_ray_lin3_pair_mirror_raw"""
+    t = EquirectangularEncoder() * FisheyeDecoder("equidistant")
+    srcs = [noise_disc_torch(n, n, 20 + k, dev) for k in range(3)]
+    def run(src):
+        dst = torch.empty((n, n, 3), dtype=torch.uint8, device=dev)
+        V.remap_tensors(t, [src], [dst], radius=n / 2, interpolation=1)
+        return dst
+    refs = [run(s).clone() for s in srcs]; bad = 0
+    for i in range(steps):
+        bad += int(not torch.equal(run(srcs[i % 3]), refs[i % 3]))
+    return bad
+def rotated(n, frames, steps):
+    """per-unit calibration rotations: k_ray_lin3_rot_pair_raw (two units per workgroup, fence-less box reduction + LDS-DMA)"""
+    import numpy as np
+    from vr180_convert_amd.quat import as_rotation_matrix, from_rotation_vector
+    from vr180_convert_amd.transformer import Euclidean3DRotator
+    t = EquirectangularEncoder() * Euclidean3DRotator((1.0, 0.0, 0.0, 0.0)) * FisheyeDecoder("equidistant")
+    rng = np.random.default_rng(3)
+    rots = [as_rotation_matrix(from_rotation_vector(rng.normal(0, 0.02, 3))) for _ in range(2 * frames)]
+    ins = [noise_disc_torch(n, 2 * n, 40 + f, dev) for f in range(frames)]
+    srcs = [v for fr in ins for v in (fr[:, :n], fr[:, n:])]
+    def run():
+        outs = [torch.empty((n, 2 * n, 3), dtype=torch.uint8, device=dev) for _ in range(frames)]
+        dsts = [v for fr in outs for v in (fr[:, :n], fr[:, n:])]
+        V.remap_tensors(t, srcs, dsts, radius=n / 2, interpolation=1, rotations=rots)
+        return torch.stack(outs)
+    ref = run().clone(); bad = 0
+    for i in range(steps):
+        bad += int(not torch.equal(run(), ref))
+    return bad
 t0 = time.time()
+print("single images 2048:", single(2048, 2000), "bad of 2000", flush=True)
+print("C5-like rotated units 1920 x 8 frames:", rotated(1920, 8, 400), "bad of 400", flush=True)
+print("rotated units 1024 x 5 frames (odd unit count per launch group):", rotated(1024, 5, 800), "bad of 800", flush=True)
 print("C2-like pairs 4096:", pair(4096, [0, 1, -0.1], 1500), "bad of 1500", flush=True)
 print("C1-like pairs 2048:", pair(2048, None, 3000), "bad of 3000", flush=True)
 print("pairs 1024 poly:", pair(1024, [0, 1, -0.1], 4000), "bad of 4000", flush=True)
