@@ -2537,8 +2537,17 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     }
     if (raw_nwp > 0) {
         // (whole rows, a multiple of 8 of them: the pair rows keep their XCDs)
-        const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
-        const dim3 rgrid(full.x, grid.y + rest_rows, 1);
+        unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
+        dim3 rgrid(full.x, grid.y + rest_rows, 1);
+        // V1C_MIRROR_SKIP=1: timing experiment, the rest rows are not launched (their tiles stay unwritten); =2: ONLY the rest rows
+        static const int skip = [] {
+            const char* e = tuning_env("V1C_MIRROR_SKIP");
+            return e ? std::atoi(e) : 0;
+        }();
+        if (skip == 1)
+            n_rest = 0, rest_rows = 0, rgrid.y = grid.y;
+        if (skip == 2)
+            rgrid.y = rest_rows;
         if (c.ray.var_is_w)
             hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
                                half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);

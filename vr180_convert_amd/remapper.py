@@ -686,7 +686,7 @@ def apply_lr(
         image = _io.imread(left_path)
         left_path = image[:, : image.shape[1] // 2]
         right_path = image[:, image.shape[1] // 2 :]
-    left, right = (_io.imread(p) if isinstance(p, (str, Path)) else p for p in (left_path, right_path))
+    left, right = _io.imread_many([left_path, right_path])  # (two files: decoded side by side, the codecs release the GIL)
     on_device = isinstance(left, torch.Tensor) and left.is_cuda
     dev = left.device if on_device else _device(device)
     lt, rt = _to_device(left, dev), _to_device(right, dev)
