@@ -49,8 +49,10 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry,
 // tile_mirror_rest: the tiles (ty << 16 | tx) that launch leaves to the pair kernel; false: no mirror launch for this plan
 // `raw_nwp` > 0: for k_ray_lin3_pair_mirror_raw (boxes by LDS-DMA, packed BGR in LDS, box buffers of raw_nwp KB:
 // tile_mirror_raw_passes) instead of k_ray_lin3_pair_mirror
+// `full_rows`: for k_ray_lin3_pair_mirror_raw proper (tile rows 0 .. TY / 2, boxes of up to two buffers: mirror_raw_fit), `n_eyes` = 2
+// (apply_lr's pair) or 1 (a single image: its own list)
 bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
-                      std::vector<uint32_t>& rest, int raw_nwp);
+                      std::vector<uint32_t>& rest, int raw_nwp, bool full_rows = false, int n_eyes = 2);
 int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, const Geom& g);
 // `pipe_tab` > 0: k_ray_lin3_pair_mirror_pipe (two tile rows per workgroup, the second pair's boxes requested while the first is
 // sampled), tile_mirror_pipe_tab() table entries per pair in LDS

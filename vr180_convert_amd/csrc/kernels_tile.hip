@@ -1575,6 +1575,21 @@ __host__ __device__ inline bool raw_box_ok(int x0, int y0, int cpr, int nrows, i
     const int upr = raw_units_per_row(cpr);
     return cpr > 0 && cpr <= kMaxCpr && nrows * upr <= nwp * 64 && !((y0 + nrows >= src_h) && (x0 * 3 + upr * 16 > src_w * 3));
 }
+// k_ray_lin3_pair_mirror_raw: 1 = all boxes of the workgroup fit their nwp KB buffers; 0 (and 2: they would fit two buffers each -- an
+// eye-by-eye form of the workgroup for those was built and cost the kernel 22 VGPRs and a wave per SIMD) = the pair goes to the
+// general pair code (rest list).  The band's table entries are a subset of the tile's (its rows mirror the tile's; tile row 0's band has
+// one row less): the tile's slice serves both.
+__host__ __device__ inline int mirror_raw_fit(const TileBox& b, const TileBox& q, int nwp, int src_h, int src_w)
+{
+    if (!(b.interior != 0 && q.interior == b.interior && b.nidx > 0 && b.nidx <= kTabSlice && q.nidx > 0 && q.idx0 >= b.idx0 &&
+          q.idx0 + q.nidx <= b.idx0 + b.nidx))
+        return 0;
+    if (raw_box_ok(b.x0, b.y0, b.cpr, b.nrows, nwp, src_h, src_w) && raw_box_ok(q.x0, q.y0, q.cpr, q.nrows, nwp, src_h, src_w))
+        return 1;
+    if (raw_box_ok(b.x0, b.y0, b.cpr, b.nrows, 2 * nwp, src_h, src_w) && raw_box_ok(q.x0, q.y0, q.cpr, q.nrows, 2 * nwp, src_h, src_w))
+        return 2;
+    return 0;
+}
 __host__ __device__ inline bool mirror_raw_static_ok(const TileBox& b, const TileBox& q, int nwp, int src_h, int src_w)
 {
     return b.interior != 0 && q.interior == b.interior && b.nidx > 0 && b.nidx <= kTabSlice && q.idx0 == b.idx0 && q.nidx == b.nidx &&
@@ -1844,7 +1859,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const RayParams& P = c.ray;
     int tx, ty;
     xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
-    ty += 1;
+    // tile rows 0 .. TY / 2: row 0 of the image has no mirror image (its band row would be row H: not stored), row H / 2 is its
+    // own (tile row TY / 2 and its band rewrite rows their neighbours write too -- with the same bytes)
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
     // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
     RowCol rc;
@@ -1853,7 +1869,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const uint8_t* __restrict__ src1 = ua.u[NE - 1].src;
     const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[NE - 1].src_pitch;
     const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
-    if (!mirror_raw_static_ok(b, q, nwp, g.src_h, g.src_w))
+    // (one image: its two boxes have the four buffers of a pair)
+    if (mirror_raw_fit(b, q, NE == 1 ? 2 * nwp : nwp, g.src_h, g.src_w) != 1)
         return;
     const bool mpoly = (b.interior & 2) != 0;
     // (the row / column values are consumed here: the compiler's own wait for them then sits in front of the DMA requests,
@@ -1864,7 +1881,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     asm volatile("" ::"v"(rc.sl), "v"(rc.cl), "v"(rc.hl));
     const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
     const uint32_t box_bytes = (uint32_t)nwp * 1024u;
-    const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + (uint32_t)NE * box_bytes;
+    const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + 2u * box_bytes;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {  // table slice: nidx * 4 units of 16 bytes, one pass (units past the slice: clamped, they land in the unused tail of tabw)
         const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
@@ -1872,6 +1889,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
+    const uint32_t row_off = (uint32_t)t.x0 * 3u;
+    const int jm = mirror_h - t.j;             // the band's row
+    const bool band_row = jm < g.dst_h;         // (false for row 0 of the image only)
+    LaneCoords L;
+    uint32_t p0[kPX], p1[kPX];
     const int nb = raw_box_dma(b, mb, src0, pitch0, lane, wave, raw_b);  // this wave's requests per box of the tile ...
     if (NE == 2)
         raw_box_dma(b, mb, src1, pitch1, lane, wave, raw_b + box_bytes);
@@ -1881,27 +1903,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
     // what the barrier publishes -- vmcnt counts in issue order -- then joins.
     wait_vm_barrier(NE * (nb + nq));  // table slice landed (this wave's box loads may still be in flight)
-    LaneCoords L;
     if (mpoly)
         lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     else
         lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     wait_vm_barrier(NE * nq);  // the tile's boxes
-    uint32_t p0[kPX], p1[kPX];
     if constexpr (NE == 2) {
         gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
         // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
         wait_vm_barrier_imm<0>();
         store_pair_row(ua, t, t.j, p0, p1);
         gather_pair_raw(q, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
-        store_pair_row(ua, t, mirror_h - t.j, p0, p1);
+        if (band_row)
+            store_pair_row(ua, t, jm, p0, p1);
     } else {
-        const uint32_t row_off = (uint32_t)t.x0 * 3u;
         gather_one_raw(b, raw_b, L.sx, L.sy, p0);
         wait_vm_barrier_imm<0>();
         store4(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), p0, 0xFu, dst_rows_dword_aligned(ua, 0));
         gather_one_raw(q, raw_q, L.sx, L.sy2, p1);
-        store4(ua.u[0].dst + (__umul24((uint32_t)(mirror_h - t.j), (uint32_t)ua.u[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(ua, 0));
+        if (band_row)
+            store4(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(ua, 0));
     }
 }
 
@@ -2407,7 +2428,7 @@ int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, cons
     const dim3 d = tile_grid(g, tile_threads(g), 1);
     std::vector<int> hist(kRawMaxWavePasses + 2, 0);
     size_t n = 0;
-    for (unsigned ty = 1; ty < d.y / 2; ty++)
+    for (unsigned ty = 0; ty <= d.y / 2; ty++)
         for (unsigned tx = 0; tx < d.x; tx++) {
             const size_t i = (size_t)ty * d.x + tx;
             if (b[i].cpr <= 0 || q[i].cpr <= 0 || b[i].cpr > kMaxCpr || q[i].cpr > kMaxCpr)
@@ -2424,8 +2445,10 @@ int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, cons
     return kMirrorRawMaxKB;
 }
 
+// `full_rows` (raw_nwp > 0): the list for k_ray_lin3_pair_mirror_raw, whose workgroups serve tile rows 0 .. TY / 2 (mirror_raw_fit) and
+// `n_eyes` units; otherwise tile rows 1 .. TY / 2 - 1 pair up and rows 0, TY / 2 and TY - 1 are always on the list
 bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
-                      std::vector<uint32_t>& rest, int raw_nwp)
+                      std::vector<uint32_t>& rest, int raw_nwp, bool full_rows, int n_eyes)
 {
     const TileBox* b = (const TileBox*)host_boxes;
     const TileBox* q = (const TileBox*)host_mboxes;
@@ -2439,14 +2462,29 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
         return false;
     std::vector<uint8_t> in_rest((size_t)d.x * d.y, 0);
     auto add = [&](unsigned tx, unsigned ty) { in_rest[(size_t)ty * d.x + tx] = 1; };
-    for (unsigned tx = 0; tx < d.x; tx++)
-        add(tx, 0), add(tx, TYh), add(tx, TY - 1);
-    for (unsigned ty = 1; ty < TYh; ty++)
-        for (unsigned tx = 0; tx < d.x; tx++) {
-            const size_t i = (size_t)ty * d.x + tx;
-            if (raw_nwp > 0 ? !mirror_raw_static_ok(b[i], q[i], raw_nwp, g.src_h, g.src_w) : !mirror_static_ok(b[i], q[i], half_dwords, g.src_h, g.src_w))
-                add(tx, ty), add(tx, TY - 1 - ty), add(tx, TY - ty);
-        }
+    if (full_rows && raw_nwp > 0) {
+        for (unsigned ty = 0; ty <= TYh; ty++)
+            for (unsigned tx = 0; tx < d.x; tx++) {
+                const size_t i = (size_t)ty * d.x + tx;
+                if (mirror_raw_fit(b[i], q[i], n_eyes == 1 ? 2 * raw_nwp : raw_nwp, g.src_h, g.src_w) != 1) {
+                    add(tx, ty);
+                    if (ty < TYh) {  // its band: 15 rows of tile row TY - 1 - ty and (ty > 0) the first row of tile row TY - ty
+                        add(tx, TY - 1 - ty);
+                        if (ty > 0)
+                            add(tx, TY - ty);
+                    }
+                }
+            }
+    } else {
+        for (unsigned tx = 0; tx < d.x; tx++)
+            add(tx, 0), add(tx, TYh), add(tx, TY - 1);
+        for (unsigned ty = 1; ty < TYh; ty++)
+            for (unsigned tx = 0; tx < d.x; tx++) {
+                const size_t i = (size_t)ty * d.x + tx;
+                if (raw_nwp > 0 ? !mirror_raw_static_ok(b[i], q[i], raw_nwp, g.src_h, g.src_w) : !mirror_static_ok(b[i], q[i], half_dwords, g.src_h, g.src_w))
+                    add(tx, ty), add(tx, TY - 1 - ty), add(tx, TY - ty);
+            }
+    }
     for (unsigned ty = 0; ty < d.y; ty++)
         for (unsigned tx = 0; tx < d.x; tx++)
             if (in_rest[(size_t)ty * d.x + tx])
@@ -2494,15 +2532,20 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     }();
     if (block_rows && grid.x % 8 == 0 && raw_nwp > 0)
         slen = 0x80000000u | std::min(block_rows, 0xffffu);
+    // k_ray_lin3_pair_mirror_raw: tile rows 0 .. TY / 2 (two more than the pairing of rows 1 .. TY / 2 - 1)
+    const unsigned raw_rows = full.y / 2 + 1;
+    const unsigned raw_per = (grid.x * raw_rows) >> 3;
+    const unsigned raw_slen = (slen & 0x80000000u) ? slen : (strip_rows && strip_rows * grid.x < raw_per ? strip_rows * grid.x : 0u);
+    const unsigned raw_smagic = (raw_slen && !(raw_slen & 0x80000000u)) ? (unsigned)(0x100000000ull / raw_slen) + 1u : 0u;
     if (raw_nwp > 0 && n_eyes == 1) {  // a single image: the LDS-DMA kernel's one-eye instantiation
         const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
-        const dim3 rgrid(full.x, grid.y + rest_rows, 1);
+        const dim3 rgrid(full.x, raw_rows + rest_rows, 1);
         if (c.ray.var_is_w)
             hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1, 1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
         else
             hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0, 1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
         return hipGetLastError();
     }
     if (raw_nwp > 0 && pipe_tab > 0) {
@@ -2538,22 +2581,22 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     if (raw_nwp > 0) {
         // (whole rows, a multiple of 8 of them: the pair rows keep their XCDs)
         unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
-        dim3 rgrid(full.x, grid.y + rest_rows, 1);
+        dim3 rgrid(full.x, raw_rows + rest_rows, 1);
         // V1C_MIRROR_SKIP=1: timing experiment, the rest rows are not launched (their tiles stay unwritten); =2: ONLY the rest rows
         static const int skip = [] {
             const char* e = tuning_env("V1C_MIRROR_SKIP");
             return e ? std::atoi(e) : 0;
         }();
         if (skip == 1)
-            n_rest = 0, rest_rows = 0, rgrid.y = grid.y;
+            n_rest = 0, rest_rows = 0, rgrid.y = raw_rows;
         if (skip == 2)
             rgrid.y = rest_rows;
         if (c.ray.var_is_w)
             hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
         else
             hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic, raw_nwp, rest_rows);
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
         return hipGetLastError();
     }
     if (c.ray.var_is_w)

@@ -179,6 +179,8 @@ struct v1c_plan {
     void* mirror_boxes = nullptr;
     const uint32_t* mirror_rest = nullptr;
     int n_mirror_rest = 0;
+    const uint32_t* mirror_rest1 = nullptr;  // ... of single-image launches (one eye: its two boxes have a pair's four buffers)
+    int n_mirror_rest1 = -1;                 // -1: no single-image mirror launch
     int mirror_raw_nwp = 0;  // > 0: the mirror launch brings its boxes in by LDS-DMA (k_ray_lin3_pair_mirror_raw), buffers of so many KB
     int mirror_pipe_tab = 0;  // > 0: ... two tile rows per workgroup (k_ray_lin3_pair_mirror_pipe), so many table entries per pair in LDS
     int mirror_h = 0;
@@ -508,17 +510,26 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         const char* rawsw = tuning_env("V1C_MIRROR_RAW");
                         const int rawv = rawsw ? std::atoi(rawsw) : 1;
                         p->mirror_raw_nwp = rawv == 1 ? tile_mirror_raw_passes(hb.data(), hm.data(), g) : rawv > 1 ? std::min(rawv, 16) : 0;
-                        if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest, p->mirror_raw_nwp)) {
+                        // V1C_MIRROR_PIPE=1 (A/B builds): two tile rows per workgroup (k_ray_lin3_pair_mirror_pipe).  Measured r03,
+                        // C2 / C1: 0.0497 / 0.0205 ms against 0.0472 / 0.0185 ms for k_ray_lin3_pair_mirror_raw
+                        const char* pipesw = tuning_env("V1C_MIRROR_PIPE");
+                        const bool pipe = p->mirror_raw_nwp > 0 && pipesw && pipesw[0] == '1';
+                        if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest, p->mirror_raw_nwp, !pipe, 2)) {
                             if ((rc = upload(p, mrest, &p->mirror_rest))) {
                                 v1c_plan_destroy(p);
                                 return rc;
                             }
                             p->mirror_boxes = mbx, p->n_mirror_rest = (int)mrest.size(), p->mirror_h = g.dst_h;
-                            // V1C_MIRROR_PIPE=1 (A/B builds): two tile rows per workgroup (k_ray_lin3_pair_mirror_pipe).  Measured r03,
-                            // C2 / C1: 0.0497 / 0.0205 ms against 0.0472 / 0.0185 ms for k_ray_lin3_pair_mirror_raw
-                            const char* pipesw = tuning_env("V1C_MIRROR_PIPE");
-                            if (p->mirror_raw_nwp > 0 && pipesw && pipesw[0] == '1')
+                            if (pipe)
                                 p->mirror_pipe_tab = tile_mirror_pipe_tab(hb.data(), hm.data(), g, p->mirror_raw_nwp);
+                            std::vector<uint32_t> mrest1;
+                            if (p->mirror_raw_nwp > 0 && tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest1, p->mirror_raw_nwp, true, 1)) {
+                                if ((rc = upload(p, mrest1, &p->mirror_rest1))) {
+                                    v1c_plan_destroy(p);
+                                    return rc;
+                                }
+                                p->n_mirror_rest1 = (int)mrest1.size();
+                            }
                             if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                                 std::fprintf(stderr, "[v1c] mirror launch: largest table slice %d entries\n",
                                              tile_mirror_pipe_tab(hb.data(), hm.data(), g, p->mirror_raw_nwp));
@@ -662,13 +673,14 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             }
             // a pair (apply_lr) of an unrotated chain: the tile + mirror-image launch
             // (a single image -- apply() of one image, BASELINE config 1 -- takes the LDS-DMA form's one-eye instantiation)
-            bool mirror = fast && (n == 2 || (n == 1 && p->mirror_raw_nwp > 0)) && !any_rot && p->mirror_boxes != nullptr && shared_entry &&
-                          !p->disable_shared_entry;
+            bool mirror = fast && (n == 2 || (n == 1 && p->mirror_raw_nwp > 0 && p->n_mirror_rest1 >= 0)) && !any_rot &&
+                          p->mirror_boxes != nullptr && shared_entry && !p->disable_shared_entry;
             for (int k = 0; k < n && mirror; k++)
                 mirror = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
             if (mirror) {
-                HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h, p->mirror_rest,
-                                                    p->n_mirror_rest, p->mirror_raw_nwp, p->mirror_pipe_tab, st, n));
+                HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h,
+                                                    n == 1 ? p->mirror_rest1 : p->mirror_rest, n == 1 ? p->n_mirror_rest1 : p->n_mirror_rest,
+                                                    p->mirror_raw_nwp, p->mirror_pipe_tab, st, n));
             } else if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
