@@ -116,7 +116,7 @@ def pick(dis, name):
 
 
 def test_no_vector_load_between_a_request_and_its_wait(kernels_dis):
-    """mirror_raw (pairs and single images), mirror_pipe, batch_lean_raw with OWN = 0: from every LDS-DMA request, in address
+    """mirror_raw (pairs and single images) and mirror_pipe: from every LDS-DMA request, in address
     order up to the next hand-written wait, there is no compiler-visible vector load and no vmcnt wait the compiler made
     (the compiler lays the request loops, the wait tables and the store blocks of a phase out together; its structurised
     control flow -- flag registers -- makes a path-exact check meaningless, so this is the layout-local form of "nothing loads
@@ -126,10 +126,10 @@ def test_no_vector_load_between_a_request_and_its_wait(kernels_dis):
         for name, ins in pick(kernels_dis, fam).items():
             succ, tables = analyse(ins)  # (verifies the jump tables)
             assert tables >= 2, (name, tables)
-            if "batch_lean_raw" in name and "lean_rawILi0ELi0ELi0E" not in name:
-                # checked on the instantiation BASELINE config 3 runs; in the others the compiler lays blocks of the general pair
-                # code (which loads through registers) between the request loops and the wait tables, OWN = 1 reads the radial
-                # table inside the coordinates and ROT = 1 keeps a wait of its own -- all of which only over-wait
+            if "batch_lean_raw" in name:
+                # (its requests sit in the unit loop, whose wait is at the loop head -- BEHIND them in address order; OWN = 1 reads the
+                # radial table inside the coordinates and ROT = 1 keeps a wait of its own: all of that only over-waits.  The wait
+                # tables are verified above.)
                 continue
             for i, x in enumerate(ins):
                 if x.kind != "D":
@@ -140,7 +140,7 @@ def test_no_vector_load_between_a_request_and_its_wait(kernels_dis):
                     j += 1
                 assert j < len(ins) and ins[j].kind == "W", (name, hex(x.addr), "no hand-written wait behind the request")
             checked += 1
-    assert checked >= 5
+    assert checked >= 6
 
 
 def test_rot_pair_has_its_tables(kernels_dis):
