@@ -60,6 +60,9 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #define V1C_LEAN_RING 2  // box buffers of k_ray_lin3_batch_lean_raw (2 or 3: the boxes of 1 or 2 units in flight; C3: 0.1807 / 0.1852 ms,
                          // 7 / 5 workgroups per CU)
 #endif
+#ifndef V1C_MIRROR_BIG
+#define V1C_MIRROR_BIG 0  // 1 (A/B builds): k_ray_lin3_pair_mirror_raw also serves pairs whose boxes need two buffers each, eye by eye (0: they go to the rest list)
+#endif
 #ifndef V1C_RAW_WAVES
 #define V1C_RAW_WAVES 5  // waves per SIMD k_ray_lin3_pair_mirror_raw is compiled for
 #endif
@@ -1870,7 +1873,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[NE - 1].src_pitch;
     const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
     // (one image: its two boxes have the four buffers of a pair)
-    if (mirror_raw_fit(b, q, NE == 1 ? 2 * nwp : nwp, g.src_h, g.src_w) != 1)
+    const int fit = mirror_raw_fit(b, q, NE == 1 ? 2 * nwp : nwp, g.src_h, g.src_w);
+    if (fit == 0 || (fit == 2 && (NE == 1 || !V1C_MIRROR_BIG)))
         return;
     const bool mpoly = (b.interior & 2) != 0;
     // (the row / column values are consumed here: the compiler's own wait for them then sits in front of the DMA requests,
@@ -1894,6 +1898,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const bool band_row = jm < g.dst_h;         // (false for row 0 of the image only)
     LaneCoords L;
     uint32_t p0[kPX], p1[kPX];
+    if (NE == 2 && V1C_MIRROR_BIG && fit == 2) {
+        // boxes of up to two buffers: the eyes one after the other, each with the buffers of both (a rolled loop: the second code path
+        // must not cost the pair path registers); the coordinates serve both eyes
+#pragma unroll 1
+        for (int e = 0; e < 2; e++) {
+            const uint8_t* __restrict__ se = e ? src1 : src0;
+            const uint32_t pe = e ? pitch1 : pitch0;
+            if (e)  // every wave has sampled eye 0's boxes
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int nb = raw_box_dma(b, mb, se, pe, lane, wave, raw_b);
+            const int nq = raw_box_dma(q, mq, se, pe, lane, wave, raw_q);
+            if (e == 0) {
+                wait_vm_barrier(nb + nq);  // table slice
+                if (mpoly)
+                    lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+                else
+                    lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+            }
+            wait_vm_barrier(nq);  // (behind the tile's box: the band's requests; eye 0's stores are older than both)
+            gather_one_raw(b, raw_b, L.sx, L.sy, p0);
+            wait_vm_barrier_imm<0>();
+            uint8_t* de = e ? ua.u[1].dst : ua.u[0].dst;
+            const uint32_t dp = (uint32_t)(e ? ua.u[1].dst_pitch : ua.u[0].dst_pitch);
+            const bool al = e ? dst_rows_dword_aligned(ua, 1) : dst_rows_dword_aligned(ua, 0);
+            store4(de + (__umul24((uint32_t)t.j, dp) + row_off), p0, 0xFu, al);
+            gather_one_raw(q, raw_q, L.sx, L.sy2, p1);
+            if (band_row)
+                store4(de + (__umul24((uint32_t)jm, dp) + row_off), p1, 0xFu, al);
+        }
+        return;
+    }
     const int nb = raw_box_dma(b, mb, src0, pitch0, lane, wave, raw_b);  // this wave's requests per box of the tile ...
     if (NE == 2)
         raw_box_dma(b, mb, src1, pitch1, lane, wave, raw_b + box_bytes);
@@ -2466,7 +2501,8 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
         for (unsigned ty = 0; ty <= TYh; ty++)
             for (unsigned tx = 0; tx < d.x; tx++) {
                 const size_t i = (size_t)ty * d.x + tx;
-                if (mirror_raw_fit(b[i], q[i], n_eyes == 1 ? 2 * raw_nwp : raw_nwp, g.src_h, g.src_w) != 1) {
+                const int fit = mirror_raw_fit(b[i], q[i], n_eyes == 1 ? 2 * raw_nwp : raw_nwp, g.src_h, g.src_w);
+                if (fit == 0 || (fit == 2 && (n_eyes == 1 || !V1C_MIRROR_BIG))) {
                     add(tx, ty);
                     if (ty < TYh) {  // its band: 15 rows of tile row TY - 1 - ty and (ty > 0) the first row of tile row TY - ty
                         add(tx, TY - 1 - ty);
