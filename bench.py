@@ -527,8 +527,8 @@ def main() -> None:
     # a step's launch(es) including the gaps between them.  (An event pair around every step would
     # add two packets per launch and, whenever the host is the slower side, measure host latency.)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
     e0.record()
+    t0 = time.perf_counter()  # (behind the opening event's own host cost: the K steps start here)
     for i in range(args.steps):
         step(args.warmup + i)
     e1.record()
