@@ -60,6 +60,11 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #define V1C_LEAN_RING 2  // box buffers of k_ray_lin3_batch_lean_raw (2 or 3: the boxes of 1 or 2 units in flight; C3: 0.1807 / 0.1852 ms,
                          // 7 / 5 workgroups per CU)
 #endif
+#ifndef V1C_RAW_RC_LDS
+#define V1C_RAW_RC_LDS 0  // 1 (A/B builds): k_ray_lin3_pair_mirror_raw takes the tile's row / column table values by LDS-DMA instead of 88 bytes per
+                          // lane through L1 (a third of its L1 accesses, and no load in front of the box requests): C2 0.0488 against 0.0491 ms,
+                          // C1 0.0193 against 0.0184, C1S 0.0131 against 0.0124 (r03: profiles/r03b_final/ab_rc_lds.log)
+#endif
 #ifndef V1C_MIRROR_BIG
 #define V1C_MIRROR_BIG 0  // 1 (A/B builds): k_ray_lin3_pair_mirror_raw also serves pairs whose boxes need two buffers each, eye by eye (0: they go to the rest list)
 #endif
@@ -1845,6 +1850,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
+#if V1C_RAW_RC_LDS
+    __shared__ __attribute__((aligned(16))) double rcw[2 * kTW + 3 * 16];  // column values [2][64] (sin, 1 - cos), row values [3][16]
+#endif
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 4 raw boxes (or the general code's cell buffers)
     const int tid = threadIdx.x;
     // grid: first `rest_rows` rows of workgroups for the tiles this path leaves out (general pair code: they take longest, so
@@ -1865,9 +1873,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     // tile rows 0 .. TY / 2: row 0 of the image has no mirror image (its band row would be row H: not stored), row H / 2 is its
     // own (tile row TY / 2 and its band rewrite rows their neighbours write too -- with the same bytes)
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
-    // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
     RowCol rc;
+#if !V1C_RAW_RC_LDS
+    // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
     load_rowcol<0>(P, t.xc, t.jc, rc);
+#endif
     const uint8_t* __restrict__ src0 = ua.u[0].src;
     const uint8_t* __restrict__ src1 = ua.u[NE - 1].src;
     const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[NE - 1].src_pitch;
@@ -1877,12 +1887,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     if (fit == 0 || (fit == 2 && (NE == 1 || !V1C_MIRROR_BIG)))
         return;
     const bool mpoly = (b.interior & 2) != 0;
+#if !V1C_RAW_RC_LDS
     // (the row / column values are consumed here: the compiler's own wait for them then sits in front of the DMA requests,
     // not -- as vmcnt(0), it does not count LDS-DMA -- in front of the coordinates)
 #pragma unroll
     for (int k = 0; k < kPX; k++)
         asm volatile("" ::"v"(rc.slon[k]), "v"(rc.qlon[k]));
     asm volatile("" ::"v"(rc.sl), "v"(rc.cl), "v"(rc.hl));
+#endif
     const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
     const uint32_t box_bytes = (uint32_t)nwp * 1024u;
     const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + 2u * box_bytes;
@@ -1892,6 +1904,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
         const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
+#if V1C_RAW_RC_LDS
+    // The row / column table values of the tile by LDS-DMA too (1.4 KB per workgroup instead of 88 bytes per lane through the vector
+    // cache -- a third of the kernel's L1 accesses -- and no load the box requests would have to wait behind): wave 0 the 64 columns'
+    // sin / 1 - cos, waves 1-3 the 16 rows' sin, cos, 1 - cos.  One request per wave, in front of the boxes.
+    const uint32_t lds_rc = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)rcw;
+    if (wave == 0) {
+        const double* ps = (lane < 32 ? P.col_s : P.col_h) + (tx * kTW + (lane & 31) * 2);
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)ps, (lds_void_ptr)(uintptr_t)lds_rc, 16, 0, 0);
+    } else if (lane < 8) {
+        const int ro = ty * 16 + lane * 2;
+        if (wave == 1)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_s + ro), (lds_void_ptr)(uintptr_t)(lds_rc + 1024u), 16, 0, 0);
+        else if (wave == 2)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_c + ro), (lds_void_ptr)(uintptr_t)(lds_rc + 1152u), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_h + ro), (lds_void_ptr)(uintptr_t)(lds_rc + 1280u), 16, 0, 0);
+    }
+#endif
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
     const uint32_t row_off = (uint32_t)t.x0 * 3u;
     const int jm = mirror_h - t.j;             // the band's row
@@ -1911,6 +1941,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
             const int nq = raw_box_dma(q, mq, se, pe, lane, wave, raw_q);
             if (e == 0) {
                 wait_vm_barrier(nb + nq);  // table slice
+#if V1C_RAW_RC_LDS
+    {
+        typedef const __attribute__((address_space(3))) double* lds_f64_ptr;
+        const lds_f64_ptr pr = (lds_f64_ptr)(uintptr_t)(lds_rc + 1024u + (uint32_t)(tid >> 4) * 8u);
+        rc.sl = pr[0], rc.cl = pr[16], rc.hl = pr[32];
+        const lds_f64_ptr pc = (lds_f64_ptr)(uintptr_t)(lds_rc + (uint32_t)(tid & 15) * (kPX * 8u));
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            rc.slon[k] = pc[k], rc.qlon[k] = pc[kTW + k];
+    }
+#endif
                 if (mpoly)
                     lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
                 else
@@ -1937,7 +1978,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
         raw_box_dma(q, mq, src1, pitch1, lane, wave, raw_q + box_bytes);
     // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
     // what the barrier publishes -- vmcnt counts in issue order -- then joins.
-    wait_vm_barrier(NE * (nb + nq));  // table slice landed (this wave's box loads may still be in flight)
+    wait_vm_barrier(NE * (nb + nq));  // table slice (and row / column values) landed (this wave's box loads may still be in flight)
+#if V1C_RAW_RC_LDS
+    {
+        typedef const __attribute__((address_space(3))) double* lds_f64_ptr;
+        const lds_f64_ptr pr = (lds_f64_ptr)(uintptr_t)(lds_rc + 1024u + (uint32_t)(tid >> 4) * 8u);
+        rc.sl = pr[0], rc.cl = pr[16], rc.hl = pr[32];
+        const lds_f64_ptr pc = (lds_f64_ptr)(uintptr_t)(lds_rc + (uint32_t)(tid & 15) * (kPX * 8u));
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            rc.slon[k] = pc[k], rc.qlon[k] = pc[kTW + k];
+    }
+#endif
     if (mpoly)
         lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     else
