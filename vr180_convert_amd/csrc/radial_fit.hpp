@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -203,9 +204,18 @@ inline void fit_parallel_for(int n, F&& body)
         for (int i = t; i < n; i += nt)  // (interleaved: the intervals that need three attempts cluster)
             body(i);
     };
-    for (int t = 1; t < nt; t++)
-        pool.emplace_back(run, t);
+    int started = 1;  // share 0 runs on this thread
+    try {
+        for (int t = 1; t < nt; t++) {
+            pool.emplace_back(run, t);
+            started++;
+        }
+    } catch (const std::system_error&) {
+        // no more threads to be had (resource limits): the shares that did not start run here -- no exception crosses the C ABI
+    }
     run(0);
+    for (int t = started; t < nt; t++)
+        run(t);
     for (auto& th : pool)
         th.join();
 }
