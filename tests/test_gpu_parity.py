@@ -162,6 +162,46 @@ def test_tile_kernels_other_border_modes(V, oracle_mod, dev, interp, border):
         assert np.array_equal(d.cpu().numpy(), w), (interp, border, int((d.cpu().numpy() != w).sum()))
 
 
+def test_border_transparent_bilinear_through_the_tile_kernels(V, oracle_mod, dev):
+    """BORDER_TRANSPARENT with INTER_LINEAR runs the tile kernels since round 3: remapBilinear leaves every pixel whose 2 x 2
+    footprint is not fully inside the source untouched -- exactly the pixels the tile kernels' patch path handles one by one, now
+    with a per-pixel store mask.  Destinations start from a pattern (not zeros): skipped pixels must keep it.  Pairs, a batch,
+    per-unit rotations, zoomed-out chains with a wide skipped rim; NEAREST / Lanczos4 with the same border stay on the generic
+    kernel and must still agree."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    n = 300
+    imgs = [noise_disc(n, n, 80 + f) for f in range(4)]
+    for im in imgs:
+        im[:, :] = np.maximum(im, 1)
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    fill = np.full((288, 352, 3), (11, 22, 33), np.uint8)
+    for spec in ([("equirect_enc", True), ("zoom", 0.55), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), ("zoom", 0.7), CS.EQUI],
+                 [("equirect_enc", True), ("rot", CS.ry(0.4)), ("zoom", 0.8), CS.EQUI]):
+        for interp in (1, 0, 4):
+            xm, ym = O.get_map(spec, radius=n / 2, size_input=(n, n), size_output=(352, 288))
+            want = [O.remap(im, xm, ym, interp, 5, 0, dst=fill.copy()) for im in imgs]
+            assert any((w == fill).all(axis=-1).any() for w in want) and any((w != fill).any() for w in want)
+            for group in (srcs[:2], srcs):  # a pair, a batch
+                dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in group]
+                assert V.remap_tensors(CS.to_product(spec), group, dsts, radius=n / 2, interpolation=interp, boarder_mode=5) == ["ray"]
+                for k, d in enumerate(dsts):
+                    got = d.cpu().numpy()
+                    assert np.array_equal(got, want[k]), (spec, interp, len(group), k, int((got != want[k]).sum()))
+    # per-unit rotations
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.ZoomTransformer(0.7) * T.FisheyeDecoder("equidistant")
+    quats = [CS.c5_spec(f // 2, f % 2)[1][1] for f in range(4)]
+    dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in range(4)]
+    V.remap_tensors(base, srcs, dsts, radius=n / 2, interpolation=1, boarder_mode=5, rotations=quats)
+    for f in range(4):
+        sp = [("equirect_enc", True), CS.c5_spec(f // 2, f % 2)[1], ("zoom", 0.7), CS.EQUI]
+        xm, ym = O.get_map(sp, radius=n / 2, size_input=(n, n), size_output=(352, 288))
+        want = O.remap(imgs[f], xm, ym, 1, 5, 0, dst=fill.copy())
+        assert np.array_equal(dsts[f].cpu().numpy(), want), f
+
+
 def test_nearest_through_the_tile_kernels(V, oracle_mod, dev):
     """INTER_NEAREST on the fused path: pairs (apply_lr), a batch sharing one map, per-unit rotations, a pitched view and a
     half-pixel-exact identity map (ties go to even) -- every byte against the oracle's remapNearest."""

@@ -101,12 +101,13 @@ __device__ __forceinline__ int wave_min_to_lane63(int v)
 }
 
 // (sx, sy) = cv2's fixed-point coordinates cvRound(32 x), cvRound(32 y)
+// (bit 24 of the result: the pixel is to be left untouched -- BORDER_TRANSPARENT with a footprint that leaves the source)
 __device__ __forceinline__ uint32_t slow_pixel_linear3_t(const uint8_t* src, int64_t pitch, int h, int w, Geom g, int sx, int sy)
 {
     uint8_t px[3] = {0, 0, 0};
     const Image im{src, pitch, h, w};
-    sample_linear_t<3>(im, g, taps_from_fixed(sx, sy), px);
-    return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+    const bool st = sample_linear_t<3>(im, g, taps_from_fixed(sx, sy), px);
+    return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | (st ? 0u : 1u << 24);
 }
 
 struct u128 {
@@ -915,6 +916,7 @@ __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitAr
 {
     const Geom& g = c.g;
     const unsigned slow = L.ok & ~done;
+    unsigned skip = 0;  // BORDER_TRANSPARENT (bilinear): pixels whose 2 x 2 footprint leaves the source keep the destination's bytes
     if (slow) {
         if (K == 2) {
             // one inlined copy in a rolled loop (a call would pin every live value above the 40
@@ -925,9 +927,10 @@ __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitAr
                     const int fsx = k == 0 ? L.sx[0] : k == 1 ? L.sx[1] : k == 2 ? L.sx[2] : L.sx[3];
                     const int fsy = k == 0 ? L.sy[0] : k == 1 ? L.sy[1] : k == 2 ? L.sy[2] : L.sy[3];
                     const uint32_t r = slow_pixel_linear3_t(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, fsx, fsy);
+                    skip |= (r >> 24) << k;
 #pragma unroll
                     for (int q = 0; q < kPX; q++)
-                        pix[q] = q == k ? r : pix[q];
+                        pix[q] = q == k ? (r & 0xffffffu) : pix[q];
                 }
             }
         } else {
@@ -943,7 +946,7 @@ __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitAr
     }
     if (!t.active)
         return;
-    store4(dst_ptr(ua, z, t), pix, L.ok, dst_rows_dword_aligned(ua, z));
+    store4(dst_ptr(ua, z, t), pix, L.ok & ~skip, dst_rows_dword_aligned(ua, z));
 }
 
 // ---- taps, blend, slow-path patch and store: shared tail of the kernels ----
@@ -2480,9 +2483,11 @@ static int taps_of(int interp)
 
 bool tile_kernel_supports(const Geom& g)
 {
-    // every border mode but TRANSPARENT (whose skipped pixels the tiled stores cannot express): the
-    // border only matters to pixels whose footprint leaves the source, and those take the generic samplers
-    return g.cn == 3 && g.border != V1C_BORDER_TRANSPARENT && taps_of(g.interp) != 0 && g.src_w >= 3 && g.src_h >= 2;
+    // every border mode (the border only matters to pixels whose footprint leaves the source, and those take the generic
+    // samplers) -- BORDER_TRANSPARENT for INTER_LINEAR only: its skipped pixels (remapBilinear: the 2 x 2 footprint not fully inside)
+    // are what the bilinear patch path leaves unstored; the NEAREST / bicubic / Lanczos4 skip rules differ and stay generic
+    return g.cn == 3 && (g.border != V1C_BORDER_TRANSPARENT || g.interp == V1C_INTER_LINEAR) && taps_of(g.interp) != 0 && g.src_w >= 3 &&
+           g.src_h >= 2;
 }
 
 // threads per workgroup (tile = 64 x threads/16) the plan-time boxes are computed for
