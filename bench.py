@@ -72,13 +72,14 @@ WORKLOADS = {
     "C2NN": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=0,
                  desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_NEAREST (not a BASELINE config: the bilinear tile kernels "
                       "with coordinates 32 * cvRound(x))"),
-    # the generic kernel's configurations (k_remap: coordinates fused, taps from global memory) -- A/B / reporting only
+    # configurations off the BASELINE list -- reporting only: gray / BGRA run the generic kernel (k_remap: coordinates fused, taps from global
+    # memory), bilinear BORDER_TRANSPARENT the tile kernels
     "C2G": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=1,
                 desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, bilinear (generic kernel; not a BASELINE config)"),
     "C2A": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=4,
                 desc="L+R 4096x4096 BGRA -> 8192x4096 SBS, PolynomialScaler, bilinear (generic kernel; not a BASELINE config)"),
     "C2T": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, border=5,
-                desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, bilinear, BORDER_TRANSPARENT (generic kernel; not a BASELINE config)"),
+                desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, bilinear, BORDER_TRANSPARENT (tile kernels since r03; not a BASELINE config)"),
     "C2N": dict(size=4080, poly=[0, 1, -0.1], rot=None, interp=1,
                 desc="L+R 4080x4080 -> 8160x4080 SBS (rows do not mirror about a tile boundary), bilinear (A/B only)"),
     # batch shapes: `frames` SBS frames per GPU per step (BASELINE configs 3 and 5 shard 8 resp. 32 per GPU)
