@@ -2446,7 +2446,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
         raw_box_dma(bA, m, ua.u[zA].src, (uint32_t)ua.u[zA].src_pitch, lane, wave, lds0);
     }
     if (hasB) {
-        lane_coords<VAR_W, 1, 2, 0, 2, MP>(c, ua, zB, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
+        // (unit B's kernel arguments -- 18 scalar registers of rotation matrix alone -- are loaded here, not hoisted in front of
+        // unit A's coordinates: the kernel is at the scalar register limit)
+        int zb = zB;
+        asm volatile("" : "+s"(zb));
+        lane_coords<VAR_W, 1, 2, 0, 2, MP>(c, ua, zb, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
         fastB = raw_box(reduce_box_all_nofence<NT / 64>(LB, red + 16, tid), zB, bB);
         if (fastB) {
             const RawLanes m = raw_lanes(bB.cpr, lane);
