@@ -1331,6 +1331,24 @@ def test_dma_kernels_random_geometries(V, oracle_mod, dev, seed):
     wants = O.apply(spec, srcs_np, size_output=(out_w, out_h), interpolation=1, radius=radius)
     for k in range(5):
         assert np.array_equal(dsts[k].cpu().numpy(), wants[k]), ("batch", k, h_in, w_in, out_w, out_h)
+    # ONE image of the same map: the one-eye instantiation of the mirror kernel (its boxes have a pair's four buffers)
+    dst = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=dev)
+    V.remap_tensors(CS.to_product(spec), [fr[:, w_in:]], [dst], radius=radius, interpolation=1, boarder_value=(9, 8, 7))
+    want1 = O.apply(spec, [np.ascontiguousarray(right)], size_output=(out_w, out_h), interpolation=1, radius=radius, border_value=(9, 8, 7))[0]
+    assert np.array_equal(dst.cpu().numpy(), want1), ("single", h_in, w_in, out_w, out_h)
+    # the pair with INTER_NEAREST (bilinear tile kernels, coordinates 32 * cvRound(x)) and with bilinear BORDER_TRANSPARENT (store mask
+    # in the patch path; the destination starts from a pattern)
+    want = O.apply_lr(spec, left, right, size_output=(out_w, out_h), interpolation=0, radius=radius, border_mode=int(seed % 5), border_value=(9, 8, 7))
+    got = V.apply_lr_tensors(CS.to_product(spec), fr[:, :w_in], fr[:, w_in:], size_output=(out_w, out_h), interpolation=0, radius=radius,
+                             boarder_mode=int(seed % 5), boarder_value=(9, 8, 7)).cpu().numpy()
+    assert np.array_equal(got, want), ("nearest", seed % 5, h_in, w_in, out_w, out_h, int((got != want).sum()))
+    xm, ym = O.get_map(spec, radius=radius, size_input=(h_in, w_in), size_output=(out_w, out_h))
+    fill = np.full((out_h, out_w, 3), (1, 2, 3), np.uint8)
+    wt = [O.remap(np.ascontiguousarray(e), xm, ym, 1, 5, 0, dst=fill.copy()) for e in (left, right)]
+    dts = [torch.from_numpy(fill.copy()).to(dev) for _ in range(2)]
+    V.remap_tensors(CS.to_product(spec), [fr[:, :w_in], fr[:, w_in:]], dts, radius=radius, interpolation=1, boarder_mode=5)
+    for e in range(2):
+        assert np.array_equal(dts[e].cpu().numpy(), wt[e]), ("transparent", e, h_in, w_in, out_w, out_h)
 
 
 @pytest.mark.parametrize("seed", range(8))
