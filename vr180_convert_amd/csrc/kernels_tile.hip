@@ -165,6 +165,7 @@ struct LaneCoords {
 struct RowCol {
     double sl, cl, hl;            // row: sin / cos / 1-cos of the latitude
     double slon[kPX], qlon[kPX];  // columns: sin(lon) and 1-cos(lon) (no rotation) or cos(lon) (rotation)
+    double tlon[kPX];             // ROT = 2 only: slon / qlon / tlon = the unit's column vectors T_k = R_k0 sin(lon) + R_k2 cos(lon), k = 0, 1, 2
 };
 
 template <int ROT>
@@ -208,7 +209,13 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
     const double rx32 = P.rx32, ry32 = P.ry32, cx32 = P.cx32, cy32 = P.cy32;
 
     double A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, C0 = 0, C1 = 0, C2 = 0;
-    if (ROT) {
+    // ROT = 2: the rotated ray in its separable form v'_k = cos(lat) T_k(column) + sin(lat) R_k1 -- the per-column vectors T_k come
+    // with rc (computed once per tile column and unit), the lane adds 3 products and 3 FMAs per pixel instead of 9 + 6
+    if (ROT == 2) {
+        C0 = (ua.u[z].has_rot ? ua.u[z].rot[1] : P.rot[1]) * sl;
+        C1 = (ua.u[z].has_rot ? ua.u[z].rot[4] : P.rot[4]) * sl;
+        C2 = (ua.u[z].has_rot ? ua.u[z].rot[7] : P.rot[7]) * sl;
+    } else if (ROT) {
         double R[9];
 #pragma unroll
         for (int q = 0; q < 9; q++)
@@ -228,7 +235,11 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
         double m;
-        if (ROT) {
+        if (ROT == 2) {
+            fx_[k] = fma(cl, slon[k], C0);
+            fy_[k] = fma(cl, qlon[k], C1);
+            m = 1.0 - fma(cl, rc.tlon[k], C2);
+        } else if (ROT) {
             fx_[k] = fma(A0, slon[k], fma(B0, qlon[k], C0));
             fy_[k] = fma(A1, slon[k], fma(B1, qlon[k], C1));
             m = 1.0 - fma(A2, slon[k], fma(B2, qlon[k], C2));
@@ -2334,6 +2345,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
 // table), full tiles whose box lies inside the source and fits a buffer; every other (unit, tile) goes through rot_unit_tile.
 // Waits: a box is followed by at least the other unit's requests / by the first unit's store (lower bounds: loads the
 // coordinates make in between only make a wait longer).
+#ifndef V1C_ROTPAIR_SEPARABLE
+#define V1C_ROTPAIR_SEPARABLE 0  // 1 (A/B builds): k_ray_lin3_rot_pair_raw takes per-column vectors of the rotated ray through LDS instead of rotating every
+                                 // ray in its lane: 17 instead of 33 fp64 operations per lane and unit, bit-exact, and 18 % SLOWER (C5 3.03 against 2.565 ms,
+                                 // profiles/r03b_final/ab_rot_separable.log): a serial load -> compute -> barrier prologue and 12 LDS reads per lane and unit
+#endif
 #ifndef V1C_ROTPAIR_WAVES
 #define V1C_ROTPAIR_WAVES 5
 #endif
@@ -2423,7 +2439,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box;
     RowCol rc;
+#if V1C_ROTPAIR_SEPARABLE
+    // The rotated ray in its separable form: per tile column and unit T_k = R_k0 sin(lon) + R_k2 cos(lon) (k = 0, 1, 2), computed once
+    // by wave 0 (unit A) and wave 1 (unit B) -- a lane per column -- and handed over through LDS; a pixel then costs 3 FMAs
+    // (v'_k = cos(lat) T_k + sin(lat) R_k1) instead of 6, a lane-unit 17 fp64 operations for the ray instead of 33, and the lanes load
+    // 2 row values instead of 2 + 8 row / column values each.
+    double* colT = (double*)((uint8_t*)dyn_box + red_off + kRotPairRedInts * sizeof(int));  // [2 units][3][64 columns]
+    rc.sl = P.row_s[t.jc], rc.cl = P.row_c[t.jc], rc.hl = 0.0;
+    if (wave == 0 || (wave == 1 && hasB)) {
+        const int z = wave ? zB : zA;
+        const double sc = P.col_s[btx * kTW + lane], cc = P.col_c[btx * kTW + lane];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double r0 = ua.u[z].has_rot ? ua.u[z].rot[3 * k] : P.rot[3 * k];
+            const double r2 = ua.u[z].has_rot ? ua.u[z].rot[3 * k + 2] : P.rot[3 * k + 2];
+            colT[(wave * 3 + k) * kTW + lane] = fma(r0, sc, r2 * cc);
+        }
+    }
+    __syncthreads();  // (nothing is in flight yet)
+    auto unit_cols = [&](int unit) {
+        const double* p = colT + unit * 3 * kTW + (tid & 15) * kPX;
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            rc.slon[k] = p[k], rc.qlon[k] = p[kTW + k], rc.tlon[k] = p[2 * kTW + k];
+    };
+    constexpr int RM = 2;
+#else
     load_rowcol<1>(P, t.xc, t.jc, rc);
+    auto unit_cols = [&](int) {};
+    constexpr int RM = 1;
+#endif
     // box of all 1024 pixels of a unit -> is the tile interior, does its raw box fit a buffer
     auto raw_box = [&](const BoxAll& ba, int z, TileBox& b) -> bool {
         b.x0 = ba.xmin & ~3, b.y0 = ba.ymin;
@@ -2439,7 +2484,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     TileBox bA, bB;
     bool fastA, fastB = false;
     int nB = 0;
-    lane_coords<VAR_W, 1, 2, 0, 2, MP>(c, ua, zA, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LA);
+    unit_cols(0);
+    lane_coords<VAR_W, RM, 2, 0, 2, MP>(c, ua, zA, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LA);
     fastA = raw_box(reduce_box_all_nofence<NT / 64>(LA, red, tid), zA, bA);
     if (fastA) {
         const RawLanes m = raw_lanes(bA.cpr, lane);
@@ -2450,7 +2496,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
         // unit A's coordinates: the kernel is at the scalar register limit)
         int zb = zB;
         asm volatile("" : "+s"(zb));
-        lane_coords<VAR_W, 1, 2, 0, 2, MP>(c, ua, zb, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
+        unit_cols(1);
+        lane_coords<VAR_W, RM, 2, 0, 2, MP>(c, ua, zb, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
         fastB = raw_box(reduce_box_all_nofence<NT / 64>(LB, red + 16, tid), zB, bB);
         if (fastB) {
             const RawLanes m = raw_lanes(bB.cpr, lane);
@@ -2969,7 +3016,8 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     if constexpr (K == 2) {
         if (!bx && shared_entry && !rot_pair_off && !nn) {
             const dim3 pgrid(grid.x, grid.y, (unsigned)((n_units + 1) / 2));
-            const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int);
+            const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int) +
+                                (V1C_ROTPAIR_SEPARABLE ? 2 * 3 * kTW * sizeof(double) : 0);
             const bool mp = mpoly_all && c.ray.radial_m != nullptr;
             if (c.ray.var_is_w) {
                 if (mp)
