@@ -1896,8 +1896,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const uint8_t* __restrict__ src1 = ua.u[NE - 1].src;
     const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[NE - 1].src_pitch;
     const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
-    // (one image: its two boxes have the four buffers of a pair)
-    const int fit = mirror_raw_fit(b, q, NE == 1 ? 2 * nwp : nwp, g.src_h, g.src_w);
+    const int fit = mirror_raw_fit(b, q, nwp, g.src_h, g.src_w);
     if (fit == 0 || (fit == 2 && (NE == 1 || !V1C_MIRROR_BIG)))
         return;
     const bool mpoly = (b.interior & 2) != 0;
@@ -1911,7 +1910,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
 #endif
     const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
     const uint32_t box_bytes = (uint32_t)nwp * 1024u;
-    const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + 2u * box_bytes;
+    // (one image: two boxes -- half the LDS of a pair's workgroup, 7 workgroups per CU at 67 VGPRs)
+    const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + (uint32_t)NE * box_bytes;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {  // table slice: nidx * 4 units of 16 bytes, one pass (units past the slice: clamped, they land in the unused tail of tabw)
         const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
@@ -2609,7 +2609,7 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
         for (unsigned ty = 0; ty <= TYh; ty++)
             for (unsigned tx = 0; tx < d.x; tx++) {
                 const size_t i = (size_t)ty * d.x + tx;
-                const int fit = mirror_raw_fit(b[i], q[i], n_eyes == 1 ? 2 * raw_nwp : raw_nwp, g.src_h, g.src_w);
+                const int fit = mirror_raw_fit(b[i], q[i], raw_nwp, g.src_h, g.src_w);
                 if (fit == 0 || (fit == 2 && (n_eyes == 1 || !V1C_MIRROR_BIG))) {
                     add(tx, ty);
                     if (ty < TYh) {  // its band: 15 rows of tile row TY - 1 - ty and (ty > 0) the first row of tile row TY - ty
@@ -2684,6 +2684,8 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     if (raw_nwp > 0 && n_eyes == 1) {  // a single image: the LDS-DMA kernel's one-eye instantiation
         const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
         const dim3 rgrid(full.x, raw_rows + rest_rows, 1);
+        // two boxes; the general pair code serves one unit from one cell buffer
+        const size_t lds = std::max((size_t)half_dwords * 4 + 16, (size_t)2 * 1024 * (size_t)raw_nwp);
         if (c.ray.var_is_w)
             hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1, 1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
                                half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
