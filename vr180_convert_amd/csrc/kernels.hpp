@@ -53,12 +53,13 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry,
 // (apply_lr's pair) or 1 (a single image: its own list)
 bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
                       std::vector<uint32_t>& rest, int raw_nwp, bool full_rows = false, int n_eyes = 2);
-int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, const Geom& g);
+int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, const Geom& g, int permille = 980, int max_kb = 12);
 // `pipe_tab` > 0: k_ray_lin3_pair_mirror_pipe (two tile rows per workgroup, the second pair's boxes requested while the first is
 // sampled), tile_mirror_pipe_tab() table entries per pair in LDS
 hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
                                        int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream,
-                                       int n_eyes = 2);  // n_eyes = 1 (raw_nwp > 0): a single image through the same workgroups
+                                       int n_eyes = 2,   // n_eyes = 1 (raw_nwp > 0): a single image through the same workgroups
+                                       int seq_kb = 0);  // > 0 (pairs): k_ray_lin3_pair_mirror_seq, two box buffers of seq_kb KB, the eyes one after the other
 int tile_mirror_pipe_tab(const void* host_boxes, const void* host_mboxes, const Geom& g, int raw_nwp);
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,

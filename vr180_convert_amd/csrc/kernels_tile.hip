@@ -1587,7 +1587,6 @@ __host__ __device__ inline bool mirror_static_ok(const TileBox& b, const TileBox
 // a box buffer holds `nwp` wave-passes of 64 units (the plan sizes it: tile_mirror_raw_passes); the last unit of a row
 // reads up to 12 bytes past the box (never past the image)
 constexpr int kRawMaxWavePasses = 16;  // 16 KB per box and eye
-constexpr int kMirrorRawMaxKB = 12;    // ... of the mirror launch (4 boxes per workgroup: 48 KB; larger boxes go to the rest list)
 __host__ __device__ inline int raw_units_per_row(int cpr)
 {
     return (3 * cpr + 3) >> 2;
@@ -2025,6 +2024,119 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
         if (band_row)
             store4(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(ua, 0));
     }
+}
+
+// ---- the pair kernel with the eyes one after the other: two box buffers instead of four ----
+// k_ray_lin3_pair_mirror_raw holds four boxes (two eyes x tile and band) in LDS at once.  Here the workgroup keeps two buffers (tile
+// box, band box) and serves eye 0, then eye 1 with the SAME tap addresses and weights (one map per call: both eyes read the same
+// box positions), requesting eye 1's tile box as soon as every wave has sampled eye 0's, and its band box likewise:
+//   requests: table slice, b(eye 0), q(eye 0) | coordinates -> tap addresses + weights of tile and band (24 registers)
+//   gather b | -> request b(eye 1) | store | gather q | -> request q(eye 1) | store | gather b | store | gather q | store
+// With the LDS of the four-box form each buffer holds boxes of twice the size -- the pairs that went to the general pair code for
+// their size (2 % of the tiles, 3 - 6 % of a C2 launch) stay here -- or, with the same capacity, a workgroup takes half the LDS
+// (C1's 9 KB boxes: 4 -> 6 workgroups per CU); a gather holds one eye's taps (24 registers instead of 48).
+#ifndef V1C_SEQ_WAVES
+#define V1C_SEQ_WAVES 6
+#endif
+__device__ __forceinline__ void gather_taps_raw(const uint32_t (&ta)[kPX], const BlendW (&W)[kPX], uint32_t pitch, uint32_t (&pix)[kPX])
+{
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        const uint32_t a = ta[k], d = a & ~3u;
+        const lds_u32_ptr r0 = (lds_u32_ptr)(uintptr_t)d, r1 = (lds_u32_ptr)(uintptr_t)(d + pitch);
+        const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+        pix[k] = blend3<3>(__builtin_amdgcn_alignbyte(a1, a0, a), __builtin_amdgcn_alignbyte(a2, a1, a), __builtin_amdgcn_alignbyte(b1, b0, a),
+                           __builtin_amdgcn_alignbyte(b2, b1, a), W[k]);
+    }
+}
+
+template <int VAR_W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_SEQ_WAVES, 8))) void k_ray_lin3_pair_mirror_seq(
+    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
+    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int cap_kb,
+    unsigned rest_rows)
+{
+    constexpr int NT = 256;
+    __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 raw boxes of cap_kb KB (or the general code's cell buffers)
+    const int tid = threadIdx.x;
+    if (blockIdx.y < rest_rows) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= (unsigned)n_rest)
+            return;
+        const uint32_t v = rest_list[lin];
+        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
+                                                  tabw, (glb_u32_ptr)c.itab);
+        return;
+    }
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    int tx, ty;
+    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
+    const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
+    RowCol rc;
+    load_rowcol<0>(P, t.xc, t.jc, rc);
+    const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
+    if (mirror_raw_fit(b, q, cap_kb, g.src_h, g.src_w) != 1)
+        return;
+    const bool mpoly = (b.interior & 2) != 0;
+#pragma unroll
+    for (int k = 0; k < kPX; k++)
+        asm volatile("" ::"v"(rc.slon[k]), "v"(rc.qlon[k]));
+    asm volatile("" ::"v"(rc.sl), "v"(rc.cl), "v"(rc.hl));
+    const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
+    const uint32_t raw_b = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, raw_q = raw_b + (uint32_t)cap_kb * 1024u;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    {
+        const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
+        const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
+    }
+    const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
+    const int nb = raw_box_dma(b, mb, ua.u[0].src, (uint32_t)ua.u[0].src_pitch, lane, wave, raw_b);
+    const int nq = raw_box_dma(q, mq, ua.u[0].src, (uint32_t)ua.u[0].src_pitch, lane, wave, raw_q);
+    wait_vm_barrier(nb + nq);  // table slice
+    const uint32_t pitch_b = (uint32_t)raw_units_per_row(b.cpr) * 16u, pitch_q = (uint32_t)raw_units_per_row(q.cpr) * 16u;
+    uint32_t ta_b[kPX], ta_q[kPX];
+    BlendW W_b[kPX], W_q[kPX];
+    {
+        LaneCoords L;
+        if (mpoly)
+            lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+        else
+            lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const uint32_t ixb = (uint32_t)((L.sx[k] >> 5) - b.x0), ixq = (uint32_t)((L.sx[k] >> 5) - q.x0);
+            ta_b[k] = __umul24((uint32_t)((L.sy[k] >> 5) - b.y0), pitch_b) + (ixb * 2u + ixb) + raw_b;
+            ta_q[k] = __umul24((uint32_t)((L.sy2[k] >> 5) - q.y0), pitch_q) + (ixq * 2u + ixq) + raw_q;
+            W_b[k] = blend_weights(L.sx[k], L.sy[k]);
+            W_q[k] = blend_weights(L.sx[k], L.sy2[k]);
+        }
+    }
+    const uint32_t row_off = (uint32_t)t.x0 * 3u;
+    const int jm = mirror_h - t.j;
+    const bool band_row = jm < g.dst_h;
+    uint32_t pix[kPX];
+    // ---- eye 0 ----
+    wait_vm_barrier(nq);  // tile box
+    gather_taps_raw(ta_b, W_b, pitch_b, pix);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // band box landed; every wave has sampled the tile box
+    raw_box_dma(b, mb, ua.u[1].src, (uint32_t)ua.u[1].src_pitch, lane, wave, raw_b);
+    store4(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 0));
+    gather_taps_raw(ta_q, W_q, pitch_q, pix);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has sampled the band box
+    raw_box_dma(q, mq, ua.u[1].src, (uint32_t)ua.u[1].src_pitch, lane, wave, raw_q);
+    if (band_row)
+        store4(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 0));
+    // ---- eye 1 (behind its tile box: eye 0's tile store and its band's nq requests; the predicated band store is not counted) ----
+    wait_vm_barrier(nq + 1);
+    gather_taps_raw(ta_b, W_b, pitch_b, pix);
+    wait_vm_barrier_imm<0>();
+    store4(ua.u[1].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 1));
+    gather_taps_raw(ta_q, W_q, pitch_q, pix);
+    if (band_row)
+        store4(ua.u[1].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 1));
 }
 
 // ---- two tile pairs per workgroup: the second pair's boxes are in flight while the first one is sampled ----
@@ -2564,7 +2676,9 @@ size_t tile_box_bytes(const Geom& g)
 // Box buffer size (wave-passes of 64 sixteen-byte units) of k_ray_lin3_pair_mirror_raw for a plan: the smallest that holds the
 // boxes of 98 % of the tile pairs (the others go to the general code with the rest list); 4 boxes of nwp KB each set the
 // workgroups per CU.
-int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, const Geom& g)
+// `permille`: the share of the tile pairs the buffers must hold (980: k_ray_lin3_pair_mirror_raw; 998 with `max_kb` 11:
+// k_ray_lin3_pair_mirror_seq, whose two buffers leave room for nearly every box)
+int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, const Geom& g, int permille, int max_kb)
 {
     const TileBox* b = (const TileBox*)host_boxes;
     const TileBox* q = (const TileBox*)host_mboxes;
@@ -2582,10 +2696,10 @@ int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, cons
     size_t acc = 0;
     for (int k = 0; k <= kRawMaxWavePasses; k++) {
         acc += hist[k];
-        if (acc * 100 >= n * 98)
-            return std::min(std::max(k, 4), kMirrorRawMaxKB);
+        if (acc * 1000 >= n * (size_t)permille)
+            return std::min(std::max(k, 4), max_kb);
     }
-    return kMirrorRawMaxKB;
+    return max_kb;
 }
 
 // `full_rows` (raw_nwp > 0): the list for k_ray_lin3_pair_mirror_raw, whose workgroups serve tile rows 0 .. TY / 2 (mirror_raw_fit) and
@@ -2657,7 +2771,7 @@ int tile_mirror_pipe_tab(const void* host_boxes, const void* host_mboxes, const 
 // `pipe_tab` > 0 (with raw_nwp > 0): k_ray_lin3_pair_mirror_pipe, two tile rows per workgroup, pipe_tab table entries per pair in LDS
 hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
                                        int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream,
-                                       int n_eyes)
+                                       int n_eyes, int seq_kb)
 {
     const dim3 full = tile_grid(c.g, 256, 1);
     const dim3 grid(full.x, full.y / 2 - 1, 2), block(256, 1, 1);
@@ -2681,6 +2795,18 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     const unsigned raw_per = (grid.x * raw_rows) >> 3;
     const unsigned raw_slen = (slen & 0x80000000u) ? slen : (strip_rows && strip_rows * grid.x < raw_per ? strip_rows * grid.x : 0u);
     const unsigned raw_smagic = (raw_slen && !(raw_slen & 0x80000000u)) ? (unsigned)(0x100000000ull / raw_slen) + 1u : 0u;
+    if (seq_kb > 0 && n_eyes == 2) {  // the eyes one after the other: two buffers of seq_kb KB (rest list made for that size)
+        const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
+        const dim3 rgrid(full.x, raw_rows + rest_rows, 1);
+        const size_t slds = std::max((size_t)half_dwords * 8 + 16, (size_t)2 * 1024 * (size_t)seq_kb);
+        if (c.ray.var_is_w)
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<1>), rgrid, block, slds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, seq_kb, rest_rows);
+        else
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<0>), rgrid, block, slds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, seq_kb, rest_rows);
+        return hipGetLastError();
+    }
     if (raw_nwp > 0 && n_eyes == 1) {  // a single image: the LDS-DMA kernel's one-eye instantiation
         const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
         const dim3 rgrid(full.x, raw_rows + rest_rows, 1);

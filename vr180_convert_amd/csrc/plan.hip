@@ -179,6 +179,7 @@ struct v1c_plan {
     void* mirror_boxes = nullptr;
     const uint32_t* mirror_rest = nullptr;
     int n_mirror_rest = 0;
+    int mirror_seq_kb = 0;                   // > 0: pairs through k_ray_lin3_pair_mirror_seq (two buffers of so many KB; mirror_rest is made for it)
     const uint32_t* mirror_rest1 = nullptr;  // ... of single-image launches (one eye: its two boxes have a pair's four buffers)
     int n_mirror_rest1 = -1;                 // -1: no single-image mirror launch
     int mirror_raw_nwp = 0;  // > 0: the mirror launch brings its boxes in by LDS-DMA (k_ray_lin3_pair_mirror_raw), buffers of so many KB
@@ -514,7 +515,14 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         // C2 / C1: 0.0497 / 0.0205 ms against 0.0472 / 0.0185 ms for k_ray_lin3_pair_mirror_raw
                         const char* pipesw = tuning_env("V1C_MIRROR_PIPE");
                         const bool pipe = p->mirror_raw_nwp > 0 && pipesw && pipesw[0] == '1';
-                        if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest, p->mirror_raw_nwp, !pipe, 2)) {
+                        // V1C_MIRROR_SEQ=1 (A/B): the eyes of a pair one after the other in two buffers (k_ray_lin3_pair_mirror_seq);
+                        // V1C_MIRROR_SEQ_KB=<n>: their size
+                        const char* seqsw = tuning_env("V1C_MIRROR_SEQ");
+                        const char* seqkb = tuning_env("V1C_MIRROR_SEQ_KB");
+                        if (p->mirror_raw_nwp > 0 && !pipe && seqsw && seqsw[0] == '1')
+                            p->mirror_seq_kb = seqkb ? std::min(std::max(std::atoi(seqkb), 2), 16) : tile_mirror_raw_passes(hb.data(), hm.data(), g, 998, 11);
+                        if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest,
+                                             p->mirror_seq_kb > 0 ? p->mirror_seq_kb : p->mirror_raw_nwp, !pipe, 2)) {
                             if ((rc = upload(p, mrest, &p->mirror_rest))) {
                                 v1c_plan_destroy(p);
                                 return rc;
@@ -531,7 +539,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                                 p->n_mirror_rest1 = (int)mrest1.size();
                             }
                             if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
-                                std::fprintf(stderr, "[v1c] mirror launch: largest table slice %d entries\n",
+                                std::fprintf(stderr, "[v1c] mirror launch: seq buffers %d KB; largest table slice %d entries\n", p->mirror_seq_kb,
                                              tile_mirror_pipe_tab(hb.data(), hm.data(), g, p->mirror_raw_nwp));
                         }
                         if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
@@ -680,7 +688,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             if (mirror) {
                 HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h,
                                                     n == 1 ? p->mirror_rest1 : p->mirror_rest, n == 1 ? p->n_mirror_rest1 : p->n_mirror_rest,
-                                                    p->mirror_raw_nwp, p->mirror_pipe_tab, st, n));
+                                                    p->mirror_raw_nwp, p->mirror_pipe_tab, st, n, p->mirror_seq_kb));
             } else if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
