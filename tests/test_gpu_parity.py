@@ -239,6 +239,45 @@ def test_nearest_through_the_tile_kernels(V, oracle_mod, dev):
         assert np.array_equal(dsts[f].cpu().numpy(), want), f
 
 
+def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev):
+    """Grayscale and BGRA sources (cv2.remap takes whatever array the caller passes, remapper.py:388-398) run k_ray_lin_cn:
+    plain and rotated chains, every border mode (TRANSPARENT over a pre-filled destination), batches of 1 - 5 units sharing the map,
+    odd output sizes, sources that are pitched views, a radius larger than the source (rays leaving it) -- every byte against the oracle."""
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    rng = np.random.default_rng(777)
+    specs = ([("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI],
+             [("equirect_enc", True), ("rot", CS.ry(0.3)), ("poly", [0, 1, -0.1]), CS.EQUI])
+    for cn in (1, 4):
+        for si, spec in enumerate(specs):
+            for border, bval in ((0, 77), (1, 0), (2, 0), (4, 0), (5, 0)):
+                hs, ws = 300 + 4 * si, 320
+                wo, ho = (333, 250) if border != 1 else (512, 384)
+                n = 1 + (si + border) % 5
+                wide = [rng.integers(0, 256, (hs, ws + 8, cn), dtype=np.uint8) for _ in range(n)]
+                imgs = [np.ascontiguousarray(w[:, 4:4 + ws]) for w in wide]
+                dev_wide = [torch.from_numpy(w).to(dev) for w in wide]
+                srcs = [w[:, 4:4 + ws] for w in dev_wide]  # pitched views (dword-aligned)
+                fill = rng.integers(0, 256, (ho, wo, cn), dtype=np.uint8)
+                dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in range(n)]
+                radius = 140.0 if border != 4 else 190.0
+                modes = V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=radius, interpolation=1, boarder_mode=border, boarder_value=bval)
+                assert modes == ["ray"], modes
+                xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+                for k in range(n):
+                    want = O.remap(imgs[k], xm, ym, 1, border, bval, dst=fill.copy())
+                    got = dsts[k].cpu().numpy()
+                    assert np.array_equal(got, want), (cn, si, border, k, int((got != want).sum()))
+    # a full-size pair of gray halves, box buffers too small for most tiles (V1C_CN_KB is a tuning-build switch; here: huge magnification)
+    img = rng.integers(0, 256, (1024, 1024, 1), dtype=np.uint8)
+    d = torch.empty((96, 96, 1), dtype=torch.uint8, device=dev)
+    spec = [("equirect_enc", True), ("zoom", 0.08), CS.EQUI]
+    V.remap_tensors(CS.to_product(spec), [torch.from_numpy(img).to(dev)], [d], radius=512.0, interpolation=1)
+    xm, ym = O.get_map(spec, radius=512.0, size_input=(1024, 1024), size_output=(96, 96))
+    assert np.array_equal(d.cpu().numpy(), O.remap(img, xm, ym, 1, 0, 0))
+
+
 def test_seeded_random_cases_bit_exact(V, oracle_mod, dev):
     """Differential sweep: seeded random output / source sizes (odd, tiny, non-square), radii,
     chains of the ray and literal kinds, interpolations, border modes / values and unit counts --

@@ -42,6 +42,11 @@ hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float
 
 // hot configuration (CN = 3, INTER_LINEAR, BORDER_CONSTANT, ray mode): kernels_tile.hip
 bool tile_kernel_supports(const Geom& g);
+// k_ray_lin_cn (grayscale / BGRA, bilinear): same plan-time boxes (launch_tile_boxes); `kb` = tile_cn_box_kb(); every source and its
+// pitch dword-aligned, no unit overriding the rotation, one table entry per lane (shared_entry)
+bool cn_kernel_supports(const Geom& g);
+int tile_cn_box_kb(const void* host_boxes, const Geom& g);
+hipError_t launch_ray_lin_cn(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int kb, hipStream_t stream);
 size_t tile_box_bytes(const Geom& g);
 hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream, int mirror_h = 0);
 // apply_lr pairs of unrotated chains: a tile and its mirror image about the equator from one set of coordinates

@@ -1744,10 +1744,10 @@ struct RawLanes {
     int R, upr;             // wave-uniform
 };
 
-__device__ __forceinline__ RawLanes raw_lanes(int cpr, int lane)
+__device__ __forceinline__ RawLanes raw_lanes_upr(int upr, int lane)
 {
     RawLanes m;
-    m.upr = raw_units_per_row(cpr);
+    m.upr = upr;
     // floor(64 / upr) and floor(l / upr) without a division: (64 + 0.5) / upr and (l + 0.5) / upr stay 0.5 / 48 away from
     // every integer, fp32's error here is < 1e-4
     const float rupr = __builtin_amdgcn_rcpf((float)m.upr);
@@ -1757,6 +1757,13 @@ __device__ __forceinline__ RawLanes raw_lanes(int cpr, int lane)
     return m;
 }
 
+__device__ __forceinline__ RawLanes raw_lanes(int cpr, int lane)
+{
+    return raw_lanes_upr(raw_units_per_row(cpr), lane);
+}
+
+// BPP: bytes per source pixel (3: packed BGR; 1 / 4: k_ray_lin_cn)
+template <int BPP = 3>
 __device__ __forceinline__ int raw_box_dma(const TileBox& b, const RawLanes& m, const uint8_t* __restrict__ src, uint32_t spitch, int lane,
                                             int wave, uint32_t lds_box)
 {
@@ -1766,7 +1773,7 @@ __device__ __forceinline__ int raw_box_dma(const TileBox& b, const RawLanes& m, 
     const int rows = min(m.R, b.nrows);
     const int last0 = b.nrows - rows;  // first row of the last pass
     const bool active = lane < rows * m.upr;
-    const uint8_t* org = src + (__umul24((uint32_t)b.y0, spitch) + (uint32_t)b.x0 * 3u);
+    const uint8_t* org = src + (__umul24((uint32_t)b.y0, spitch) + (uint32_t)b.x0 * (uint32_t)BPP);
     const uint32_t lpitch = (uint32_t)m.upr * 16u;
     int n = 0;
     for (int r0 = wave * m.R; r0 < b.nrows; r0 += 4 * m.R) {  // wave-uniform
@@ -2638,6 +2645,180 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     }
 }
 
+
+// ---- grayscale and BGRA (cn = 1 / 4), bilinear, plan-time boxes: k_ray_lin_cn ----
+// The reference hands cv2.remap whatever array the caller passes (remapper.py:388-398); BGR has the kernels above, the other two channel
+// counts cv2 images come in run this one: the same tiles, boxes, radial-table slices and coordinates (lane_coords), the source box as it
+// is in memory by LDS-DMA (rows of 16-byte units, as k_ray_lin3_batch_lean_raw), two box buffers -- the next unit's box is in flight while
+// this one is sampled -- and one workgroup per tile walking all units of the launch (they share the map).  Pixels the box cannot serve
+// (footprint leaving the source: border rules; a box beyond the buffers; an unaligned source) take the border-aware per-pixel sampler
+// sample_linear_t<CN> from global memory; table intervals the fit flagged go to the fix-up launch like everywhere else.
+template <int CN>
+__host__ __device__ inline int cn_units_per_row(int cpr)
+{
+    return CN == 1 ? (cpr + 3) >> 2 : cpr;  // 4 cpr pixels of CN bytes in 16-byte units
+}
+template <int CN>
+__host__ __device__ inline bool cn_box_ok(int x0, int y0, int cpr, int nrows, int kb, int src_h, int src_w)
+{
+    const int upr = cn_units_per_row<CN>(cpr);
+    // (the last unit of a row may read past the box -- never past the image's last row)
+    return cpr > 0 && cpr <= kMaxCpr && nrows > 0 && nrows * upr <= kb * 64 && !((y0 + nrows >= src_h) && (x0 * CN + upr * 16 > src_w * CN));
+}
+
+// result byte of one channel: taps (p0, p1) of the upper and the lower row as bytes `LO`, `HI` of the 8 bytes (ahi : alo) / (bhi : blo)
+template <uint32_t SEL>
+__device__ __forceinline__ uint32_t blend_channel(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, const BlendW w)
+{
+    const uint32_t pa = __builtin_amdgcn_perm(ahi, alo, SEL), pb = __builtin_amdgcn_perm(bhi, blo, SEL);
+    uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pa), __builtin_bit_cast(ushort2v, w.wa), 32768u, false);
+    v = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pb), __builtin_bit_cast(ushort2v, w.wb), v, false);
+    return v;  // the channel is byte 2
+}
+
+// taps of a lane's 4 pixels from a raw box in LDS (`ta`: byte address of the top-left tap), blend; one dword per pixel (CN = 4) or one
+// byte per pixel in the low byte (CN = 1)
+template <int CN>
+__device__ __forceinline__ void gather_cn(const uint32_t (&ta)[kPX], const BlendW (&W)[kPX], uint32_t pitch, uint32_t (&pix)[kPX])
+{
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        const uint32_t a = ta[k], d = a & ~3u;
+        const lds_u32_ptr r0 = (lds_u32_ptr)(uintptr_t)d, r1 = (lds_u32_ptr)(uintptr_t)(d + pitch);
+        const uint32_t a0 = r0[0], a1 = r0[1], b0 = r1[0], b1 = r1[1];
+        if (CN == 1) {
+            const uint32_t ra = __builtin_amdgcn_alignbyte(a1, a0, a), rb = __builtin_amdgcn_alignbyte(b1, b0, a);
+            pix[k] = blend_channel<0x0c010c00u>(ra, 0u, rb, 0u, W[k]) >> 16;
+        } else {
+            const uint32_t v0 = blend_channel<0x0c040c00u>(a0, a1, b0, b1, W[k]), v1 = blend_channel<0x0c050c01u>(a0, a1, b0, b1, W[k]);
+            const uint32_t v2 = blend_channel<0x0c060c02u>(a0, a1, b0, b1, W[k]), v3 = blend_channel<0x0c070c03u>(a0, a1, b0, b1, W[k]);
+            const uint32_t lo = __builtin_amdgcn_perm(v1, v0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(v3, v2, 0x06020c0cu);
+            pix[k] = lo | hi;
+        }
+    }
+}
+
+template <int CN>
+__device__ __forceinline__ void store_cn(uint8_t* drow, const uint32_t (&pix)[kPX], unsigned ok, bool aligned)
+{
+    if (ok == 0xFu && aligned) {
+        uint32_t* d32 = (uint32_t*)drow;
+        if (CN == 1) {
+            __builtin_nontemporal_store((pix[0] & 255u) | ((pix[1] & 255u) << 8) | ((pix[2] & 255u) << 16) | (pix[3] << 24), d32);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPX; k++)
+                __builtin_nontemporal_store(pix[k], d32 + k);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            if (ok & (1u << k)) {
+#pragma unroll
+                for (int ch = 0; ch < CN; ch++)
+                    drow[CN * k + ch] = (uint8_t)(pix[k] >> (8 * ch));
+            }
+    }
+}
+
+template <int VAR_W, int ROT, int CN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_ray_lin_cn(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes,
+                                                                                                 int n_units, unsigned tiles_x_magic,
+                                                                                                 unsigned strip_len, unsigned strip_magic, int kb)
+{
+    constexpr int K = 2;
+    __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // two box buffers of kb KB (+ 16 bytes: the gather's third dword)
+    const Geom& g = c.g;
+    const RayParams& P = c.ray;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int tx, ty;
+    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+    const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, 16);
+    const TileBox b = load_tile_box(boxes, t.box_tile);
+    const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
+    const bool mpoly = (b.interior & 2) != 0;
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    d2 tv = {0.0, 0.0};
+    if (tab_lds && tid < b.nidx * 4)
+        tv = ((const d2*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs))[tid];
+    RowCol rc;
+    load_rowcol<ROT>(P, t.xc, t.jc, rc);
+    if (tab_lds && tid < b.nidx * 4)
+        ((d2*)tabw)[tid] = tv;
+    __syncthreads();
+    // every source dword-aligned (host) and the box inside the buffers: wave-uniform
+    const bool fits = cn_box_ok<CN>(b.x0, b.y0, b.cpr, b.nrows, kb, g.src_h, g.src_w);
+    const int upr = cn_units_per_row<CN>(b.cpr);
+    const RawLanes m = raw_lanes_upr(max(upr, 1), lane);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, buf_bytes = (uint32_t)kb * 1024u;
+    if (fits)  // the first unit's box flies behind the coordinates
+        raw_box_dma<CN>(b, m, ua.u[0].src, (uint32_t)ua.u[0].src_pitch, lane, wave, lds0);
+    const bool interior = tab_lds & (b.interior != 0);
+    LaneCoords L;
+    if (interior && mpoly)
+        lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, 0>(c, ua, 0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+    else if (interior)
+        lane_coords<VAR_W, ROT, K, 0, 1, 0, 0, 0>(c, ua, 0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+    else if (tab_lds)
+        lane_coords<VAR_W, ROT, K, 0, 0, 0, 0, 0>(c, ua, 0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+    else
+        lane_coords<VAR_W, ROT, K, 0, 0, 0, 0, 0>(c, ua, 0, rc, t.npx, P.radial, 0, P.n_int, L);
+    const bool incomplete = L.ok != (1u << t.npx) - 1;
+    const uint32_t lpitch = (uint32_t)upr * 16u;
+    uint32_t ta[kPX];
+    BlendW W[kPX];
+#pragma unroll
+    for (int k = 0; k < kPX; k++) {
+        const bool in = (L.inside >> k) & 1;
+        ta[k] = in ? __umul24((uint32_t)((L.sy[k] >> 5) - b.y0), lpitch) + (uint32_t)((L.sx[k] >> 5) - b.x0) * (uint32_t)CN : 0u;
+        W[k] = blend_weights(L.sx[k], L.sy[k]);
+    }
+    for (int u = 0; u < n_units; u++) {
+        if (incomplete)
+            c.tile_flags[t.flag_tile + u * t.flag_stride] = 1;
+        uint32_t pix[kPX] = {0u, 0u, 0u, 0u};
+        unsigned done = 0;
+        if (fits) {
+            // unit u's box has landed in every wave's share, and every wave is done reading unit u - 1's buffer
+            wait_vm_barrier_imm<0>();
+            if (u + 1 < n_units)
+                raw_box_dma<CN>(b, m, ua.u[u + 1].src, (uint32_t)ua.u[u + 1].src_pitch, lane, wave, lds0 + (uint32_t)((u + 1) & 1) * buf_bytes);
+            const uint32_t base = lds0 + (uint32_t)(u & 1) * buf_bytes;
+            uint32_t tb[kPX];
+#pragma unroll
+            for (int k = 0; k < kPX; k++)
+                tb[k] = ta[k] + base;
+            gather_cn<CN>(tb, W, lpitch, pix);
+            done = L.inside;
+        }
+        const unsigned slow = L.ok & ~done;
+        unsigned skip = 0;  // BORDER_TRANSPARENT: the destination keeps its bytes
+        if (slow) {
+            const Image im{ua.u[u].src, ua.u[u].src_pitch, g.src_h, g.src_w};
+#pragma unroll 1
+            for (int k = 0; k < kPX; k++) {
+                if (slow & (1u << k)) {
+                    const int fsx = k == 0 ? L.sx[0] : k == 1 ? L.sx[1] : k == 2 ? L.sx[2] : L.sx[3];
+                    const int fsy = k == 0 ? L.sy[0] : k == 1 ? L.sy[1] : k == 2 ? L.sy[2] : L.sy[3];
+                    uint8_t px[4] = {0, 0, 0, 0};
+                    const bool st = sample_linear_t<CN>(im, g, taps_from_fixed(fsx, fsy), px);
+                    const uint32_t r = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
+                    skip |= (st ? 0u : 1u) << k;
+#pragma unroll
+                    for (int q = 0; q < kPX; q++)
+                        pix[q] = q == k ? r : pix[q];
+                }
+            }
+        }
+        if (t.active) {
+            uint8_t* drow = ua.u[u].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[u].dst_pitch) + (uint32_t)t.x0 * (uint32_t)CN);
+            store_cn<CN>(drow, pix, L.ok & ~skip, dst_rows_dword_aligned(ua, u));
+        }
+    }
+}
+
 static int taps_of(int interp)
 {
     // (INTER_NEAREST rides the bilinear kernels: lane_coords<..., NN = 1>)
@@ -2670,6 +2851,65 @@ size_t tile_box_bytes(const Geom& g)
     const dim3 d = tile_grid(g, tile_threads(g), 1);
     return (size_t)d.x * d.y * sizeof(TileBox);
 }
+
+// k_ray_lin_cn: grayscale / BGRA, bilinear, every border mode
+bool cn_kernel_supports(const Geom& g)
+{
+    return (g.cn == 1 || g.cn == 4) && g.interp == V1C_INTER_LINEAR && g.src_w >= 3 && g.src_h >= 2;
+}
+
+// box buffer size (KB) of k_ray_lin_cn for a plan: the smallest that holds 99 % of the tile boxes (at most 16)
+int tile_cn_box_kb(const void* host_boxes, const Geom& g)
+{
+    const TileBox* hb = (const TileBox*)host_boxes;
+    const dim3 full = tile_grid(g, 256, 1);
+    const size_t n = (size_t)full.x * full.y;
+    size_t hist[17] = {0};
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        const TileBox& b = hb[i];
+        if (b.cpr <= 0 || b.cpr > kMaxCpr || b.nrows <= 0)
+            continue;
+        const int upr = g.cn == 1 ? cn_units_per_row<1>(b.cpr) : cn_units_per_row<4>(b.cpr);
+        const int kb = (b.nrows * upr + 63) / 64;
+        hist[std::min(std::max(kb, 1), 16)]++, total++;
+    }
+    size_t acc = 0;
+    for (int k = 1; k <= 16; k++) {
+        acc += hist[k];
+        if (acc * 100 >= total * 99)
+            return std::max(k, 2);
+    }
+    return 16;
+}
+
+hipError_t launch_ray_lin_cn(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int kb, hipStream_t stream)
+{
+    const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, 1);
+    const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
+    // XCD interleave: strips of two tile rows (as the BGR launches)
+    const unsigned two_rows = 2u * grid.x;
+    const unsigned slen = two_rows < ((grid.x * grid.y) >> 3) ? two_rows : 0u;
+    const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    const size_t lds = (size_t)2 * 1024 * (size_t)kb + 16;
+    const TileBox* bx = (const TileBox*)boxes;
+#define V1C_CN_LAUNCH(VW, R, CN) \
+    hipLaunchKernelGGL((k_ray_lin_cn<VW, R, CN>), grid, block, lds, stream, c, ua, bx, n_units, xmagic, slen, smagic, kb)
+    const int sel = (c.ray.var_is_w ? 4 : 0) | (use_rot ? 2 : 0) | (c.g.cn == 4 ? 1 : 0);
+    switch (sel) {
+    case 0: V1C_CN_LAUNCH(0, 0, 1); break;
+    case 1: V1C_CN_LAUNCH(0, 0, 4); break;
+    case 2: V1C_CN_LAUNCH(0, 1, 1); break;
+    case 3: V1C_CN_LAUNCH(0, 1, 4); break;
+    case 4: V1C_CN_LAUNCH(1, 0, 1); break;
+    case 5: V1C_CN_LAUNCH(1, 0, 4); break;
+    case 6: V1C_CN_LAUNCH(1, 1, 1); break;
+    default: V1C_CN_LAUNCH(1, 1, 4); break;
+    }
+#undef V1C_CN_LAUNCH
+    return hipGetLastError();
+}
+
 
 // Rest list of the mirror launch; false when the plan cannot use it (geometry, or more remaining tiles than the
 // launch's first grid slice holds).

@@ -179,6 +179,7 @@ struct v1c_plan {
     void* mirror_boxes = nullptr;
     const uint32_t* mirror_rest = nullptr;
     int n_mirror_rest = 0;
+    int cn_kb = 0;                           // > 0: grayscale / BGRA bilinear through k_ray_lin_cn with box buffers of so many KB
     int mirror_seq_kb = 0;                   // > 0: pairs through k_ray_lin3_pair_mirror_seq (two buffers of so many KB; mirror_rest is made for it)
     const uint32_t* mirror_rest1 = nullptr;  // ... of single-image launches (one eye: its two boxes have a pair's four buffers)
     int n_mirror_rest1 = -1;                 // -1: no single-image mirror launch
@@ -442,6 +443,28 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
 #endif
             // source boxes of the tiled kernel, computed once (BGR, constant border, linear/cubic/lanczos4)
             const Geom& g = p->ctx.g;
+            if (cn_kernel_supports(g) && p->plan_shared_entry && !p->disable_shared_entry) {
+                // grayscale / BGRA: the same boxes, consumed by k_ray_lin_cn
+                void* bx = nullptr;
+                e = hipMalloc(&bx, tile_box_bytes(g));
+                if (e == hipSuccess) {
+                    p->allocs.push_back(bx);
+                    e = launch_tile_boxes(p->ctx, bx, true, nullptr);
+                }
+                std::vector<char> hb(tile_box_bytes(g));
+                if (e == hipSuccess)
+                    e = hipMemcpy(hb.data(), bx, hb.size(), hipMemcpyDeviceToHost);
+                if (e != hipSuccess) {
+                    v1c_plan_destroy(p);
+                    return fail(V1C_E_HIP, std::string("tile boxes (cn): ") + hipGetErrorString(e));
+                }
+                p->tile_boxes = bx;
+                p->cn_kb = tile_cn_box_kb(hb.data(), g);
+                if (const char* kbsw = tuning_env("V1C_CN_KB"))  // A/B: box buffer size; 0 = the generic kernel
+                    p->cn_kb = std::min(std::max(std::atoi(kbsw), 0), 16);
+                if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
+                    std::fprintf(stderr, "[v1c] cn = %d tile kernel: box buffers of %d KB\n", g.cn, p->cn_kb);
+            }
             if (tile_kernel_supports(g)) {
                 void* bx = nullptr;
                 e = hipMalloc(&bx, tile_box_bytes(g));
@@ -689,6 +712,15 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h,
                                                     n == 1 ? p->mirror_rest1 : p->mirror_rest, n == 1 ? p->n_mirror_rest1 : p->n_mirror_rest,
                                                     p->mirror_raw_nwp, p->mirror_pipe_tab, st, n, p->mirror_seq_kb));
+            } else if (fast && p->ctx.g.cn != 3) {
+                // grayscale / BGRA: k_ray_lin_cn (plan-time boxes: the plan's own rotation only; one table entry per lane)
+                bool cn_ok = p->cn_kb > 0 && !any_rot && shared_entry && !p->disable_shared_entry;
+                for (int k = 0; k < n && cn_ok; k++)
+                    cn_ok = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
+                if (cn_ok)
+                    HIP_TRY(launch_ray_lin_cn(p->ctx, ua, n, p->ana.has_rot, p->tile_boxes, p->cn_kb, st));
+                else
+                    HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             } else if (fast) {
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
