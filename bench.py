@@ -72,12 +72,12 @@ WORKLOADS = {
     "C2NN": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=0,
                  desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_NEAREST (not a BASELINE config: the bilinear tile kernels "
                       "with coordinates 32 * cvRound(x))"),
-    # configurations off the BASELINE list -- reporting only: gray / BGRA run the generic kernel (k_remap: coordinates fused, taps from global
-    # memory), bilinear BORDER_TRANSPARENT the tile kernels
+    # configurations off the BASELINE list -- reporting only: gray / BGRA run k_ray_lin_cn (raw LDS-DMA boxes), bilinear
+    # BORDER_TRANSPARENT the BGR tile kernels
     "C2G": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=1,
-                desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, bilinear (generic kernel; not a BASELINE config)"),
+                desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, bilinear (k_ray_lin_cn since r03; not a BASELINE config)"),
     "C2A": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=4,
-                desc="L+R 4096x4096 BGRA -> 8192x4096 SBS, PolynomialScaler, bilinear (generic kernel; not a BASELINE config)"),
+                desc="L+R 4096x4096 BGRA -> 8192x4096 SBS, PolynomialScaler, bilinear (k_ray_lin_cn since r03; not a BASELINE config)"),
     "C2T": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, border=5,
                 desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, bilinear, BORDER_TRANSPARENT (tile kernels since r03; not a BASELINE config)"),
     "C2N": dict(size=4080, poly=[0, 1, -0.1], rot=None, interp=1,

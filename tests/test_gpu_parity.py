@@ -269,6 +269,28 @@ def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev):
                     want = O.remap(imgs[k], xm, ym, 1, border, bval, dst=fill.copy())
                     got = dsts[k].cpu().numpy()
                     assert np.array_equal(got, want), (cn, si, border, k, int((got != want).sum()))
+    # seeded random geometries: odd / tiny / non-square sizes, radii beyond the source, negative radii, 1 - 6 units
+    menus = [[("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0.02, 0.9, 0.05]), ("zoom", 1.1), CS.EQUI],
+             [("equirect_enc", True), ("rot", CS.ry(-0.2)), CS.EQUI], [("equirect_enc", True), ("fisheye_dec", "stereographic")]]
+    for case in range(32):
+        spec = menus[int(rng.integers(len(menus)))]
+        cn = int(rng.choice([1, 4]))
+        wo, ho = int(rng.integers(1, 400)), int(rng.integers(1, 300))
+        ws, hs = int(rng.integers(1, 80)) * 4, int(rng.integers(2, 300))
+        border = int(rng.choice([0, 0, 1, 2, 3, 4, 5]))
+        bval = int(rng.integers(0, 256))
+        radius = float(rng.choice([min(ws, hs) / 2, rng.uniform(5, 250), -rng.uniform(5, 100)]))
+        n = int(rng.integers(1, 7))
+        imgs = [rng.integers(0, 256, (hs, ws, cn), dtype=np.uint8) for _ in range(n)]
+        fill = rng.integers(0, 256, (ho, wo, cn), dtype=np.uint8)
+        dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in range(n)]
+        V.remap_tensors(CS.to_product(spec), [torch.from_numpy(i).to(dev) for i in imgs], dsts, radius=radius, interpolation=1,
+                        boarder_mode=border, boarder_value=bval)
+        xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+        for k in range(n):
+            want = O.remap(imgs[k], xm, ym, 1, border, bval, dst=fill.copy())
+            got = dsts[k].cpu().numpy()
+            assert np.array_equal(got, want), (case, cn, spec, (wo, ho), (ws, hs), border, radius, k, int((got != want).sum()))
     # a full-size pair of gray halves, box buffers too small for most tiles (V1C_CN_KB is a tuning-build switch; here: huge magnification)
     img = rng.integers(0, 256, (1024, 1024, 1), dtype=np.uint8)
     d = torch.empty((96, 96, 1), dtype=torch.uint8, device=dev)

@@ -66,7 +66,23 @@ def rotated(n, frames, steps):
     for i in range(steps):
         bad += int(not torch.equal(run(), ref))
     return bad
+def cn_batch(n, cn, units, steps):
+    """grayscale / BGRA units sharing the map: k_ray_lin_cn (double-buffered LDS-DMA boxes behind bare barriers)"""
+    t = EquirectangularEncoder() * PolynomialScaler([0, 1, -0.1]) * FisheyeDecoder("equidistant")
+    g = torch.Generator(device=dev).manual_seed(5)
+    srcs = [torch.randint(0, 256, (n, n, cn), dtype=torch.uint8, device=dev, generator=g) for _ in range(units)]
+    def run():
+        dsts = [torch.empty((n, n, cn), dtype=torch.uint8, device=dev) for _ in range(units)]
+        V.remap_tensors(t, srcs, dsts, radius=n / 2, interpolation=1)
+        return torch.stack(dsts)
+    ref = run().clone(); bad = 0
+    for i in range(steps):
+        bad += int(not torch.equal(run(), ref))
+    return bad
 t0 = time.time()
+print("gray 2048 x 5 units:", cn_batch(2048, 1, 5, 1000), "bad of 1000", flush=True)
+print("BGRA 2048 x 2 units:", cn_batch(2048, 4, 2, 1000), "bad of 1000", flush=True)
+print("BGRA 1024 x 7 units:", cn_batch(1024, 4, 7, 1000), "bad of 1000", flush=True)
 print("single images 2048:", single(2048, 2000), "bad of 2000", flush=True)
 print("C5-like rotated units 1920 x 8 frames:", rotated(1920, 8, 400), "bad of 400", flush=True)
 print("rotated units 1024 x 5 frames (odd unit count per launch group):", rotated(1024, 5, 800), "bad of 800", flush=True)
