@@ -347,6 +347,9 @@ def main() -> None:
                          "profiles/traffic_latest.json, or omitted")
     ap.add_argument("--no-cold-extra", action="store_true", help="skip the 8192x8192 Lanczos4 cold-call measurement")
     ap.add_argument("--no-rotate", action="store_true", help="A/B only: replay ONE buffer set (L3-warm for small workloads)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="A/B only: deal the steps round-robin to this many HIP streams (independent frames overlap: one launch's tail "
+                         "fills with the next one's head); the default, one stream, is what every reported number uses")
     ap.add_argument("--no-condition", action="store_true",
                     help="skip the 0.5 s clock / launch-queue conditioning (the --pmc child passes: counters do not depend on clocks)")
     args = ap.parse_args()
@@ -530,8 +533,20 @@ def main() -> None:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     t0 = time.perf_counter()  # (behind the opening event's own host cost: the K steps start here)
-    for i in range(args.steps):
-        step(args.warmup + i)
+    if args.streams > 1:
+        # (consecutive steps use different buffer sets, so they are independent; the side streams start behind e0 and the
+        # launch stream joins them in front of e1: the bracket still covers exactly the K steps)
+        side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+        for st in side:
+            st.wait_event(e0)
+        for i in range(args.steps):
+            with torch.cuda.stream(side[i % args.streams]):
+                step(args.warmup + i)
+        for st in side:
+            torch.cuda.current_stream(dev).wait_stream(st)
+    else:
+        for i in range(args.steps):
+            step(args.warmup + i)
     e1.record()
     # (the host polls the closing event before it synchronises: a blocking hipDeviceSynchronize wakes tens of microseconds
     # after the GPU is done, which is several per cent of a 20-step region of 50 us kernels)

@@ -24,6 +24,35 @@ def test_parallel_png_decodes_with_pillow(tmp_path, shape, threads):
     assert got.shape == want.shape and np.array_equal(got, want)
     back = _io.imread(p)  # cv2.imread's default: always 3 channels, BGR
     assert np.array_equal(back, np.repeat(img[..., None], 3, axis=2) if img.ndim == 2 else img[..., :3])
+    # the writer's own reader (band directory chunk, bands inflated in parallel): the array as written, for either filter
+    assert np.array_equal(_png.read(p, threads=threads), img)
+    assert np.array_equal(_png.decode(_png.encode(img, threads=threads, band_rows=7, up_filter=False), threads=threads), img)
+
+
+def test_parallel_png_reader_leaves_foreign_and_damaged_files_to_the_general_decoder(tmp_path):
+    from PIL import Image
+
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (90, 70, 3), dtype=np.uint8)
+    # a PNG of another writer: no band directory
+    Image.fromarray(img[..., ::-1].copy()).save(tmp_path / "pil.png")
+    assert _png.read(tmp_path / "pil.png") is None and np.array_equal(_io.imread(tmp_path / "pil.png"), img)
+    good = _png.encode(img, band_rows=16)
+    assert np.array_equal(_png.decode(good), img)
+    at = good.index(b"vrBD")
+    # a directory that does not match the stream (an offset moved), a damaged band, a damaged checksum, a truncated file
+    moved = bytearray(good)
+    moved[at + 4 + 6 + 12 + 11] ^= 1
+    assert _png.decode(bytes(moved)) is None  # (the chunk's CRC no longer matches)
+    idat = good.index(b"IDAT")
+    hurt = bytearray(good)
+    hurt[idat + 40] ^= 0x55
+    assert _png.decode(bytes(hurt)) is None
+    tail = bytearray(good)
+    tail[-17] ^= 1  # last byte of the Adler-32
+    assert _png.decode(bytes(tail)) is None
+    assert _png.decode(good[: len(good) // 2]) is None and _png.decode(b"") is None
+    assert _png.read(tmp_path / "missing.png") is None
 
 
 def test_imwrite_uses_the_parallel_encoder_for_large_pngs_and_round_trips(tmp_path):

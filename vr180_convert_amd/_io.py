@@ -5,7 +5,8 @@ BGR like cv2's.  Codec work is outside the measured path.
 Two additions for batch work, where codecs -- not the remap -- set the end-to-end time:
 * ``.npy`` files are read (memory-mapped) and written as raw uint8 arrays in cv2 channel order: the codec-free
   format for frame sequences (the GPU image ships no device-side JPEG / PNG codec: no rocJPEG, no torchvision);
-* large PNGs are written by the multi-threaded encoder of ``_png.py`` when cv2 is absent."""
+* large PNGs are written by the multi-threaded encoder of ``_png.py`` when cv2 is absent, and PNGs it wrote are read back by its
+  multi-threaded decoder (a private chunk holds the band directory; every other reader sees an ordinary PNG)."""
 from __future__ import annotations
 
 from pathlib import Path
@@ -32,6 +33,13 @@ def imread(path: Any):
         return a if a.dtype == np.uint8 and a.ndim in (2, 3) else None
     if _cv is not None:
         return _cv.imread(p)
+    if p.lower().endswith(".png"):
+        # PNGs of this package's writer carry a band directory: inflated on all cores (any other PNG: None, Pillow below)
+        from . import _png
+
+        a = _png.read(p)
+        if a is not None:  # cv2.imread's default flag (IMREAD_COLOR): always 3 channels
+            return a if a.ndim == 3 and a.shape[2] == 3 else np.repeat(a[..., None], 3, axis=2) if a.ndim == 2 else np.ascontiguousarray(a[..., :3])
     from PIL import Image
 
     try:

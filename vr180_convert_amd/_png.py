@@ -69,8 +69,117 @@ def encode(image: np.ndarray, *, level: int = 1, threads: int | None = None, ban
         adler = zlib.adler32(lines[r0:r1], adler)
     stream = b"\x78\x01" + b"".join(parts) + struct.pack(">I", adler & 0xFFFFFFFF)
     ihdr = struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0)
-    return _SIGNATURE + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", stream) + _chunk(b"IEND", b"")
+    # band directory for decode(): an ancillary, private, unsafe-to-copy chunk other readers skip.  Every band was deflated from an
+    # empty window, so each segment inflates on its own.
+    index = struct.pack(">BBI", 1, 2 if up_filter else 0, len(bands))
+    off = 2
+    for (r0, r1), part in zip(bands, parts):
+        index += struct.pack(">III", r0, r1, off)
+        off += len(part)
+    return _SIGNATURE + _chunk(b"IHDR", ihdr) + _chunk(_INDEX_CHUNK, index) + _chunk(b"IDAT", stream) + _chunk(b"IEND", b"")
+
+
+_INDEX_CHUNK = b"vrBD"
+
+
+def decode(data: bytes, *, threads: int | None = None):
+    """The image of a PNG written by ``encode`` (cv2 channel order), its bands inflated in parallel -- or ``None`` for every other
+    PNG (no band directory, several IDAT chunks, other bit depths / filters, anything inconsistent): the caller then uses a general
+    decoder.  The Adler-32 of the zlib stream is verified."""
+    if len(data) < 8 + 25 or data[:8] != _SIGNATURE:
+        return None
+    pos, ihdr, index, idat = 8, None, None, None
+    while pos + 12 <= len(data):
+        (n,), kind = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        if len(body) != n:
+            return None
+        if kind == b"IHDR":
+            ihdr = body
+        elif kind == _INDEX_CHUNK:
+            if zlib.crc32(kind + body) & 0xFFFFFFFF != struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]:
+                return None
+            index = body
+        elif kind == b"IDAT":
+            if idat is not None:
+                return None
+            idat = memoryview(data)[pos + 8:pos + 8 + n]
+        elif kind == b"IEND":
+            break
+        pos += 12 + n
+    if ihdr is None or index is None or idat is None or len(ihdr) != 13 or len(index) < 6:
+        return None
+    w, h, depth, color_type, comp, flt, lace = struct.unpack(">IIBBBBB", ihdr)
+    cn = {0: 1, 2: 3, 6: 4}.get(color_type)
+    version, ftype, nb = struct.unpack(">BBI", index[:6])
+    if depth != 8 or cn is None or comp or flt or lace or version != 1 or ftype not in (0, 2) or len(index) != 6 + 12 * nb or nb == 0:
+        return None
+    bands = [struct.unpack(">III", index[6 + 12 * k:18 + 12 * k]) for k in range(nb)]
+    stride = 1 + w * cn
+    end = len(idat) - 4
+    ok = bands[0][0] == 0 and bands[-1][1] == h and all(a[1] == b[0] for a, b in zip(bands, bands[1:])) and \
+        all(r0 < r1 and 2 <= off <= end for r0, r1, off in bands) and all(a[2] <= b[2] for a, b in zip(bands, bands[1:]))
+    if not ok or len(idat) < 6:
+        return None
+    lines = np.empty((h, stride), np.uint8)
+
+    def inflate(k: int) -> bool:
+        r0, r1, off = bands[k]
+        stop = bands[k + 1][2] if k + 1 < nb else end
+        try:
+            raw = zlib.decompressobj(-15).decompress(idat[off:stop])
+        except zlib.error:
+            return False
+        if len(raw) != (r1 - r0) * stride:
+            return False
+        lines[r0:r1] = np.frombuffer(raw, np.uint8).reshape(r1 - r0, stride)
+        return True
+
+    nthreads = threads or min(32, os.cpu_count() or 1)
+    if nb > 1 and nthreads > 1:
+        with ThreadPoolExecutor(max_workers=nthreads) as pool:
+            good = all(pool.map(inflate, range(nb)))
+    else:
+        good = all(inflate(k) for k in range(nb))
+    if not good or not (lines[:, 0] == ftype).all():
+        return None
+    adler = 1
+    for r0, r1, _ in bands:
+        adler = zlib.adler32(lines[r0:r1], adler)
+    if adler & 0xFFFFFFFF != struct.unpack(">I", idat[end:])[0]:
+        return None
+    flat = lines[:, 1:]
+    if ftype == 2 and h > 1:
+        # "Up": every byte was stored minus the one above it -- a running sum down the columns (modulo 256), in column blocks
+        step = max(4096, -(-flat.shape[1] // max(nthreads, 1)))
+        cols = [(c, min(c + step, flat.shape[1])) for c in range(0, flat.shape[1], step)]
+
+        def unfilter(c: tuple) -> None:
+            np.add.accumulate(flat[:, c[0]:c[1]], axis=0, dtype=np.uint8, out=flat[:, c[0]:c[1]])
+
+        if len(cols) > 1 and nthreads > 1:
+            with ThreadPoolExecutor(max_workers=nthreads) as pool:
+                list(pool.map(unfilter, cols))
+        else:
+            for c in cols:
+                unfilter(c)
+    body = flat.reshape(h, w, cn)
+    if cn == 1:
+        return np.ascontiguousarray(body[..., 0])
+    out = np.empty((h, w, cn), np.uint8)
+    out[..., 0], out[..., 1], out[..., 2] = body[..., 2], body[..., 1], body[..., 0]
+    if cn == 4:
+        out[..., 3] = body[..., 3]
+    return out
 
 
 def write(path: Any, image: np.ndarray, **kw: Any) -> None:
     Path(path).write_bytes(encode(image, **kw))
+
+
+def read(path: Any, **kw: Any):
+    """``decode`` of a file; ``None`` when it is not one of this writer's PNGs (or cannot be read)."""
+    try:
+        return decode(Path(path).read_bytes(), **kw)
+    except OSError:
+        return None
