@@ -31,8 +31,8 @@ for f in sorted(out.glob('*_bench_line.json')):
         continue
     r = d['roofline']
     if r.get('traffic'):
-        t[f.name[:2]] = {'hbm_bytes_per_step': r['traffic'], 'tag': out.name, **{k: v for k, v in r.get('traffic_detail', {}).items() if k != 'hbm_bytes_per_step'}}
-    print(f.name[:2], 'kernel_ms', r['kernel_ms'], 'frac', r['frac'], 'traffic', r.get('traffic'), 'alg', r['algorithmic_bytes_per_launch'])
+        t[f.name.split('_')[0]] = {'hbm_bytes_per_step': r['traffic'], 'tag': out.name, **{k: v for k, v in r.get('traffic_detail', {}).items() if k != 'hbm_bytes_per_step'}}
+    print(f.name.split('_')[0], 'kernel_ms', r['kernel_ms'], 'frac', r['frac'], 'traffic', r.get('traffic'), 'alg', r['algorithmic_bytes_per_launch'])
 (out / 'traffic.json').write_text(json.dumps(t, indent=1))
 PY
 head -4 $OUT/*_kernel_stats.csv | cut -c1-200

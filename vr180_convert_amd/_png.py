@@ -26,6 +26,36 @@ def _chunk(kind: bytes, data: bytes) -> bytes:
     return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
 
 
+def _adler32_combine(a1: int, a2: int, len2: int) -> int:
+    """Adler-32 of a concatenation from the checksums of its two parts (zlib's adler32_combine)."""
+    base = 65521
+    rem = len2 % base
+    s1 = a1 & 0xFFFF
+    s2 = (rem * s1) % base
+    s1 += (a2 & 0xFFFF) + base - 1
+    s2 += ((a1 >> 16) & 0xFFFF) + ((a2 >> 16) & 0xFFFF) + base - rem
+    if s1 >= base:
+        s1 -= base
+    if s1 >= base:
+        s1 -= base
+    if s2 >= base << 1:
+        s2 -= base << 1
+    if s2 >= base:
+        s2 -= base
+    return s1 | (s2 << 16)
+
+
+def _to_png_order(dst: np.ndarray, a: np.ndarray) -> None:
+    """cv2 channel order (gray, BGR, BGRA) -> PNG's (gray, RGB, RGBA), and back: the swap is its own inverse"""
+    cn = a.shape[2]
+    if cn == 1:
+        dst[...] = a
+    else:
+        dst[..., 0], dst[..., 1], dst[..., 2] = a[..., 2], a[..., 1], a[..., 0]
+        if cn == 4:
+            dst[..., 3] = a[..., 3]
+
+
 def encode(image: np.ndarray, *, level: int = 1, threads: int | None = None, band_rows: int | None = None, up_filter: bool = True) -> bytes:
     """PNG bytes of a uint8 image in cv2 channel order: (H, W) gray, (H, W, 3) BGR or (H, W, 4) BGRA.
     ``up_filter``: scanline filter 2 ("Up": each byte minus the one above it, one vectorised subtraction) instead
@@ -37,36 +67,41 @@ def encode(image: np.ndarray, *, level: int = 1, threads: int | None = None, ban
     if cn not in (1, 3, 4) or h == 0 or w == 0:
         raise ValueError("1, 3 or 4 channels and a non-empty image")
     color_type = {1: 0, 3: 2, 4: 6}[cn]
-    # scanlines: filter byte + pixels in RGB(A) order
-    lines = np.empty((h, 1 + w * cn), np.uint8)
-    lines[:, 0] = 2 if up_filter else 0
-    body = lines[:, 1:].reshape(h, w, cn)
-    if cn == 1:
-        body[...] = a
-    else:
-        body[..., 0], body[..., 1], body[..., 2] = a[..., 2], a[..., 1], a[..., 0]
-        if cn == 4:
-            body[..., 3] = a[..., 3]
-    if up_filter and h > 1:
-        flat = lines[:, 1:]
-        flat[1:] -= flat[:-1].copy()  # uint8 wrap-around = the filter's modulo-256 difference (row 0: the row above is zero)
     nthreads = threads or min(32, os.cpu_count() or 1)
     rows = band_rows or max(16, -(-h // (4 * nthreads)))
     bands = [(r, min(r + rows, h)) for r in range(0, h, rows)]
+    stride = 1 + w * cn
 
-    def deflate(k: int) -> bytes:
+    def band(k: int):
+        # everything a band needs on its own thread (numpy and zlib release the GIL): scanlines = filter byte + pixels in RGB(A)
+        # order, the "Up" differences (uint8 wrap-around = the filter's modulo-256 difference; the row above row 0 is zero),
+        # the deflate segment from an empty window and the band's Adler-32
         r0, r1 = bands[k]
+        lines = np.empty((r1 - r0, stride), np.uint8)
+        lines[:, 0] = 2 if up_filter else 0
+        body = lines[:, 1:].reshape(r1 - r0, w, cn)
+        _to_png_order(body, a[r0:r1])
+        if up_filter:
+            flat = lines[:, 1:]
+            if r1 - r0 > 1:
+                flat[1:] -= flat[:-1].copy()
+            if r0 > 0:
+                above = np.empty((1, w, cn), np.uint8)
+                _to_png_order(above, a[r0 - 1:r0])
+                flat[0] -= above.reshape(-1)
         c = zlib.compressobj(level, zlib.DEFLATED, -15)
-        return c.compress(lines[r0:r1]) + c.flush(zlib.Z_FINISH if k == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
+        part = c.compress(lines) + c.flush(zlib.Z_FINISH if k == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
+        return part, zlib.adler32(lines), lines.size
 
     if len(bands) > 1 and nthreads > 1:
         with ThreadPoolExecutor(max_workers=nthreads) as pool:
-            parts = list(pool.map(deflate, range(len(bands))))
+            done = list(pool.map(band, range(len(bands))))
     else:
-        parts = [deflate(k) for k in range(len(bands))]
+        done = [band(k) for k in range(len(bands))]
+    parts = [d[0] for d in done]
     adler = 1
-    for r0, r1 in bands:
-        adler = zlib.adler32(lines[r0:r1], adler)
+    for _, ad, n in done:
+        adler = _adler32_combine(adler, ad, n)
     stream = b"\x78\x01" + b"".join(parts) + struct.pack(">I", adler & 0xFFFFFFFF)
     ihdr = struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0)
     # band directory for decode(): an ancillary, private, unsafe-to-copy chunk other readers skip.  Every band was deflated from an
@@ -122,6 +157,7 @@ def decode(data: bytes, *, threads: int | None = None):
     if not ok or len(idat) < 6:
         return None
     lines = np.empty((h, stride), np.uint8)
+    sums = [0] * nb
 
     def inflate(k: int) -> bool:
         r0, r1, off = bands[k]
@@ -132,45 +168,47 @@ def decode(data: bytes, *, threads: int | None = None):
             return False
         if len(raw) != (r1 - r0) * stride:
             return False
+        sums[k] = zlib.adler32(raw)
         lines[r0:r1] = np.frombuffer(raw, np.uint8).reshape(r1 - r0, stride)
-        return True
+        return bool((lines[r0:r1, 0] == ftype).all())
 
     nthreads = threads or min(32, os.cpu_count() or 1)
-    if nb > 1 and nthreads > 1:
-        with ThreadPoolExecutor(max_workers=nthreads) as pool:
-            good = all(pool.map(inflate, range(nb)))
-    else:
-        good = all(inflate(k) for k in range(nb))
-    if not good or not (lines[:, 0] == ftype).all():
-        return None
-    adler = 1
-    for r0, r1, _ in bands:
-        adler = zlib.adler32(lines[r0:r1], adler)
-    if adler & 0xFFFFFFFF != struct.unpack(">I", idat[end:])[0]:
-        return None
-    flat = lines[:, 1:]
-    if ftype == 2 and h > 1:
-        # "Up": every byte was stored minus the one above it -- a running sum down the columns (modulo 256), in column blocks
-        step = max(4096, -(-flat.shape[1] // max(nthreads, 1)))
-        cols = [(c, min(c + step, flat.shape[1])) for c in range(0, flat.shape[1], step)]
+    pool = ThreadPoolExecutor(max_workers=nthreads) if nthreads > 1 else None
 
-        def unfilter(c: tuple) -> None:
-            np.add.accumulate(flat[:, c[0]:c[1]], axis=0, dtype=np.uint8, out=flat[:, c[0]:c[1]])
+    def run(fn, items):
+        return list(pool.map(fn, items)) if pool is not None and len(items) > 1 else [fn(i) for i in items]
 
-        if len(cols) > 1 and nthreads > 1:
-            with ThreadPoolExecutor(max_workers=nthreads) as pool:
-                list(pool.map(unfilter, cols))
-        else:
-            for c in cols:
-                unfilter(c)
-    body = flat.reshape(h, w, cn)
-    if cn == 1:
-        return np.ascontiguousarray(body[..., 0])
-    out = np.empty((h, w, cn), np.uint8)
-    out[..., 0], out[..., 1], out[..., 2] = body[..., 2], body[..., 1], body[..., 0]
-    if cn == 4:
-        out[..., 3] = body[..., 3]
-    return out
+    try:
+        if not all(run(inflate, list(range(nb)))):
+            return None
+        adler = 1
+        for k, (r0, r1, _) in enumerate(bands):
+            adler = _adler32_combine(adler, sums[k], (r1 - r0) * stride)
+        if adler & 0xFFFFFFFF != struct.unpack(">I", idat[end:])[0]:
+            return None
+        flat = lines[:, 1:]
+        if ftype == 2 and h > 1:
+            # "Up": every byte was stored minus the one above it -- a running sum down the columns (modulo 256), in column blocks
+            step = max(4096, -(-flat.shape[1] // (2 * nthreads)))
+
+            def unfilter(c0: int) -> None:
+                np.add.accumulate(flat[:, c0:c0 + step], axis=0, dtype=np.uint8, out=flat[:, c0:c0 + step])
+
+            run(unfilter, list(range(0, flat.shape[1], step)))
+        body = flat.reshape(h, w, cn)
+        if cn == 1:
+            return np.ascontiguousarray(body[..., 0])
+        out = np.empty((h, w, cn), np.uint8)
+        rstep = max(16, -(-h // (4 * nthreads)))
+
+        def swap(r0: int) -> None:
+            _to_png_order(out[r0:r0 + rstep], body[r0:r0 + rstep])
+
+        run(swap, list(range(0, h, rstep)))
+        return out
+    finally:
+        if pool is not None:
+            pool.shutdown()
 
 
 def write(path: Any, image: np.ndarray, **kw: Any) -> None:
