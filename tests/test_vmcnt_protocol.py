@@ -163,3 +163,18 @@ def test_mirror_raw_has_its_requests_and_waits(kernels_dis):
         assert "L" in head and head[-1] == "w", (name, head[-6:])
         # the stores of the fast path: one 12-byte store per eye and row in either alignment path
         assert sum(x.op == "global_store_dwordx3" for x in ins) >= 4 * eyes
+
+
+def test_cn_kernel_waits_for_every_request_before_the_barrier(kernels_dis):
+    """k_ray_lin_cn publishes a box with ``s_waitcnt vmcnt(0)`` + ``s_barrier`` (no counting): every instantiation has its LDS-DMA
+    requests (the first unit's in front of the coordinates, the next unit's inside the loop) and at least one such wait, and no
+    LDS-DMA request is followed by a plain ``s_barrier`` without the wait in front of it."""
+    for name, ins in pick(kernels_dis, "k_ray_lin_cn").items():
+        analyse(ins)
+        assert sum(x.kind == "D" for x in ins) >= 2, name
+        full_waits = [i for i, x in enumerate(ins) if x.kind == "W" and "vmcnt(0)" in x.args]
+        assert full_waits, name
+        for i, x in enumerate(ins):
+            if x.op == "s_barrier" and ins[i - 1].kind != "W":
+                # a bare barrier (the table slice's __syncthreads) must sit in front of the first request
+                assert not any(y.kind == "D" for y in ins[:i]), (name, hex(x.addr))
