@@ -79,16 +79,19 @@ def cn_batch(n, cn, units, steps):
     for i in range(steps):
         bad += int(not torch.equal(run(), ref))
     return bad
+import os
+REPS = int(os.environ.get("SOAK_REPS", "1"))  # SOAK_REPS=<n>: the whole list n times
 t0 = time.time()
-print("gray 2048 x 5 units:", cn_batch(2048, 1, 5, 1000), "bad of 1000", flush=True)
-print("BGRA 2048 x 2 units:", cn_batch(2048, 4, 2, 1000), "bad of 1000", flush=True)
-print("BGRA 1024 x 7 units:", cn_batch(1024, 4, 7, 1000), "bad of 1000", flush=True)
-print("single images 2048:", single(2048, 2000), "bad of 2000", flush=True)
-print("C5-like rotated units 1920 x 8 frames:", rotated(1920, 8, 400), "bad of 400", flush=True)
-print("rotated units 1024 x 5 frames (odd unit count per launch group):", rotated(1024, 5, 800), "bad of 800", flush=True)
-print("C2-like pairs 4096:", pair(4096, [0, 1, -0.1], 1500), "bad of 1500", flush=True)
-print("C1-like pairs 2048:", pair(2048, None, 3000), "bad of 3000", flush=True)
-print("pairs 1024 poly:", pair(1024, [0, 1, -0.1], 4000), "bad of 4000", flush=True)
-print("C3-like batches 2880 x 8 frames:", batch(2880, 8, 300), "bad of 300", flush=True)
-print("batches 1440 x 5 frames:", batch(1440, 5, 1000), "bad of 1000", flush=True)
+for rep in range(REPS):
+    print("gray 2048 x 5 units:", cn_batch(2048, 1, 5, 1000), "bad of 1000", flush=True)
+    print("BGRA 2048 x 2 units:", cn_batch(2048, 4, 2, 1000), "bad of 1000", flush=True)
+    print("BGRA 1024 x 7 units:", cn_batch(1024, 4, 7, 1000), "bad of 1000", flush=True)
+    print("single images 2048:", single(2048, 2000), "bad of 2000", flush=True)
+    print("C5-like rotated units 1920 x 8 frames:", rotated(1920, 8, 400), "bad of 400", flush=True)
+    print("rotated units 1024 x 5 frames (odd unit count per launch group):", rotated(1024, 5, 800), "bad of 800", flush=True)
+    print("C2-like pairs 4096:", pair(4096, [0, 1, -0.1], 1500), "bad of 1500", flush=True)
+    print("C1-like pairs 2048:", pair(2048, None, 3000), "bad of 3000", flush=True)
+    print("pairs 1024 poly:", pair(1024, [0, 1, -0.1], 4000), "bad of 4000", flush=True)
+    print("C3-like batches 2880 x 8 frames:", batch(2880, 8, 300), "bad of 300", flush=True)
+    print("batches 1440 x 5 frames:", batch(1440, 5, 1000), "bad of 1000", flush=True)
 print(f"{time.time() - t0:.0f} s")
