@@ -1767,20 +1767,32 @@ template <int BPP = 3>
 __device__ __forceinline__ int raw_box_dma(const TileBox& b, const RawLanes& m, const uint8_t* __restrict__ src, uint32_t spitch, int lane,
                                             int wave, uint32_t lds_box)
 {
+    // request address = scalar base (source + first row of the pass + box column, all wave-uniform: scalar ALU) + the lane's 32-bit
+    // offset (row in the pass x pitch + column unit; the same for every pass and every box of this geometry): the request's
+    // SGPR-base form, no vector arithmetic per pass
+    const uint32_t sp = (uint32_t)__builtin_amdgcn_readfirstlane((int)spitch);
     uint32_t voff;  // (v_mul_u32_u24 by hand: with a scalar factor the compiler picks the quarter-rate v_mul_lo_u32)
-    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(voff) : "v"(m.row_l), "v"(spitch));
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(voff) : "v"(m.row_l), "s"(sp));
     voff += m.col16;
     const int rows = min(m.R, b.nrows);
     const int last0 = b.nrows - rows;  // first row of the last pass
     const bool active = lane < rows * m.upr;
-    const uint8_t* org = src + (__umul24((uint32_t)b.y0, spitch) + (uint32_t)b.x0 * (uint32_t)BPP);
+    const uint64_t org = (uint64_t)(uintptr_t)src + (uint64_t)((uint32_t)b.y0 * sp + (uint32_t)b.x0 * (uint32_t)BPP);
     const uint32_t lpitch = (uint32_t)m.upr * 16u;
     int n = 0;
     for (int r0 = wave * m.R; r0 < b.nrows; r0 += 4 * m.R) {  // wave-uniform
         const int rs = min(r0, last0);
-        const uint8_t* gp = org + (uint32_t)rs * spitch + voff;
+        const uint64_t base = org + (uint64_t)((uint32_t)rs * sp);
+        const uint32_t m0v = lds_box + (uint32_t)rs * lpitch;
+        // (by hand: as a pointer expression the compiler sums the two offsets first and addresses through a 64-bit VGPR pair --
+        // a quarter-rate v_mul_lo_u32 and two 64-bit adds per pass.  M0 = LDS destination of lane 0; it is put back, the compiler
+        // keeps its own value there across statements it does not know to write it)
+        uint32_t m0_saved;
         if (active)
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_box + (uint32_t)rs * lpitch), 16, 0, 0);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved)
+                         : "v"(voff), "s"(base), "s"(m0v)
+                         : "memory");
         n++;
     }
     return n;
