@@ -1786,10 +1786,12 @@ __device__ __forceinline__ int raw_box_dma(const TileBox& b, const RawLanes& m, 
         const uint32_t m0v = lds_box + (uint32_t)rs * lpitch;
         // (by hand: as a pointer expression the compiler sums the two offsets first and addresses through a 64-bit VGPR pair --
         // a quarter-rate v_mul_lo_u32 and two 64-bit adds per pass.  M0 = LDS destination of lane 0; it is put back, the compiler
-        // keeps its own value there across statements it does not know to write it)
+        // keeps its own value there across statements it does not know to write it.  s_nop 2: with the two moves five wait states
+        // in front of the request -- what a VMEM instruction needs behind a VALU write (v_readfirstlane) of an SGPR it reads, a
+        // hazard the compiler does not see inside an asm statement; it also covers the wait state M0 needs)
         uint32_t m0_saved;
         if (active)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(m0_saved)
                          : "v"(voff), "s"(base), "s"(m0v)
                          : "memory");
