@@ -116,13 +116,13 @@ def pick(dis, name):
 
 
 def test_no_vector_load_between_a_request_and_its_wait(kernels_dis):
-    """mirror_raw (pairs and single images) and mirror_pipe: from every LDS-DMA request, in address
+    """mirror_seq (pairs: the default), mirror_raw (single images; pairs as an A/B form) and mirror_pipe: from every LDS-DMA request, in address
     order up to the next hand-written wait, there is no compiler-visible vector load and no vmcnt wait the compiler made
     (the compiler lays the request loops, the wait tables and the store blocks of a phase out together; its structurised
     control flow -- flag registers -- makes a path-exact check meaningless, so this is the layout-local form of "nothing loads
     through registers while boxes are in flight").  Every kernel has its wait tables, each verified block by block."""
     checked = 0
-    for fam in ("k_ray_lin3_pair_mirror_raw", "k_ray_lin3_pair_mirror_pipe", "k_ray_lin3_batch_lean_raw"):
+    for fam in ("k_ray_lin3_pair_mirror_seq", "k_ray_lin3_pair_mirror_raw", "k_ray_lin3_pair_mirror_pipe", "k_ray_lin3_batch_lean_raw"):
         for name, ins in pick(kernels_dis, fam).items():
             succ, tables = analyse(ins)  # (verifies the jump tables)
             assert tables >= 2, (name, tables)
@@ -140,7 +140,7 @@ def test_no_vector_load_between_a_request_and_its_wait(kernels_dis):
                     j += 1
                 assert j < len(ins) and ins[j].kind == "W", (name, hex(x.addr), "no hand-written wait behind the request")
             checked += 1
-    assert checked >= 6
+    assert checked >= 8
 
 
 def test_rot_pair_has_its_tables(kernels_dis):

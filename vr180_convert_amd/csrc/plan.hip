@@ -538,11 +538,12 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         // C2 / C1: 0.0497 / 0.0205 ms against 0.0472 / 0.0185 ms for k_ray_lin3_pair_mirror_raw
                         const char* pipesw = tuning_env("V1C_MIRROR_PIPE");
                         const bool pipe = p->mirror_raw_nwp > 0 && pipesw && pipesw[0] == '1';
-                        // V1C_MIRROR_SEQ=1 (A/B): the eyes of a pair one after the other in two buffers (k_ray_lin3_pair_mirror_seq);
-                        // V1C_MIRROR_SEQ_KB=<n>: their size
+                        // pairs: the eyes one after the other through two buffers of twice the size (k_ray_lin3_pair_mirror_seq: 99.8 % of
+                        // the tile pairs fit, C2 -0.4 ... -2.6 %, C1 -1.6 ... -3 % against the four-buffer kernel on three boxes,
+                        // DESIGN.md 4.4c); V1C_MIRROR_SEQ=0 (A/B): k_ray_lin3_pair_mirror_raw for pairs too; V1C_MIRROR_SEQ_KB=<n>: buffer size
                         const char* seqsw = tuning_env("V1C_MIRROR_SEQ");
                         const char* seqkb = tuning_env("V1C_MIRROR_SEQ_KB");
-                        if (p->mirror_raw_nwp > 0 && !pipe && seqsw && seqsw[0] == '1')
+                        if (p->mirror_raw_nwp > 0 && !pipe && !(seqsw && seqsw[0] == '0'))
                             p->mirror_seq_kb = seqkb ? std::min(std::max(std::atoi(seqkb), 2), 16) : tile_mirror_raw_passes(hb.data(), hm.data(), g, 998, 11);
                         if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest,
                                              p->mirror_seq_kb > 0 ? p->mirror_seq_kb : p->mirror_raw_nwp, !pipe, 2)) {
