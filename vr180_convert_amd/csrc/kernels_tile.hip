@@ -768,9 +768,21 @@ __device__ __noinline__ uint32_t slow_pixel_table3_t(const uint8_t* src, int64_t
 
 // `aligned`: the lane's 12 bytes start on a dword boundary.  x0 * 3 is a multiple of 12, so this is
 // a property of the unit (dst and its pitch), wave-uniform -- see dst_rows_dword_aligned().
+// SYS = 1 (the mirror pair kernels): the streaming stores at SYSTEM scope (`sc0 sc1 nt`: written through to memory, nothing
+// kept in L2).  With plain `nt` a 128-byte line that two workgroups write half each leaves L2 twice in part (1.10 x the bytes of
+// the image: DESIGN.md 4.4c); at system scope a C2 launch writes 99 312 KB for its 98 304 KB of output and runs 2 - 4 % faster
+// (profiles/r03d_final/ab_store_policy.log).  The batch, rotation and Lanczos4 launches measured equal or slower with it (C4 +3.8 %)
+// and keep `nt`.  No builtin selects that policy without the waits of a volatile access, so the store is written by hand; the
+// `s_nop 1` inside the statement is the two wait states gfx940+ needs between a store of more than 8 bytes and a VALU write of its
+// data registers -- a hazard the compiler cannot see through an asm statement.
+template <int SYS = 0>
 __device__ __forceinline__ void store4(uint8_t* drow, const uint32_t (&pix)[kPX], unsigned ok, bool aligned)
 {
-    if (ok == 0xFu && aligned) {
+    if (SYS && ok == 0xFu && aligned) {
+        typedef uint32_t __attribute__((ext_vector_type(3))) u32x3;
+        const u32x3 v = {pix[0] | (pix[1] << 24), (pix[1] >> 8) | (pix[2] << 16), (pix[2] >> 16) | (pix[3] << 8)};
+        asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(drow), "v"(v) : "memory");
+    } else if (ok == 0xFu && aligned) {
         uint32_t* d32 = (uint32_t*)drow;
         // non-temporal: the destination is written once and never read by this launch; with the stores marked
         // streaming the L2 / Infinity Cache keep the source halo rows instead (L3-cold bench, r02: C2 -4 %, C1 -5 %,
@@ -1868,8 +1880,8 @@ __device__ __forceinline__ void gather_pair_raw(const TileBox& b, uint32_t raw, 
 __device__ __forceinline__ void store_pair_row(const UnitArgs& ua, const TileIds& t, int j, const uint32_t (&pix0)[kPX], const uint32_t (&pix1)[kPX])
 {
     const uint32_t row_off = (uint32_t)t.x0 * 3u;
-    store4(ua.u[0].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[0].dst_pitch) + row_off), pix0, 0xFu, dst_rows_dword_aligned(ua, 0));
-    store4(ua.u[1].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix1, 0xFu, dst_rows_dword_aligned(ua, 1));
+    store4<1>(ua.u[0].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[0].dst_pitch) + row_off), pix0, 0xFu, dst_rows_dword_aligned(ua, 0));
+    store4<1>(ua.u[1].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix1, 0xFu, dst_rows_dword_aligned(ua, 1));
 }
 
 // NE = number of eyes (units) of the launch: 2 = apply_lr's pair; 1 = a single image (apply() of one image, BASELINE config 1):
@@ -1997,10 +2009,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
             uint8_t* de = e ? ua.u[1].dst : ua.u[0].dst;
             const uint32_t dp = (uint32_t)(e ? ua.u[1].dst_pitch : ua.u[0].dst_pitch);
             const bool al = e ? dst_rows_dword_aligned(ua, 1) : dst_rows_dword_aligned(ua, 0);
-            store4(de + (__umul24((uint32_t)t.j, dp) + row_off), p0, 0xFu, al);
+            store4<1>(de + (__umul24((uint32_t)t.j, dp) + row_off), p0, 0xFu, al);
             gather_one_raw(q, raw_q, L.sx, L.sy2, p1);
             if (band_row)
-                store4(de + (__umul24((uint32_t)jm, dp) + row_off), p1, 0xFu, al);
+                store4<1>(de + (__umul24((uint32_t)jm, dp) + row_off), p1, 0xFu, al);
         }
         return;
     }
@@ -2040,10 +2052,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     } else {
         gather_one_raw(b, raw_b, L.sx, L.sy, p0);
         wait_vm_barrier_imm<0>();
-        store4(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), p0, 0xFu, dst_rows_dword_aligned(ua, 0));
+        store4<1>(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), p0, 0xFu, dst_rows_dword_aligned(ua, 0));
         gather_one_raw(q, raw_q, L.sx, L.sy2, p1);
         if (band_row)
-            store4(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(ua, 0));
+            store4<1>(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(ua, 0));
     }
 }
 
@@ -2144,20 +2156,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_SEQ_WAV
     gather_taps_raw(ta_b, W_b, pitch_b, pix);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // band box landed; every wave has sampled the tile box
     raw_box_dma(b, mb, ua.u[1].src, (uint32_t)ua.u[1].src_pitch, lane, wave, raw_b);
-    store4(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 0));
+    store4<1>(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 0));
     gather_taps_raw(ta_q, W_q, pitch_q, pix);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has sampled the band box
     raw_box_dma(q, mq, ua.u[1].src, (uint32_t)ua.u[1].src_pitch, lane, wave, raw_q);
     if (band_row)
-        store4(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 0));
+        store4<1>(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 0));
     // ---- eye 1 (behind its tile box: eye 0's tile store and its band's nq requests; the predicated band store is not counted) ----
     wait_vm_barrier(nq + 1);
     gather_taps_raw(ta_b, W_b, pitch_b, pix);
     wait_vm_barrier_imm<0>();
-    store4(ua.u[1].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 1));
+    store4<1>(ua.u[1].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 1));
     gather_taps_raw(ta_q, W_q, pitch_q, pix);
     if (band_row)
-        store4(ua.u[1].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 1));
+        store4<1>(ua.u[1].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 1));
 }
 
 // ---- two tile pairs per workgroup: the second pair's boxes are in flight while the first one is sampled ----
