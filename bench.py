@@ -78,6 +78,10 @@ WORKLOADS = {
                 desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, bilinear (k_ray_lin_cn since r03; not a BASELINE config)"),
     "C2A": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=4,
                 desc="L+R 4096x4096 BGRA -> 8192x4096 SBS, PolynomialScaler, bilinear (k_ray_lin_cn since r03; not a BASELINE config)"),
+    "C2C": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=2,
+                desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_CUBIC (the K x K tile kernel with 4 x 4 taps; not a BASELINE config)"),
+    "C2L": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=4,
+                desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_LANCZOS4 (the reference's default interpolation at C2's size; not a BASELINE config)"),
     "C2T": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, border=5,
                 desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, bilinear, BORDER_TRANSPARENT (tile kernels since r03; not a BASELINE config)"),
     "C2N": dict(size=4080, poly=[0, 1, -0.1], rot=None, interp=1,
