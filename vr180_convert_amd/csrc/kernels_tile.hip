@@ -2553,7 +2553,9 @@ __device__ __forceinline__ void gather_one_raw(const TileBox& b, uint32_t raw, c
     }
 }
 
-template <int VAR_W, int MP>
+// NC = 1: the host has bounded every pixel's fixed-point coordinates inside the cvRound trick's range (launch_ray_lin3_tile's
+// `coords_bounded`): the speculative coordinates need no clamps (2 v_med3_f32 per pixel of a launch that is bound by vector issue)
+template <int VAR_W, int MP, int NC = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR_WAVES, 8))) void k_ray_lin3_rot_pair_raw(
     KernelCtx c, UnitArgs ua, int n_units, int slot_bytes, unsigned tiles_x_magic, unsigned strip_len, unsigned strip_magic)
 {
@@ -2630,7 +2632,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     bool fastA, fastB = false;
     int nB = 0;
     unit_cols(0);
-    lane_coords<VAR_W, RM, 2, 0, 2, MP>(c, ua, zA, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LA);
+    lane_coords<VAR_W, RM, 2, 0, (NC ? 1 : 2), MP>(c, ua, zA, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LA);
     fastA = raw_box(reduce_box_all_nofence<NT / 64>(LA, red, tid), zA, bA);
     if (fastA) {
         const RawLanes m = raw_lanes(bA.cpr, lane);
@@ -2642,7 +2644,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
         int zb = zB;
         asm volatile("" : "+s"(zb));
         unit_cols(1);
-        lane_coords<VAR_W, RM, 2, 0, 2, MP>(c, ua, zb, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
+        lane_coords<VAR_W, RM, 2, 0, (NC ? 1 : 2), MP>(c, ua, zb, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
         fastB = raw_box(reduce_box_all_nofence<NT / 64>(LB, red + 16, tid), zB, bB);
         if (fastB) {
             const RawLanes m = raw_lanes(bB.cpr, lane);
@@ -3335,7 +3337,7 @@ hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry,
 template <int K>
 static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, int half_dwords,
                           bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
-                          int lean_raw_nwp, hipStream_t stream)
+                          int lean_raw_nwp, hipStream_t stream, bool coords_bounded)
 {
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     static const int upb_max = [] {  // V1C_UPB=<n>: A/B override of the units per workgroup
@@ -3413,17 +3415,25 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
             const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int) +
                                 (V1C_ROTPAIR_SEPARABLE ? 2 * 3 * kTW * sizeof(double) : 0);
             const bool mp = mpoly_all && c.ray.radial_m != nullptr;
+#define V1C_ROTPAIR(VW, MPV)                                                                                                                       \
+    do {                                                                                                                                           \
+        if (coords_bounded)                                                                                                                        \
+            hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<VW, MPV, 1>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic); \
+        else                                                                                                                                       \
+            hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<VW, MPV, 0>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic); \
+    } while (0)
             if (c.ray.var_is_w) {
                 if (mp)
-                    hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<1, 1>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic);
+                    V1C_ROTPAIR(1, 1);
                 else
-                    hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<1, 0>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic);
+                    V1C_ROTPAIR(1, 0);
             } else {
                 if (mp)
-                    hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<0, 1>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic);
+                    V1C_ROTPAIR(0, 1);
                 else
-                    hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<0, 0>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic);
+                    V1C_ROTPAIR(0, 0);
             }
+#undef V1C_ROTPAIR
             return;
         }
     }
@@ -3506,13 +3516,13 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 // buffer size (dwords) it was made for.
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
                                 bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
-                                int lean_raw_nwp, hipStream_t stream)
+                                int lean_raw_nwp, hipStream_t stream, bool coords_bounded)
 {
     const TileBox* bx = (const TileBox*)boxes;
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream); break;
-    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream); break;
-    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream); break;
+    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
+    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
+    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

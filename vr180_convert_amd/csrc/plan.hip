@@ -187,6 +187,7 @@ struct v1c_plan {
     int mirror_pipe_tab = 0;  // > 0: ... two tile rows per workgroup (k_ray_lin3_pair_mirror_pipe), so many table entries per pair in LDS
     int mirror_h = 0;
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
+    bool disable_coords_bounded = false;  // V1C_DISABLE_COORDS_BOUNDED=1: k_ray_lin3_rot_pair_raw with its clamps (A/B testing)
     bool disable_shared_entry = false;  // V1C_DISABLE_SHARED_ENTRY=1: keep the per-pixel table fallback compiled in
     bool disable_mpoly = false;         // V1C_DISABLE_MPOLY=1: no m-polynomial table (every tile takes the square root)
     bool plan_shared_entry = false;     // one table entry serves a lane's 4 pixels (ray_entry_is_shared)
@@ -194,6 +195,7 @@ struct v1c_plan {
     int mp_valid_upto = -1;             // m-polynomial table (when uploaded): intervals 0 .. this are all valid at the
                                         // level a lane needs (shared_entry_level)
     double m_reach_norot = 0;           // largest m an unrotated ray reaches
+    std::vector<double> g_bounds;       // radial_table_g_bounds(table): |G| over the entries 0 .. i
     // The tile-flag words are per plan: a ray pass sets them, the fix-up pass behind it consumes and clears
     // them.  Launch sequences that use them are serialised ACROSS streams (host: flags_mu; device: the next
     // sequence on another stream waits for flags_ev, recorded behind the previous fix-up pass), so one plan
@@ -324,6 +326,8 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
     {
         const char* e = tuning_env("V1C_DISABLE_FAST");
         p->disable_fast = e && e[0] == '1';
+        const char* ecb = tuning_env("V1C_DISABLE_COORDS_BOUNDED");
+        p->disable_coords_bounded = ecb && ecb[0] == '1';
         e = tuning_env("V1C_DISABLE_SHARED_ENTRY");
         p->disable_shared_entry = e && e[0] == '1';
         e = tuning_env("V1C_DISABLE_MPOLY");
@@ -380,6 +384,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             r.rx32 = 32.0 * a.rx, r.ry32 = 32.0 * a.ry, r.cx32 = 32.0 * a.cx, r.cy32 = 32.0 * a.cy;
             r.n_int_f = (double)r.n_int;
             p->m_reach_norot = ht.m_reach;
+            p->g_bounds = radial_table_g_bounds(p->table);
             p->ray_no_rot_safe = !a.has_rot && ray_reach_is_safe(p->table, ht.m_reach);
             p->front_hemisphere = ht.front_hemisphere;
             p->ray_plan_rot_safe = a.has_rot && ht.front_hemisphere && ray_reach_is_safe(p->table, rotated_reach(a.rot));
@@ -678,6 +683,9 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             // the m-polynomial table (no fp64 index arithmetic) serves a launch of overriding rotations
             // when every interval up to each unit's reach is valid at the level the lanes need
             bool mpoly_all = any_rot && p->ctx.ray.radial_m != nullptr;
+            // every pixel's |32 x|, |32 y| provably below 2^21 (half the cvRound trick's range): |x32 - cx32| <= |G| |rx32| with G bounded
+            // over every table entry in reach
+            bool coords_bounded = any_rot;
             if (any_rot) {
                 need_fixup = !p->front_hemisphere;
                 shared_entry = p->front_hemisphere;
@@ -686,6 +694,11 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                     const bool rotated = ua.u[k].has_rot || p->ana.has_rot;
                     const bool covered = rotated ? ray_reach_is_safe(p->table, rotated_reach(r)) : p->ray_no_rot_safe;
                     need_fixup = !covered;
+                    if (coords_bounded) {
+                        const RayParams& rp = p->ctx.ray;
+                        const double gb = covered ? radial_table_g_bound(p->table, p->g_bounds, rotated ? rotated_reach(r) : p->m_reach_norot) : INFINITY;
+                        coords_bounded = gb * std::fabs(rp.rx32) + std::fabs(rp.cx32) < 2097152.0 && gb * std::fabs(rp.ry32) + std::fabs(rp.cy32) < 2097152.0;
+                    }
                     shared_entry = shared_entry && covered &&
                                    (rotated ? ray_entry_is_shared(p->table, rotated_reach(r), p->ray_step) : p->plan_shared_entry);
                     if (mpoly_all) {  // (same interval bound as mpoly_first_ok: reach + 2 for the fp32 index)
@@ -726,7 +739,8 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                 // precomputed tile boxes describe the plan's own rotation only
                 HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
                                              shared_entry && !p->disable_shared_entry, mpoly_all && !p->disable_mpoly,
-                                             any_rot ? nullptr : p->rest_list, p->n_rest, p->lean_half, p->strip_len, p->lean_raw_nwp, st));
+                                             any_rot ? nullptr : p->rest_list, p->n_rest, p->lean_half, p->strip_len, p->lean_raw_nwp, st,
+                                             coords_bounded && !p->disable_coords_bounded));
             } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
             }

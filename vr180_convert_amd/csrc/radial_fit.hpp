@@ -516,6 +516,30 @@ inline int table_intervals_for(double ray_step)
     return 256;
 }
 
+// Upper bounds of |G|: entry i of the result bounds every table entry 0 .. i over its whole validated range |z| <= 2.5 (sum of the
+// coefficient magnitudes); infinity from the first flagged entry on.  With |x32 - cx32| <= |G| |rx32| it bounds the fixed-point
+// coordinates of EVERY pixel of a launch whose rays reach entry i at most, inside the source or not.
+inline std::vector<double> radial_table_g_bounds(const RadialTable& T)
+{
+    std::vector<double> out((size_t)T.n_int);
+    double bound = 0;
+    for (int i = 0; i < T.n_int; i++) {
+        const double* c = &T.coef[(size_t)i * kRadialCoefs];
+        double b = 0, zp = 1;
+        for (int k = 0; k < kRadialCoefs; k++, zp *= 2.5)
+            b += std::fabs(c[k]) * zp;
+        bound = (b == b) ? std::max(bound, b) : INFINITY;
+        out[(size_t)i] = bound;
+    }
+    return out;
+}
+inline double radial_table_g_bound(const RadialTable& T, const std::vector<double>& bounds, double m_reach)
+{
+    const double u = (T.var_is_w ? std::sqrt(m_reach / 2) : m_reach) * (1 + 1e-9);
+    const int last = std::min(T.n_int - 1, (int)(u * T.inv_step) + 3);
+    return last >= 0 && (size_t)last < bounds.size() ? bounds[(size_t)last] : INFINITY;
+}
+
 // true when no pixel of an unrotated chain can land in a flagged interval
 inline bool ray_reach_is_safe(const RadialTable& T, double m_reach)
 {
