@@ -178,3 +178,28 @@ def test_cn_kernel_waits_for_every_request_before_the_barrier(kernels_dis):
             if x.op == "s_barrier" and ins[i - 1].kind != "W":
                 # a bare barrier (the table slice's __syncthreads) must sit in front of the first request
                 assert not any(y.kind == "D" for y in ins[:i]), (name, hex(x.addr))
+
+
+def test_hand_written_memory_instructions_keep_their_wait_states(kernels_dis):
+    """The two memory instructions issued from asm statements are invisible to the compiler's hazard recogniser, so their wait
+    states are part of the statements (csrc/kernels_tile.hip raw_box_dma, store4<1>) -- checked here in the code object:
+    * every SGPR-base LDS-DMA request of a box (``global_load_lds_dwordx4 v, s[..]`` behind an ``s_mov_b32 m0``) has ``s_nop 2``
+      directly in front of it (M0 write -> use, VALU-written SGPR -> VMEM read) and puts M0 back directly behind it;
+    * every system-scope streaming store (``sc0 sc1 nt``) is directly followed by ``s_nop 1`` (store data of more than 8 bytes ->
+      VALU write of those registers)."""
+    n_dma = n_st = 0
+    for name, ins in kernels_dis.items():
+        if not name.startswith("_ZN3v1c"):
+            continue
+        for i, x in enumerate(ins):
+            # (the statement: s_mov_b32 sA, m0 | s_mov_b32 m0, sB | s_nop 2 | request | s_mov_b32 m0, sA; requests the compiler
+            # emits for the builtin have no save in front and get their wait states from its own hazard recogniser)
+            if (x.op == "global_load_lds_dwordx4" and i >= 3 and ins[i - 2].op == "s_mov_b32" and ins[i - 2].args.startswith("m0")
+                    and ins[i - 3].op == "s_mov_b32" and ins[i - 3].args.replace(" ", "").endswith(",m0")):
+                assert ins[i - 1].op == "s_nop" and ins[i - 1].args.strip() == "2", (name, hex(x.addr), ins[i - 1].op, ins[i - 1].args)
+                assert ins[i + 1].op == "s_mov_b32" and ins[i + 1].args.startswith("m0"), (name, hex(x.addr))
+                n_dma += 1
+            if x.op.startswith("global_store") and {"sc0", "sc1", "nt"} <= set(x.args.split()):  # (printed as "sc0 nt sc1")
+                assert ins[i + 1].op == "s_nop" and ins[i + 1].args.strip() == "1", (name, hex(x.addr), ins[i + 1].op, ins[i + 1].args)
+                n_st += 1
+    assert n_dma >= 20 and n_st >= 8, (n_dma, n_st)
