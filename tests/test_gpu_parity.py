@@ -913,7 +913,7 @@ def test_batch_plan_run_is_graph_capturable(V, oracle_mod, dev):
                                  {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_COORDS_BOUNDED": "1"}, {"V1C_DISABLE_LEAN": "1"}, {"V1C_DISABLE_MERGE": "1"}, {"V1C_XCD_STRIPS": "2"},
                                  {"V1C_DISABLE_MIRROR": "1"}, {"V1C_MIRROR_RAW": "0"}, {"V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_RAW": "7"}, {"V1C_MIRROR_PIPE": "1"},
                                  {"V1C_MIRROR_PIPE": "1", "V1C_PIPE_SINGLE_ROWS": "0"}, {"V1C_MIRROR_PIPE": "1", "V1C_MIRROR_RAW": "7", "V1C_PIPE_SINGLE_ROWS": "3"},
-                                 {"V1C_MIRROR_SEQ": "0"}, {"V1C_MIRROR_SEQ_KB": "5"}, {"V1C_MIRROR_SEQ_KB": "16"}, {"V1C_MIRROR_SEQ": "0", "V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_SEQ": "0", "V1C_MIRROR_RAW": "7"},
+                                 {"V1C_MIRROR_SEQ": "0"}, {"V1C_SEQ_NOREST": "0"}, {"V1C_MIRROR_SEQ_KB": "5"}, {"V1C_MIRROR_SEQ_KB": "16"}, {"V1C_MIRROR_SEQ": "0", "V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_SEQ": "0", "V1C_MIRROR_RAW": "7"},
                                  {"V1C_LEAN_RAW": "0"}, {"V1C_LEAN_RAW": "4"}, {}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_variants_bit_exact(env):

@@ -2083,8 +2083,11 @@ __device__ __forceinline__ void gather_taps_raw(const uint32_t (&ta)[kPX], const
     }
 }
 
-template <int VAR_W>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_SEQ_WAVES, 8))) void k_ray_lin3_pair_mirror_seq(
+// REST = 0: the plan's rest list is empty (C2: every tile pair fits) -- the instantiation without the general pair code, whose
+// registers (74 against 68 VGPRs, 94 against 66 SGPRs) and LDS (its cell buffers) otherwise set the occupancy of a launch that never
+// runs it: 7 instead of 6 workgroups per CU
+template <int VAR_W, int REST = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_SEQ_WAVES : V1C_SEQ_WAVES + 1, 8))) void k_ray_lin3_pair_mirror_seq(
     KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
     unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int cap_kb,
     unsigned rest_rows)
@@ -2093,14 +2096,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_SEQ_WAV
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 raw boxes of cap_kb KB (or the general code's cell buffers)
     const int tid = threadIdx.x;
-    if (blockIdx.y < rest_rows) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin >= (unsigned)n_rest)
+    if constexpr (REST) {
+        if (blockIdx.y < rest_rows) {
+            const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+            if (lin >= (unsigned)n_rest)
+                return;
+            const uint32_t v = rest_list[lin];
+            shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
+                                                      half_dwords, tabw, (glb_u32_ptr)c.itab);
             return;
-        const uint32_t v = rest_list[lin];
-        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
-                                                  tabw, (glb_u32_ptr)c.itab);
-        return;
+        }
     }
     const Geom& g = c.g;
     const RayParams& P = c.ray;
@@ -3064,6 +3069,21 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, c
     const unsigned raw_slen = (slen & 0x80000000u) ? slen : (strip_rows && strip_rows * grid.x < raw_per ? strip_rows * grid.x : 0u);
     const unsigned raw_smagic = (raw_slen && !(raw_slen & 0x80000000u)) ? (unsigned)(0x100000000ull / raw_slen) + 1u : 0u;
     if (seq_kb > 0 && n_eyes == 2) {  // the eyes one after the other: two buffers of seq_kb KB (rest list made for that size)
+        static const bool norest_off = [] {  // V1C_SEQ_NOREST=0 (A/B): the instantiation with the general pair code for every plan
+            const char* e = tuning_env("V1C_SEQ_NOREST");
+            return e && e[0] == '0';
+        }();
+        if (n_rest == 0 && !norest_off) {  // nothing for the general pair code: the instantiation (and the LDS) without it
+            const dim3 rgrid(full.x, raw_rows, 1);
+            const size_t slds = (size_t)2 * 1024 * (size_t)seq_kb + 16;
+            if (c.ray.var_is_w)
+                hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<1, 0>), rgrid, block, slds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                                   half_dwords, mirror_h, xmagic, rest_list, 0, raw_slen, raw_smagic, seq_kb, 0u);
+            else
+                hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<0, 0>), rgrid, block, slds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
+                                   half_dwords, mirror_h, xmagic, rest_list, 0, raw_slen, raw_smagic, seq_kb, 0u);
+            return hipGetLastError();
+        }
         const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
         const dim3 rgrid(full.x, raw_rows + rest_rows, 1);
         const size_t slds = std::max((size_t)half_dwords * 8 + 16, (size_t)2 * 1024 * (size_t)seq_kb);
