@@ -909,10 +909,56 @@ def test_batch_plan_run_is_graph_capturable(V, oracle_mod, dev):
             assert np.array_equal(dsts[k].cpu().numpy(), want[k]), k
 
 
+def test_launches_of_more_than_16_units_go_through_the_unit_ring(V, oracle_mod, dev):
+    """Up to 16 units travel in the kernel arguments; longer batches are copied into a slot of the plan's device ring by
+    launches of their own (plan.hip: ring_put) and run as ONE launch: 37 frames sharing a map (the lean batch kernel, 5 groups),
+    21 units with a rotation each (k_ray_lin3_rot_pair_raw: 11 pairs, the last one half empty), repeated so that the ring wraps,
+    and the same batch recorded into a graph (capture slots)."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    size = 256
+    spec = [("equirect_enc", True), CS.EQUI]
+    t = CS.to_product(spec)
+    imgs = [noise_disc(size, size, 300 + k) for k in range(37)]
+    want = oracle_mod.apply(spec, imgs, size_output=(size, size), interpolation=1, radius=size / 2)
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    for rep in range(6):  # (4 ring slots)
+        dsts = [torch.zeros_like(x) for x in srcs]
+        assert V.remap_tensors(t, srcs, dsts, radius=size / 2, interpolation=1) == ["ray"]
+        for k in range(37):
+            assert np.array_equal(dsts[k].cpu().numpy(), want[k]), (rep, k)
+    # a rotation per unit
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    quats = [CS.c5_spec(f // 2, f % 2)[1][1] for f in range(21)]
+    dsts = [torch.zeros_like(x) for x in srcs[:21]]
+    V.remap_tensors(base, srcs[:21], dsts, radius=size / 2, interpolation=1, rotations=quats)
+    for f in range(21):
+        w = oracle_mod.apply(CS.c5_spec(f // 2, f % 2), [imgs[f]], size_output=(size, size), interpolation=1, radius=size / 2)[0]
+        assert np.array_equal(dsts[f].cpu().numpy(), w), f
+    # recorded into a graph: the launch owns a capture slot of the ring
+    dsts = [torch.zeros_like(x) for x in srcs]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        V.remap_tensors(t, srcs, dsts, radius=size / 2, interpolation=1)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        V.remap_tensors(t, srcs, dsts, radius=size / 2, interpolation=1)
+    for _ in range(2):
+        for d in dsts:
+            d.zero_()
+        V.remap_tensors(t, srcs[:20], [torch.empty_like(x) for x in srcs[:20]], radius=size / 2, interpolation=1)  # eager traffic in between
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for k in range(37):
+            assert np.array_equal(dsts[k].cpu().numpy(), want[k]), k
+
+
 @pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_DISABLE_MPOLY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"},
                                  {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_COORDS_BOUNDED": "1"}, {"V1C_DISABLE_LEAN": "1"}, {"V1C_DISABLE_MERGE": "1"}, {"V1C_XCD_STRIPS": "2"},
-                                 {"V1C_DISABLE_MIRROR": "1"}, {"V1C_MIRROR_RAW": "0"}, {"V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_RAW": "7"}, {"V1C_MIRROR_PIPE": "1"},
-                                 {"V1C_MIRROR_PIPE": "1", "V1C_PIPE_SINGLE_ROWS": "0"}, {"V1C_MIRROR_PIPE": "1", "V1C_MIRROR_RAW": "7", "V1C_PIPE_SINGLE_ROWS": "3"},
+                                 {"V1C_DISABLE_MIRROR": "1"}, {"V1C_MIRROR_RAW": "0"}, {"V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_RAW": "7"},
                                  {"V1C_MIRROR_SEQ": "0"}, {"V1C_SEQ_NOREST": "0"}, {"V1C_MIRROR_SEQ_KB": "5"}, {"V1C_MIRROR_SEQ_KB": "16"}, {"V1C_MIRROR_SEQ": "0", "V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_SEQ": "0", "V1C_MIRROR_RAW": "7"},
                                  {"V1C_LEAN_RAW": "0"}, {"V1C_LEAN_RAW": "4"}, {}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))

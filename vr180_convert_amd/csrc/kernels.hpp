@@ -23,7 +23,9 @@ constexpr int kBlockY = 4;   // rows (waves) per workgroup
 
 enum { MODE_LITERAL = 0, MODE_RAY = 1, MODE_LUT = 2, MODE_FIXUP = 3 };
 
-// Everything a launch needs besides the units; passed by value as a kernel argument.
+// Everything a launch needs besides the units and its own scalars: launch-invariant.  The plan keeps a copy in device memory
+// (v1c_plan::ctx_dev) that the tile kernels read through a constant-address-space reference -- scalar loads where a value is
+// used; the generic kernels (kernels.hip) still take it by value.
 struct KernelCtx {
     Geom g;
     const v1c_chain* chain;   // device copy of the lowered chain (literal / fix-up modes)
@@ -35,42 +37,77 @@ struct KernelCtx {
     int64_t map_pitch;        // bytes
 };
 
+// ---- argument block of the tile kernels (kernels_tile.hip): their ONE by-value kernel argument ----
+// Until round 3 every tile kernel took KernelCtx (330 bytes) and UnitArgs (16 units, 1.8 KB) by value.  Kernel-argument loads are
+// invariant and dereferenceable, so the compiler hoisted them to the kernel entry and kept them live: 98 of the 102 scalar
+// registers pinned, up to 28 of them spilled into vector lanes (two instantiations into scratch), and 16 units per launch at most.
+// Now the launch-invariant part is plan-resident (`ctx`), the units are read through a pointer -- the launch's own copy in this block
+// for up to kInlineUnits units (the runtime copies kernel arguments for free; no upload in front of a pair's 47 us launch) or a slot
+// of the plan's device ring for longer batches (any number of units per launch) -- and the kernels read everything through
+// constant-address-space references: scalar loads that stay where the value is used.
+constexpr int kInlineUnits = 16;
+struct TileBox;
+struct TileArgs {
+    const KernelCtx* ctx;        // plan-resident copy (device memory)
+    const DevUnit* units;        // null: the launch's units are `inl` below; else n_units records in device memory
+    const TileBox* boxes;        // plan-time tile boxes (null: units that override the rotation reduce theirs in the kernel)
+    const TileBox* mboxes;       // ... of the bands that mirror the tiles (mirror launches)
+    const uint32_t* rest_list;   // tiles (ty << 16 | tx) a launch's fast path leaves to its general code / the tile list of a LIST launch
+    uint32_t* tile_flags;        // one word per (unit slot, tile) for the fix-up pass behind this launch; null: proven unnecessary
+    int n_units, upb;            // units of the launch, units per workgroup group
+    int half_dwords, n_rest;     // LDS dwords per box buffer of the general pair / batch code; entries of rest_list
+    unsigned tiles_x_magic, strip_len, strip_magic, rest_rows;  // xcd_tile(); rows of workgroups in front of the grid that serve rest_list
+    int mirror_h, kb, tiles_x, pad;  // kb: box buffer KB of the LDS-DMA kernels (bytes for k_ray_lin3_rot_pair_raw)
+    DevUnit inl[kInlineUnits];
+};
+
+// the units of one launch as the host launchers see them
+struct LaunchUnits {
+    const DevUnit* host;  // n records
+    const DevUnit* dev;   // their device copy (ring slot), or null: n <= kInlineUnits, they travel in the kernel arguments
+    int n;
+};
+
 int tiles_per_unit(const Geom& g);
 hipError_t launch_remap(int mode, const KernelCtx& c, const UnitArgs& ua, int n_units, hipStream_t stream);
 hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float* xmap, float* ymap, int64_t pitch,
                           hipStream_t stream);
 
-// hot configuration (CN = 3, INTER_LINEAR, BORDER_CONSTANT, ray mode): kernels_tile.hip
+// ---- tile kernels (kernels_tile.hip).  Every launcher takes the plan's context twice -- `c`, the host copy its decisions read, and
+// `cdev`, the device copy the kernels read --, the launch's units and `flags`: the plan's tile-flag words when a fix-up pass follows
+// the launch, null when the host has proven it unnecessary (the kernels then write none). ----
+// copy `n` unit records into device memory (a ring slot) with launches of their own: stream-ordered and graph-capturable
+hipError_t launch_put_units(DevUnit* dst, const DevUnit* host, int n, hipStream_t stream);
+// hot configuration (CN = 3, INTER_LINEAR, BORDER_CONSTANT, ray mode)
 bool tile_kernel_supports(const Geom& g);
 // k_ray_lin_cn (grayscale / BGRA, bilinear): same plan-time boxes (launch_tile_boxes); `kb` = tile_cn_box_kb(); every source and its
 // pitch dword-aligned, no unit overriding the rotation, one table entry per lane (shared_entry)
 bool cn_kernel_supports(const Geom& g);
 int tile_cn_box_kb(const void* host_boxes, const Geom& g);
-hipError_t launch_ray_lin_cn(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int kb, hipStream_t stream);
+hipError_t launch_ray_lin_cn(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,
+                             int kb, hipStream_t stream);
 size_t tile_box_bytes(const Geom& g);
-hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream, int mirror_h = 0);
-// apply_lr pairs of unrotated chains: a tile and its mirror image about the equator from one set of coordinates
-// (k_ray_lin3_pair_mirror); `host_mboxes` = boxes of the mirrored bands (launch_tile_boxes with mirror_h).
-// tile_mirror_rest: the tiles (ty << 16 | tx) that launch leaves to the pair kernel; false: no mirror launch for this plan
-// `raw_nwp` > 0: for k_ray_lin3_pair_mirror_raw (boxes by LDS-DMA, packed BGR in LDS, box buffers of raw_nwp KB:
-// tile_mirror_raw_passes) instead of k_ray_lin3_pair_mirror
-// `full_rows`: for k_ray_lin3_pair_mirror_raw proper (tile rows 0 .. TY / 2, boxes of up to two buffers: mirror_raw_fit), `n_eyes` = 2
-// (apply_lr's pair) or 1 (a single image: its own list)
+hipError_t launch_tile_boxes(const KernelCtx& c, const KernelCtx* cdev, void* boxes, bool shared_entry, hipStream_t stream, int mirror_h = 0);
+// apply_lr pairs of unrotated chains: a tile and its mirror image about the equator from one set of coordinates;
+// `host_mboxes` = boxes of the mirrored bands (launch_tile_boxes with mirror_h).
+// tile_mirror_rest: the tiles (ty << 16 | tx) that launch leaves to the general pair code; false: no mirror launch for this plan.
+// `raw_nwp` > 0: for the LDS-DMA kernels (packed BGR boxes in LDS, buffers of raw_nwp KB: tile_mirror_raw_passes), whose workgroups
+// serve tile rows 0 .. TY / 2 (`full_rows`) and `n_eyes` = 2 (apply_lr's pair) or 1 (a single image: its own list) units;
+// raw_nwp == 0 (tuning build): for the register-staged k_ray_lin3_pair_mirror
 bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geom& g, int half_dwords, int mirror_h,
                       std::vector<uint32_t>& rest, int raw_nwp, bool full_rows = false, int n_eyes = 2);
 int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, const Geom& g, int permille = 980, int max_kb = 12);
-// `pipe_tab` > 0: k_ray_lin3_pair_mirror_pipe (two tile rows per workgroup, the second pair's boxes requested while the first is
-// sampled), tile_mirror_pipe_tab() table entries per pair in LDS
-hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
-                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream,
-                                       int n_eyes = 2,   // n_eyes = 1 (raw_nwp > 0): a single image through the same workgroups
-                                       int seq_kb = 0);  // > 0 (pairs): k_ray_lin3_pair_mirror_seq, two box buffers of seq_kb KB, the eyes one after the other
-int tile_mirror_pipe_tab(const void* host_boxes, const void* host_mboxes, const Geom& g, int raw_nwp);
+// lu.n = 2: a pair -- k_ray_lin3_pair_mirror_seq (seq_kb > 0: two box buffers of seq_kb KB, the eyes one after the other); 1: a single
+// image through the one-eye instantiation of k_ray_lin3_pair_mirror_raw (raw_nwp KB per box).  Tuning build: seq_kb == 0 selects the
+// four-buffer / register-staged A/B partners
+hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, const void* boxes,
+                                       const void* mboxes, int half_dwords, int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp,
+                                       hipStream_t stream, int seq_kb);
 int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 // `coords_bounded` (launches without boxes): the host has bounded |32 x|, |32 y| < 2^21 for every pixel of every unit
 // (radial_table_g_bound): k_ray_lin3_rot_pair_raw evaluates its speculative coordinates without the clamps of the cvRound trick
-hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
-                                bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,
+                                int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
                                 int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded = false);
 int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int lean_half);
 int tile_lean_half_dwords(int half_dwords);

@@ -30,7 +30,9 @@
 // Compile-time switches for A/B measurements: V1C_TILE_W (64), V1C_UPB (8), V1C_XCD_SWIZZLE (1),
 // V1C_STAMPS (per-phase cycle counters); run-time: V1C_UPB=<n>.
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.hpp"
 
@@ -39,6 +41,43 @@ namespace v1c {
 #ifndef V1C_TILE_W
 #define V1C_TILE_W 64
 #endif
+// ---- how the kernels see their arguments (kernels.hpp: TileArgs) ----
+// Constant address space: a load through these is a scalar load (s_load) whatever stores or asm statements surround it -- the
+// fence-less vmcnt protocol of the LDS-DMA kernels must never see a compiler-made VECTOR load behind a request -- and, unlike a load
+// of a by-value kernel argument, it is not speculated to the kernel entry: the value occupies scalar registers from its use on.
+#define V1C_CONST __attribute__((address_space(4)))
+typedef const V1C_CONST KernelCtx& ctx_cref;
+typedef const V1C_CONST Geom& geom_cref;
+typedef const V1C_CONST RayParams& ray_cref;
+typedef const V1C_CONST DevUnit* units_cptr;
+typedef const V1C_CONST TileArgs& args_cref;
+typedef const V1C_CONST double* rot_cptr;  // 9 doubles, row-major
+
+// the kernel's own argument block (its one by-value parameter: offset 0 of the kernel-argument segment)
+__device__ __forceinline__ args_cref kernel_args()
+{
+    return *(const V1C_CONST TileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+__device__ __forceinline__ ctx_cref args_ctx(args_cref a)
+{
+    return *(const V1C_CONST KernelCtx*)a.ctx;
+}
+__device__ __forceinline__ units_cptr args_units(args_cref a)
+{
+    return a.units ? (units_cptr)a.units : (units_cptr)a.inl;
+}
+// a generic copy of the geometry for the border-aware samplers of v1c_core.hpp (slow paths only)
+__device__ __forceinline__ Geom geom_copy(geom_cref g)
+{
+    Geom r;
+    r.src_h = g.src_h, r.src_w = g.src_w, r.dst_h = g.dst_h, r.dst_w = g.dst_w;
+    r.cn = g.cn, r.interp = g.interp, r.border = g.border;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        r.cval[k] = g.cval[k];
+    return r;
+}
+
 constexpr int kTW = V1C_TILE_W;            // output tile width (px); height = threads / kLanesX
 constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_BOX_KB
@@ -59,14 +98,6 @@ constexpr int kLanesX = kTW / 4;           // lanes per tile row (4 px each)
 #ifndef V1C_LEAN_RING
 #define V1C_LEAN_RING 2  // box buffers of k_ray_lin3_batch_lean_raw (2 or 3: the boxes of 1 or 2 units in flight; C3: 0.1807 / 0.1852 ms,
                          // 7 / 5 workgroups per CU)
-#endif
-#ifndef V1C_RAW_RC_LDS
-#define V1C_RAW_RC_LDS 0  // 1 (A/B builds): k_ray_lin3_pair_mirror_raw takes the tile's row / column table values by LDS-DMA instead of 88 bytes per
-                          // lane through L1 (a third of its L1 accesses, and no load in front of the box requests): C2 0.0488 against 0.0491 ms,
-                          // C1 0.0193 against 0.0184, C1S 0.0131 against 0.0124 (r03: profiles/r03b_final/ab_rc_lds.log)
-#endif
-#ifndef V1C_MIRROR_BIG
-#define V1C_MIRROR_BIG 0  // 1 (A/B builds): k_ray_lin3_pair_mirror_raw also serves pairs whose boxes need two buffers each, eye by eye (0: they go to the rest list)
 #endif
 #ifndef V1C_RAW_WAVES
 #define V1C_RAW_WAVES 5  // waves per SIMD k_ray_lin3_pair_mirror_raw is compiled for
@@ -102,8 +133,9 @@ __device__ __forceinline__ int wave_min_to_lane63(int v)
 
 // (sx, sy) = cv2's fixed-point coordinates cvRound(32 x), cvRound(32 y)
 // (bit 24 of the result: the pixel is to be left untouched -- BORDER_TRANSPARENT with a footprint that leaves the source)
-__device__ __forceinline__ uint32_t slow_pixel_linear3_t(const uint8_t* src, int64_t pitch, int h, int w, Geom g, int sx, int sy)
+__device__ __forceinline__ uint32_t slow_pixel_linear3_t(const uint8_t* src, int64_t pitch, int h, int w, geom_cref gc, int sx, int sy)
 {
+    const Geom g = geom_copy(gc);
     uint8_t px[3] = {0, 0, 0};
     const Image im{src, pitch, h, w};
     const bool st = sample_linear_t<3>(im, g, taps_from_fixed(sx, sy), px);
@@ -165,11 +197,10 @@ struct LaneCoords {
 struct RowCol {
     double sl, cl, hl;            // row: sin / cos / 1-cos of the latitude
     double slon[kPX], qlon[kPX];  // columns: sin(lon) and 1-cos(lon) (no rotation) or cos(lon) (rotation)
-    double tlon[kPX];             // ROT = 2 only: slon / qlon / tlon = the unit's column vectors T_k = R_k0 sin(lon) + R_k2 cos(lon), k = 0, 1, 2
 };
 
 template <int ROT>
-__device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, RowCol& rc)
+__device__ __forceinline__ void load_rowcol(ray_cref P, int xc, int jc, RowCol& rc)
 {
     rc.sl = P.row_s[jc], rc.cl = P.row_c[jc], rc.hl = P.row_h[jc];
     const double* __restrict__ ps = P.col_s + xc;
@@ -200,29 +231,21 @@ __device__ __forceinline__ void load_rowcol(const RayParams& P, int xc, int jc, 
 // top-left tap follows borderInterpolate like remapNearest's).  The rounded pixel lies inside the bilinear footprint of the same
 // coordinate, so boxes computed with NN = 1 (k_tile_boxes) bound it.
 template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, int MPOLY, int MIRROR = 0, int NN = 0, typename TabPtr>
-__device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& ua, int z, const RowCol& rc, int npx, TabPtr tab,
+// `rot`: the rotation that applies (ROT != 0): the unit's own record -- the host stores the EFFECTIVE matrix there, the unit's override
+// or the chain's composed rotation (plan.hip: fill_unit) -- or c.ray.rot (k_tile_boxes)
+__device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowCol& rc, int npx, TabPtr tab,
                                             int tab0, int tabn, LaneCoords& L)
 {
-    const RayParams& P = c.ray;
-    const Geom& g = c.g;
+    ray_cref P = c.ray;
+    geom_cref g = c.g;
     const double sl = rc.sl, cl = rc.cl, hl = rc.hl;
     const double rx32 = P.rx32, ry32 = P.ry32, cx32 = P.cx32, cy32 = P.cy32;
 
     double A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, C0 = 0, C1 = 0, C2 = 0;
-    // ROT = 2: the rotated ray in its separable form v'_k = cos(lat) T_k(column) + sin(lat) R_k1 -- the per-column vectors T_k come
-    // with rc (computed once per tile column and unit), the lane adds 3 products and 3 FMAs per pixel instead of 9 + 6
-    if (ROT == 2) {
-        C0 = (ua.u[z].has_rot ? ua.u[z].rot[1] : P.rot[1]) * sl;
-        C1 = (ua.u[z].has_rot ? ua.u[z].rot[4] : P.rot[4]) * sl;
-        C2 = (ua.u[z].has_rot ? ua.u[z].rot[7] : P.rot[7]) * sl;
-    } else if (ROT) {
-        double R[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++)
-            R[q] = ua.u[z].has_rot ? ua.u[z].rot[q] : P.rot[q];
-        A0 = R[0] * cl, B0 = R[2] * cl, C0 = R[1] * sl;
-        A1 = R[3] * cl, B1 = R[5] * cl, C1 = R[4] * sl;
-        A2 = R[6] * cl, B2 = R[8] * cl, C2 = R[7] * sl;
+    if (ROT) {
+        A0 = rot[0] * cl, B0 = rot[2] * cl, C0 = rot[1] * sl;
+        A1 = rot[3] * cl, B1 = rot[5] * cl, C1 = rot[4] * sl;
+        A2 = rot[6] * cl, B2 = rot[8] * cl, C2 = rot[7] * sl;
     }
     const double* slon = rc.slon;
     const double* qlon = rc.qlon;
@@ -235,11 +258,7 @@ __device__ __forceinline__ void lane_coords(const KernelCtx& c, const UnitArgs& 
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
         double m;
-        if (ROT == 2) {
-            fx_[k] = fma(cl, slon[k], C0);
-            fy_[k] = fma(cl, qlon[k], C1);
-            m = 1.0 - fma(cl, rc.tlon[k], C2);
-        } else if (ROT) {
+        if (ROT) {
             fx_[k] = fma(A0, slon[k], fma(B0, qlon[k], C0));
             fy_[k] = fma(A1, slon[k], fma(B1, qlon[k], C1));
             m = 1.0 - fma(A2, slon[k], fma(B2, qlon[k], C2));
@@ -807,7 +826,7 @@ struct TileIds {
 };
 
 // tile (tx, ty) of a grid of tiles_x columns; the tile is 64 px wide and `th` = threads/16 rows high
-__device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid, int tx, int ty, int tiles_x, int th)
+__device__ __forceinline__ TileIds tile_ids(geom_cref g, int z, int tid, int tx, int ty, int tiles_x, int th)
 {
     TileIds t;
     const int lx = tid % kLanesX, ly = tid / kLanesX;
@@ -824,7 +843,7 @@ __device__ __forceinline__ TileIds tile_ids(const Geom& g, int z, int tid, int t
     return t;
 }
 
-__device__ __forceinline__ bool box_touches_image_end(const TileBox& b, const Geom& g)
+__device__ __forceinline__ bool box_touches_image_end(const TileBox& b, geom_cref g)
 {
     // only the last chunk(s) of the image's last row can reach past the allocation
     return (b.y0 + b.nrows >= g.src_h) & ((b.x0 + 4 * b.cpr) > g.src_w);
@@ -838,8 +857,12 @@ __device__ __forceinline__ bool box_touches_image_end(const TileBox& b, const Ge
 template <int VAR_W, int ROT, int K, int NT, int OWN, int NN = 0>
 // `mirror_h` > 0: the boxes of the MIRRORED bands instead -- entry (tx, ty) describes output rows mirror_h - j for
 // the rows j of tile (tx, ty) (k_ray_lin3_pair_mirror evaluates a tile and its mirror image from one set of coordinates).
-__global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, TileBox* boxes, int mirror_h)
+__global__ __launch_bounds__(NT) void k_tile_boxes(TileArgs a_)  // a.boxes: written here; a.mirror_h
 {
+    args_cref a = kernel_args();
+    ctx_cref c = args_ctx(a);
+    TileBox* boxes = const_cast<TileBox*>(a.boxes);
+    const int mirror_h = a.mirror_h;
     constexpr int NW = NT / 64;
     __shared__ __attribute__((aligned(16))) int red[4 * NW];
     __shared__ int red2[2 * NW];
@@ -848,7 +871,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, mirror_h > 0 ? min(max(mirror_h - t.j, 0), c.g.dst_h - 1) : t.jc, rc);
     LaneCoords L;
-    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, ua, 0, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
+    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, c.ray.rot, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
     TileBox b = reduce_box<K, NW>(L, red, tid);
     int interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L.ok == 0xFu) & (L.inside == 0xFu))) ? 1 : 0;
     const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
@@ -867,7 +890,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(KernelCtx c, UnitArgs ua, Til
     if (mpoly) {
         __syncthreads();  // red / red2 are reused
         LaneCoords L2;
-        lane_coords<VAR_W, ROT, K, 0, 0, 1, 0, NN>(c, ua, 0, rc, t.npx, c.ray.radial_m, 0, c.ray.n_int, L2);
+        lane_coords<VAR_W, ROT, K, 0, 0, 1, 0, NN>(c, c.ray.rot, rc, t.npx, c.ray.radial_m, 0, c.ray.n_int, L2);
         b = reduce_box<K, NW>(L2, red, tid);
         interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L2.ok == 0xFu) & (L2.inside == 0xFu)));
         interior = interior ? 3 : 0;  // (not interior any more: an ordinary tile, evaluated through w)
@@ -915,29 +938,29 @@ __device__ __forceinline__ void blend_taps(const Taps2& T, const LaneCoords& L, 
 
 // interior tile: every lane is active with 4 valid pixels -- three dword stores when the row
 // pointer is dword-aligned (wave-uniform per unit: dst and its pitch), bytes otherwise
-__device__ __forceinline__ bool dst_rows_dword_aligned(const UnitArgs& ua, int z)
+__device__ __forceinline__ bool dst_rows_dword_aligned(units_cptr U, int z)
 {
-    return ((((uintptr_t)ua.u[z].dst) | (uintptr_t)ua.u[z].dst_pitch) & 3u) == 0;
+    return ((((uintptr_t)U[z].dst) | (uintptr_t)U[z].dst_pitch) & 3u) == 0;
 }
 
 // first byte of the lane's 4 pixels: 32-bit offset (the host checks dst_h * dst_pitch < 2^32 and
 // dst_pitch < 2^24 before it selects these kernels)
-__device__ __forceinline__ uint8_t* dst_ptr(const UnitArgs& ua, int z, const TileIds& t)
+__device__ __forceinline__ uint8_t* dst_ptr(units_cptr U, int z, const TileIds& t)
 {
-    return ua.u[z].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[z].dst_pitch) + (uint32_t)t.x0 * 3u);
+    return U[z].dst + (__umul24((uint32_t)t.j, (uint32_t)U[z].dst_pitch) + (uint32_t)t.x0 * 3u);
 }
 
-__device__ __forceinline__ void store_interior(const UnitArgs& ua, int z, const TileIds& t, const uint32_t (&pix)[kPX])
+__device__ __forceinline__ void store_interior(units_cptr U, int z, const TileIds& t, const uint32_t (&pix)[kPX])
 {
-    store4(dst_ptr(ua, z, t), pix, 0xFu, dst_rows_dword_aligned(ua, z));
+    store4(dst_ptr(U, z, t), pix, 0xFu, dst_rows_dword_aligned(U, z));
 }
 
 // ---- slow-path patch (pixels with valid coordinates the tiled path did not produce) and store ----
 template <int K>
-__device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
+__device__ __forceinline__ void patch_and_store(ctx_cref c, units_cptr U, int z, const TileIds& t, const LaneCoords& L,
                                                 uint32_t (&pix)[kPX], unsigned done, const uint8_t* __restrict__ src)
 {
-    const Geom& g = c.g;
+    geom_cref g = c.g;
     const unsigned slow = L.ok & ~done;
     unsigned skip = 0;  // BORDER_TRANSPARENT (bilinear): pixels whose 2 x 2 footprint leaves the source keep the destination's bytes
     if (slow) {
@@ -949,7 +972,7 @@ __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitAr
                 if (slow & (1u << k)) {
                     const int fsx = k == 0 ? L.sx[0] : k == 1 ? L.sx[1] : k == 2 ? L.sx[2] : L.sx[3];
                     const int fsy = k == 0 ? L.sy[0] : k == 1 ? L.sy[1] : k == 2 ? L.sy[2] : L.sy[3];
-                    const uint32_t r = slow_pixel_linear3_t(src, ua.u[z].src_pitch, g.src_h, g.src_w, g, fsx, fsy);
+                    const uint32_t r = slow_pixel_linear3_t(src, U[z].src_pitch, g.src_h, g.src_w, g, fsx, fsy);
                     skip |= (r >> 24) << k;
 #pragma unroll
                     for (int q = 0; q < kPX; q++)
@@ -962,20 +985,20 @@ __device__ __forceinline__ void patch_and_store(const KernelCtx& c, const UnitAr
                 if (slow & (1u << k))
                     // (float)sx / 32 re-quantises to sx while |sx| < 2^24; beyond that the footprint is
                     // outside the source either way (saturated short coordinates)
-                    pix[k] = slow_pixel_table3_t<K>(src, ua.u[z].src_pitch, g.src_h, g.src_w, g.border,
+                    pix[k] = slow_pixel_table3_t<K>(src, U[z].src_pitch, g.src_h, g.src_w, g.border,
                                                     (uint32_t)g.cval[0] | ((uint32_t)g.cval[1] << 8) | ((uint32_t)g.cval[2] << 16), c.itab,
                                                     (float)L.sx[k] * 0.03125f, (float)L.sy[k] * 0.03125f);
         }
     }
     if (!t.active)
         return;
-    store4(dst_ptr(ua, z, t), pix, L.ok & ~skip, dst_rows_dword_aligned(ua, z));
+    store4(dst_ptr(U, z, t), pix, L.ok & ~skip, dst_rows_dword_aligned(U, z));
 }
 
 // ---- taps, blend, slow-path patch and store: shared tail of the kernels ----
 // `wtab` = OpenCV's int16 weight table for K = 4 / 8 (global memory, or LDS in the persistent kernel)
 template <int K, typename WPtr>
-__device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitArgs& ua, int z, const TileIds& t, const LaneCoords& L,
+__device__ __forceinline__ void sample_and_store(ctx_cref c, units_cptr U, int z, const TileIds& t, const LaneCoords& L,
                                                  const TileBox& b, bool use_lds, const uint32_t* boxw, WPtr wtab,
                                                  const uint8_t* __restrict__ src, uint32_t spitch, bool all_in = false)
 {
@@ -1019,7 +1042,7 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
         done = L.inside;
     }
 
-    patch_and_store<K>(c, ua, z, t, L, pix, done, src);
+    patch_and_store<K>(c, U, z, t, L, pix, done, src);
 }
 
 // ---- one tile for up to `upb` units that share the map (plan-time boxes) ----
@@ -1049,12 +1072,14 @@ __device__ __forceinline__ void sample_and_store(const KernelCtx& c, const UnitA
 // not eligible for it (lean_static_ok) exit at once; the host launches the general kernel on the list
 // of exactly those tiles (launch_tile_k).
 template <int VAR_W, int ROT, int K, int OWN, int PAIR, int NT, int LEAN, int NN = 0, typename WPtr>
-__device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitArgs& ua, const TileBox* __restrict__ boxes, int n_units,
-                                                int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw, int half_dwords,
-                                                double* tabw, WPtr wtab)
+__device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int upb, int zg, int tx, int ty, int tiles_x, uint32_t* boxw,
+                                                int half_dwords, double* tabw, WPtr wtab)
 {
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    const TileBox* __restrict__ boxes = a.boxes;
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     const int tid = threadIdx.x;
 #ifdef V1C_STAMPS
     unsigned long long stamp_ = __builtin_readcyclecounter();
@@ -1064,11 +1089,11 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     const int nu = min(upb, n_units - z0);
     // (the first two units' pointers are read here, next to the tile box, not behind it: every
     // dependent scalar load of the prologue is a wait)
-    const uint8_t* __restrict__ usrc0 = ua.u[z0].src;
-    const uint32_t upitch0 = (uint32_t)ua.u[z0].src_pitch;
-    const int z1 = min(z0 + 1, kMaxUnitsPerLaunch - 1);
-    const uint8_t* __restrict__ usrc1 = ua.u[z1].src;
-    const uint32_t upitch1 = (uint32_t)ua.u[z1].src_pitch;
+    const uint8_t* __restrict__ usrc0 = U[z0].src;
+    const uint32_t upitch0 = (uint32_t)U[z0].src_pitch;
+    const int z1 = min(z0 + 1, n_units - 1);
+    const uint8_t* __restrict__ usrc1 = U[z1].src;
+    const uint32_t upitch1 = (uint32_t)U[z1].src_pitch;
     // everything the tile needs from global memory is requested up front: the boxes of the first
     // two units, the radial-table slice and the row / column table entries (one exposed latency)
     TileBox b;
@@ -1086,8 +1111,8 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
     make_chunk_map<NT>(b, tid, M);
 
     auto issue = [&](int z, Staged& S) -> bool {  // start the box loads of unit z; false: it must gather from global memory
-        const uint8_t* __restrict__ src = z == z0 ? usrc0 : z == z0 + 1 ? usrc1 : ua.u[z].src;
-        const uint32_t spitch = z == z0 ? upitch0 : z == z0 + 1 ? upitch1 : (uint32_t)ua.u[z].src_pitch;
+        const uint8_t* __restrict__ src = z == z0 ? usrc0 : z == z0 + 1 ? usrc1 : U[z].src;
+        const uint32_t spitch = z == z0 ? upitch0 : z == z0 + 1 ? upitch1 : (uint32_t)U[z].src_pitch;
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
         const bool fits = box_fits(b, src, spitch, 4 * NT, LEAN ? 2 * half_dwords : half_dwords);
         if (fits) {
@@ -1142,9 +1167,9 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
             {
                 LaneCoords L;
                 if (OWN == 0 && mpoly)
-                    lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+                    lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
                 else
-                    lane_coords<VAR_W, ROT, K, OWN, 1, 0, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+                    lane_coords<VAR_W, ROT, K, OWN, 1, 0, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
 #pragma unroll
                 for (int k = 0; k < kPX; k++) {
                     ta[k] = __umul24((L.sy[k] >> 5) - b.y0, lpw4) + (uint32_t)((L.sx[k] >> 5) - b.x0) * 4u;  // byte offset in a box buffer
@@ -1153,8 +1178,8 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
             }
             const lds_u32_ptr lbox = (lds_u32_ptr)boxw;
             auto load_unit = [&](int z) {  // box loads of unit z into S0
-                const uint8_t* __restrict__ src = ua.u[z].src;
-                const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+                const uint8_t* __restrict__ src = U[z].src;
+                const uint32_t spitch = (uint32_t)U[z].src_pitch;
                 if (tail)
                     stage_load<true, false>(M, src, spitch, (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u, S0);
                 else
@@ -1168,7 +1193,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                     const lds_u32_ptr pb = (lds_u32_ptr)((const __attribute__((address_space(3))) char*)pa + lpw4);
                     pix[k] = blend3<4>(pa[0], pa[1], pb[0], pb[1], W[k]);
                 }
-                store_interior(ua, z, t, pix);
+                store_interior(U, z, t, pix);
             };
             if (single) {
                 // the few tiles whose box needs both buffers (diagonal footprints): one unit at a time,
@@ -1203,13 +1228,13 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         return;
     LaneCoords L;
     if (OWN == 0 && interior && mpoly)
-        lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (interior)
-        lane_coords<VAR_W, ROT, K, OWN, 1, 0, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, OWN, 1, 0, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (tab_lds)
-        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else
-        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, ua, z0, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z0].rot, rc, t.npx, P.radial, 0, P.n_int, L);
     const bool incomplete = L.ok != (1u << t.npx) - 1;
     V1C_STAMP(3);  // coordinates
 
@@ -1221,9 +1246,11 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         // a pair (apply_lr: the two eyes): both boxes are already visible, no further barrier --
         // straight-line code lets the second unit's LDS reads overlap the first unit's blend
         if (incomplete) {
-            c.tile_flags[t.flag_tile] = 1;
-            if (nu == 2)
-                c.tile_flags[t.flag_tile + t.flag_stride] = 1;
+            if (uint32_t* flags = a.tile_flags) {  // (null: the host proved that no fix-up pass is needed)
+                flags[t.flag_tile] = 1;
+                if (nu == 2)
+                    flags[t.flag_tile + t.flag_stride] = 1;
+            }
         }
         if (K == 2 && nu == 2 && fit0 && fit1) {
             // taps of both eyes first: the second eye's LDS latency hides behind the first eye's blend
@@ -1247,10 +1274,10 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                 }
                 V1C_STAMP(4);  // tap addresses + LDS reads issued
                 blend_taps(T0, L, pix);
-                store_interior(ua, z0, t, pix);
+                store_interior(U, z0, t, pix);
                 V1C_STAMP(5);  // blend + store, first eye
                 blend_taps(T1, L, pix);
-                store_interior(ua, z0 + 1, t, pix);
+                store_interior(U, z0 + 1, t, pix);
                 V1C_STAMP(6);  // blend + store, second eye
                 return;
             }
@@ -1268,9 +1295,9 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                 }
             }
             blend_taps(T0, L, pix);
-            patch_and_store<K>(c, ua, z0, t, L, pix, L.inside, ua.u[z0].src);
+            patch_and_store<K>(c, U, z0, t, L, pix, L.inside, U[z0].src);
             blend_taps(T1, L, pix);
-            patch_and_store<K>(c, ua, z0 + 1, t, L, pix, L.inside, ua.u[z0 + 1].src);
+            patch_and_store<K>(c, U, z0 + 1, t, L, pix, L.inside, U[z0 + 1].src);
             return;
         }
         if constexpr (K != 2) {
@@ -1338,21 +1365,22 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
                     pa[k] = (uint32_t)pp, pb[k] = (uint32_t)(pp >> 32);
                 }
             }
-            patch_and_store<K>(c, ua, z0, t, L, pa, L.inside, ua.u[z0].src);
-            patch_and_store<K>(c, ua, z0 + 1, t, L, pb, L.inside, ua.u[z0 + 1].src);
+            patch_and_store<K>(c, U, z0, t, L, pa, L.inside, U[z0].src);
+            patch_and_store<K>(c, U, z0 + 1, t, L, pb, L.inside, U[z0 + 1].src);
             return;
         }
         }
-        sample_and_store<K>(c, ua, z0, t, L, b, fit0, boxw, wtab, ua.u[z0].src, (uint32_t)ua.u[z0].src_pitch);
+        sample_and_store<K>(c, U, z0, t, L, b, fit0, boxw, wtab, U[z0].src, (uint32_t)U[z0].src_pitch);
         if (nu == 2)
-            sample_and_store<K>(c, ua, z0 + 1, t, L, b, fit1, boxw + half_dwords, wtab, ua.u[z0 + 1].src, (uint32_t)ua.u[z0 + 1].src_pitch);
+            sample_and_store<K>(c, U, z0 + 1, t, L, b, fit1, boxw + half_dwords, wtab, U[z0 + 1].src, (uint32_t)U[z0 + 1].src_pitch);
         return;
     }
     bool fit_cur = fit0, fit_nxt = fit1, fit_s = false;
     for (int u = 0; u < nu; u++) {
         const int z = z0 + u;
         if (incomplete)
-            c.tile_flags[t.flag_tile + u * t.flag_stride] = 1;
+            if (uint32_t* flags = a.tile_flags)
+                flags[t.flag_tile + u * t.flag_stride] = 1;
         if (u >= 1 && nu > 2)
             __syncthreads();
         if (u + 1 < nu && u + 1 >= 2) {
@@ -1362,7 +1390,7 @@ __device__ __forceinline__ void shared_map_tile(const KernelCtx& c, const UnitAr
         }
         if (u + 2 < nu)
             fit_s = issue(z + 2, S0);
-        sample_and_store<K>(c, ua, z, t, L, b, fit_cur, boxw + (u & 1) * half_dwords, wtab, ua.u[z].src, (uint32_t)ua.u[z].src_pitch,
+        sample_and_store<K>(c, U, z, t, L, b, fit_cur, boxw + (u & 1) * half_dwords, wtab, U[z].src, (uint32_t)U[z].src_pitch,
                             interior);
         fit_cur = fit_nxt;
         V1C_STAMP(4 + (u & 1));  // taps + blend + store of one unit
@@ -1417,15 +1445,17 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, uns
 // ---- one tile of ONE unit that overrides the rotation (per-frame calibration): box reduced in-kernel, table from global memory ----
 // `red`: 16 ints of LDS, `boxw`: kBoxBytes + 16 bytes of LDS (BGRx box)
 template <int VAR_W, int ROT, int K, int OWN, int PAIR, int NN = 0, typename WPtr>
-__device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs& ua, int z, int btx, int bty, int* red, uint32_t* boxw, WPtr wtab)
+__device__ __forceinline__ void rot_unit_tile(args_cref a, int z, int btx, int bty, int* red, uint32_t* boxw, WPtr wtab)
 {
     constexpr int NT = 256;
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     const int tid = threadIdx.x;
     const TileIds t = tile_ids(g, z, tid, btx, bty, gridDim.x, NT / kLanesX);
-    const uint8_t* __restrict__ src = ua.u[z].src;
-    const uint32_t spitch = (uint32_t)ua.u[z].src_pitch;
+    const uint8_t* __restrict__ src = U[z].src;
+    const uint32_t spitch = (uint32_t)U[z].src_pitch;
     const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
     RowCol rc;
     load_rowcol<ROT>(P, t.xc, t.jc, rc);
@@ -1439,9 +1469,9 @@ __device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs
     const bool tile_full = ((btx + 1) * kTW <= g.dst_w) & ((bty + 1) * (NT / kLanesX) <= g.dst_h);
     if (K == 2 && OWN == 0 && tile_full) {
         if (PAIR)
-            lane_coords<VAR_W, ROT, K, 0, 2, 1, 0, NN>(c, ua, z, rc, kPX, P.radial_m, 0, P.n_int, L);
+            lane_coords<VAR_W, ROT, K, 0, 2, 1, 0, NN>(c, U[z].rot, rc, kPX, P.radial_m, 0, P.n_int, L);
         else
-            lane_coords<VAR_W, ROT, K, 0, 2, 0, 0, NN>(c, ua, z, rc, kPX, P.radial, 0, P.n_int, L);
+            lane_coords<VAR_W, ROT, K, 0, 2, 0, 0, NN>(c, U[z].rot, rc, kPX, P.radial, 0, P.n_int, L);
         const BoxAll ba = reduce_box_all<NT / 64>(L, red, tid);
         if ((ba.xmin >= 0) & (ba.xmax < g.src_w - 2) & (ba.ymin >= 0) & (ba.ymax < g.src_h - 1)) {
             TileBox fb;
@@ -1471,15 +1501,15 @@ __device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs
                 uint32_t pix[kPX];
                 read_taps_lds<true>(L, fb, boxw, T);
                 blend_taps(T, L, pix);
-                store_interior(ua, z, t, pix);
+                store_interior(U, z, t, pix);
             } else {  // box too large for LDS (strong minification): gather from global memory
-                sample_and_store<K>(c, ua, z, t, L, fb, false, boxw, wtab, src, spitch);
+                sample_and_store<K>(c, U, z, t, L, fb, false, boxw, wtab, src, spitch);
             }
             return;
         }
         __syncthreads();  // `red` is reused below
     }
-    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, ua, z, rc, t.npx, P.radial, 0, P.n_int, L);
+    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z].rot, rc, t.npx, P.radial, 0, P.n_int, L);
     const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
     const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
     if (use_lds) {
@@ -1491,85 +1521,81 @@ __device__ __forceinline__ void rot_unit_tile(const KernelCtx& c, const UnitArgs
     }
     __syncthreads();
     if (L.ok != (1u << t.npx) - 1)
-        c.tile_flags[t.flag_tile] = 1;
-    sample_and_store<K>(c, ua, z, t, L, b, use_lds, boxw, wtab, src, spitch);
+        if (uint32_t* flags = a.tile_flags)
+            flags[t.flag_tile] = 1;
+    sample_and_store<K>(c, U, z, t, L, b, use_lds, boxw, wtab, src, spitch);
 }
 
 // BOXES = 1: boxes (+ table slices) precomputed by k_tile_boxes, coordinates shared by `upb` units.
 // BOXES = 0: units that override the rotation (per-frame calibration): one unit per workgroup, box
 //   reduced in-kernel, table read from global memory.
 template <int VAR_W, int ROT, int BOXES, int K, int OWN, int PAIR, int LIST = 0, int NN = 0>
-// LIST = 1 (BOXES = 1): blockIdx.x indexes `tile_list` (ty << 16 | tx) instead of the tile grid;
-// `tiles_x` = tile columns of the full grid then.  (A template switch rather than a null test: the
-// test split the kernel-argument loads of the prologue over two more dependent waits.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && PAIR && K == 2 && !ROT && !OWN) ? V1C_PAIR_WAVES : (!BOXES && K == 2) ? V1C_NOBOX_WAVES : 1, 8))) void k_ray_lin3_tile(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
-                                                       int upb, int half_dwords, unsigned tiles_x_magic,
-                                                       const uint32_t* __restrict__ tile_list, int tiles_x, unsigned strip_len,
-                                                       unsigned strip_magic)
+// LIST = 1 (BOXES = 1): blockIdx.x indexes a.rest_list (ty << 16 | tx) instead of the tile grid;
+// a.tiles_x = tile columns of the full grid then.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && PAIR && K == 2 && !ROT && !OWN) ? V1C_PAIR_WAVES : (!BOXES && K == 2) ? V1C_NOBOX_WAVES : 1, 8))) void k_ray_lin3_tile(TileArgs a_)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) int red[16];
     __shared__ __attribute__((aligned(16))) double tabw[BOXES ? kTabSlice * kRadialCoefs : 2];
-    const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
+    args_cref a = kernel_args();
+    const glb_u32_ptr wtab = K == 2 ? (glb_u32_ptr) nullptr : (glb_u32_ptr)args_ctx(a).itab;
     if (BOXES) {
-        int tx, ty;
+        int tx, ty, tiles_x;
         if (LIST) {
-            const uint32_t v = tile_list[blockIdx.x];
+            const uint32_t v = a.rest_list[blockIdx.x];
             tx = (int)(v & 0xffffu), ty = (int)(v >> 16);
+            tiles_x = a.tiles_x;
         } else {
-            xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+            xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty);
             tiles_x = gridDim.x;
         }
         // two box buffers of half_dwords each, sized by the plan from its largest tile box
         extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT, 0, NN>(c, ua, boxes, n_units, upb, blockIdx.z, tx, ty, tiles_x, dyn_box,
-                                                         half_dwords, tabw, wtab);
+        shared_map_tile<VAR_W, ROT, K, OWN, PAIR, NT, 0, NN>(a, a.n_units, a.upb, blockIdx.z, tx, ty, tiles_x, dyn_box, a.half_dwords, tabw, wtab);
     } else {
         __shared__ __attribute__((aligned(16))) uint32_t boxw[kBoxBytes / 4 + 4];
         // (natural tile order unless the host passes strips: with one block of tiles per XCD the swizzle measured 6 % slower on C5)
         int btx = blockIdx.x, bty = blockIdx.y;
-        if (strip_len)
-            xcd_tile(tiles_x_magic, strip_len, strip_magic, btx, bty);
-        rot_unit_tile<VAR_W, ROT, K, OWN, PAIR, NN>(c, ua, (int)blockIdx.z, btx, bty, red, boxw, wtab);
+        if (a.strip_len)
+            xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, btx, bty);
+        rot_unit_tile<VAR_W, ROT, K, OWN, PAIR, NN>(a, (int)blockIdx.z, btx, bty, red, boxw, wtab);
     }
 }
 
+#ifdef V1C_TUNING
 // The lean batch path of shared_map_tile as a kernel of its own (bilinear, plan-time boxes, more than
-// two units per workgroup): launched over the whole tile grid; k_ray_lin3_tile<..., PAIR = 0> then
-// runs on the list of the tiles this one leaves out.
+// two units per workgroup; register-staged boxes): the A/B partner (V1C_LEAN_RAW=0) of k_ray_lin3_batch_lean_raw, tuning build only.
 template <int VAR_W, int ROT, int OWN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units,
-                                                             int upb, int half_dwords, unsigned tiles_x_magic,
-                                                             const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len,
-                                                             unsigned strip_magic)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean(TileArgs a_)
 {
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
+    args_cref a = kernel_args();
     int tx, ty;
-    // `rest_list` != null: grid slice z = 0 serves the tiles the lean path leaves out, two units per
+    // a.rest_list != null: grid slice z = 0 serves the tiles the lean path leaves out, two units per
     // workgroup through the pair code, and the lean groups are slices 1 .. n_groups: the few
     // latency-bound workgroups are dispatched first and run alongside the lean ones instead of in a
     // launch of their own behind them (C3 0.210 -> 0.202 ms).  LDS is sized for the lean path: a
     // remaining tile whose box needs more gathers from global memory.
     int zl = (int)blockIdx.z;
-    if (rest_list != nullptr) {
+    if (a.rest_list != nullptr)
         zl -= 1;
-    }
     if (zl < 0) {
-        const unsigned pairs = (unsigned)(n_units + 1) / 2u;
+        const unsigned pairs = (unsigned)(a.n_units + 1) / 2u;
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin >= (unsigned)n_rest * pairs)
+        if (lin >= (unsigned)a.n_rest * pairs)
             return;
         const unsigned ti = lin / pairs, zg = lin - ti * pairs;
-        const uint32_t v = rest_list[ti];
-        shared_map_tile<VAR_W, ROT, 2, OWN, 1, 256, 0>(c, ua, boxes, n_units, 2, (int)zg, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
-                                                       half_dwords, tabw, (glb_u32_ptr)c.itab);
+        const uint32_t v = a.rest_list[ti];
+        shared_map_tile<VAR_W, ROT, 2, OWN, 1, 256, 0>(a, a.n_units, 2, (int)zg, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
+                                                       a.half_dwords, tabw, (glb_u32_ptr) nullptr);
         return;
     }
-    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
-    shared_map_tile<VAR_W, ROT, 2, OWN, 0, 256, 1>(c, ua, boxes, n_units, upb, zl, tx, ty, gridDim.x, dyn_box, half_dwords, tabw,
+    xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty);
+    shared_map_tile<VAR_W, ROT, 2, OWN, 0, 256, 1>(a, a.n_units, a.upb, zl, tx, ty, gridDim.x, dyn_box, a.half_dwords, tabw,
                                                    (glb_u32_ptr) nullptr);
 }
+#endif
 
 // ---- a pair (apply_lr) of an unrotated chain: a tile AND its mirror image about the equator per workgroup ----
 // Rows j and mirror_h - j of an unrotated equirectangular chain differ only in the sign of sin(lat): m, the radial
@@ -1640,7 +1666,7 @@ __device__ __forceinline__ TileBox load_tile_box(const TileBox* __restrict__ box
 
 // taps of both eyes of a lane's 4 pixels from the interleaved cells of box `b` (fixed-point rows `sy`), blend, store
 // into output row `j`
-__device__ __forceinline__ void sample_pair_cells(const UnitArgs& ua, const TileIds& t, int j, const TileBox& b, const uint32_t* boxw,
+__device__ __forceinline__ void sample_pair_cells(units_cptr U, const TileIds& t, int j, const TileBox& b, const uint32_t* boxw,
                                                   const int (&sx)[kPX], const int (&sy)[kPX])
 {
     typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
@@ -1665,38 +1691,43 @@ __device__ __forceinline__ void sample_pair_cells(const UnitArgs& ua, const Tile
             const BlendW w = blend_weights(sx[k], sy[k]);
             pix[k] = e == 0 ? blend3<4>(T0.alo[k], T0.ahi[k], T0.blo[k], T0.bhi[k], w) : blend3<4>(T1.alo[k], T1.ahi[k], T1.blo[k], T1.bhi[k], w);
         }
-        uint8_t* drow = ua.u[e].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[e].dst_pitch) + row_off);
-        store4(drow, pix, 0xFu, dst_rows_dword_aligned(ua, e));
+        uint8_t* drow = U[e].dst + (__umul24((uint32_t)j, (uint32_t)U[e].dst_pitch) + row_off);
+        store4(drow, pix, 0xFu, dst_rows_dword_aligned(U, e));
     }
 }
 
+#ifdef V1C_TUNING  // (the register-staged form: A/B partner, V1C_MIRROR_RAW=0, of the LDS-DMA kernels below)
 template <int VAR_W>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_ray_lin3_pair_mirror(
-    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
-    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_ray_lin3_pair_mirror(TileArgs a_)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // one pair of interleaved boxes: 2 x half_dwords
+    args_cref a = kernel_args();
     const int tid = threadIdx.x;
     if (blockIdx.z == 0) {  // the tiles the mirror path leaves out, through the general pair code
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin >= (unsigned)n_rest)
+        if (lin >= (unsigned)a.n_rest)
             return;
-        const uint32_t v = rest_list[lin];
-        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
-                                                  tabw, (glb_u32_ptr)c.itab);
+        const uint32_t v = a.rest_list[lin];
+        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, a.half_dwords,
+                                                  tabw, (glb_u32_ptr) nullptr);
         return;
     }
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    const TileBox* __restrict__ boxes = a.boxes;
+    const TileBox* __restrict__ mboxes = a.mboxes;
+    const int half_dwords = a.half_dwords, mirror_h = a.mirror_h;
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     int tx, ty;
-    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+    xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty);
     ty += 1;  // tile row 0 has no mirror image (row 0 <-> row mirror_h)
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
-    const uint8_t* __restrict__ src0 = ua.u[0].src;
-    const uint8_t* __restrict__ src1 = ua.u[1].src;
-    const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[1].src_pitch;
+    const uint8_t* __restrict__ src0 = U[0].src;
+    const uint8_t* __restrict__ src1 = U[1].src;
+    const uint32_t pitch0 = (uint32_t)U[0].src_pitch, pitch1 = (uint32_t)U[1].src_pitch;
     const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
     if (!mirror_static_ok(b, q, half_dwords, g.src_h, g.src_w))
         return;
@@ -1722,15 +1753,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     stage_load<false, false>(M, src1, pitch1, 0u, S1);
     LaneCoords L;
     if (mpoly)
-        lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, nullptr, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     else
-        lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
-    sample_pair_cells(ua, t, t.j, b, dyn_box, L.sx, L.sy);
+        lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, nullptr, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+    sample_pair_cells(U, t, t.j, b, dyn_box, L.sx, L.sy);
     __syncthreads();  // every wave has read its taps of the tile's box
     stage_store_pair(M, S0, S1, dyn_box);
     __syncthreads();
-    sample_pair_cells(ua, t, mirror_h - t.j, q, dyn_box, L.sx, L.sy2);
+    sample_pair_cells(U, t, mirror_h - t.j, q, dyn_box, L.sx, L.sy2);
 }
+#endif  // V1C_TUNING
 
 // ---- the same workgroup with the boxes brought in by LDS-DMA, as they are in memory ----
 // global_load_lds_dwordx4 copies 16 bytes per lane from any dword-aligned address straight into LDS (lane-linear: unit
@@ -1877,11 +1909,11 @@ __device__ __forceinline__ void gather_pair_raw(const TileBox& b, uint32_t raw, 
     }
 }
 
-__device__ __forceinline__ void store_pair_row(const UnitArgs& ua, const TileIds& t, int j, const uint32_t (&pix0)[kPX], const uint32_t (&pix1)[kPX])
+__device__ __forceinline__ void store_pair_row(units_cptr U, const TileIds& t, int j, const uint32_t (&pix0)[kPX], const uint32_t (&pix1)[kPX])
 {
     const uint32_t row_off = (uint32_t)t.x0 * 3u;
-    store4<1>(ua.u[0].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[0].dst_pitch) + row_off), pix0, 0xFu, dst_rows_dword_aligned(ua, 0));
-    store4<1>(ua.u[1].dst + (__umul24((uint32_t)j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix1, 0xFu, dst_rows_dword_aligned(ua, 1));
+    store4<1>(U[0].dst + (__umul24((uint32_t)j, (uint32_t)U[0].dst_pitch) + row_off), pix0, 0xFu, dst_rows_dword_aligned(U, 0));
+    store4<1>(U[1].dst + (__umul24((uint32_t)j, (uint32_t)U[1].dst_pitch) + row_off), pix1, 0xFu, dst_rows_dword_aligned(U, 1));
 }
 
 // NE = number of eyes (units) of the launch: 2 = apply_lr's pair; 1 = a single image (apply() of one image, BASELINE config 1):
@@ -1889,57 +1921,48 @@ __device__ __forceinline__ void store_pair_row(const UnitArgs& ua, const TileIds
 __device__ __forceinline__ void gather_one_raw(const TileBox& b, uint32_t raw, const int (&sx)[kPX], const int (&sy)[kPX], uint32_t (&pix)[kPX]);
 
 template <int VAR_W, int NE = 2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAVES, 8))) void k_ray_lin3_pair_mirror_raw(
-    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
-    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp,
-    unsigned rest_rows)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAVES, 8))) void k_ray_lin3_pair_mirror_raw(TileArgs a_)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
-#if V1C_RAW_RC_LDS
-    __shared__ __attribute__((aligned(16))) double rcw[2 * kTW + 3 * 16];  // column values [2][64] (sin, 1 - cos), row values [3][16]
-#endif
-    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 4 raw boxes (or the general code's cell buffers)
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 NE raw boxes (or the general code's cell buffers)
+    args_cref a = kernel_args();
     const int tid = threadIdx.x;
     // grid: first `rest_rows` rows of workgroups for the tiles this path leaves out (general pair code: they take longest, so
     // they are dispatched first -- dispatched last they were a tail: C1 0.0188 -> 0.0245 ms), then the rows of tile pairs
+    const unsigned rest_rows = a.rest_rows;
     if (blockIdx.y < rest_rows) {
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin >= (unsigned)n_rest)
+        if (lin >= (unsigned)a.n_rest)
             return;
-        const uint32_t v = rest_list[lin];
-        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, NE, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
-                                                  tabw, (glb_u32_ptr)c.itab);
+        const uint32_t v = a.rest_list[lin];
+        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, NE, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, a.half_dwords,
+                                                  tabw, (glb_u32_ptr) nullptr);
         return;
     }
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     int tx, ty;
-    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
+    xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
     // tile rows 0 .. TY / 2: row 0 of the image has no mirror image (its band row would be row H: not stored), row H / 2 is its
     // own (tile row TY / 2 and its band rewrite rows their neighbours write too -- with the same bytes)
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
     RowCol rc;
-#if !V1C_RAW_RC_LDS
     // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
     load_rowcol<0>(P, t.xc, t.jc, rc);
-#endif
-    const uint8_t* __restrict__ src0 = ua.u[0].src;
-    const uint8_t* __restrict__ src1 = ua.u[NE - 1].src;
-    const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[NE - 1].src_pitch;
-    const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
-    const int fit = mirror_raw_fit(b, q, nwp, g.src_h, g.src_w);
-    if (fit == 0 || (fit == 2 && (NE == 1 || !V1C_MIRROR_BIG)))
+    const TileBox b = load_tile_box(a.boxes, t.box_tile), q = load_tile_box(a.mboxes, t.box_tile);
+    const int nwp = a.kb;
+    if (mirror_raw_fit(b, q, nwp, g.src_h, g.src_w) != 1)
         return;
     const bool mpoly = (b.interior & 2) != 0;
-#if !V1C_RAW_RC_LDS
     // (the row / column values are consumed here: the compiler's own wait for them then sits in front of the DMA requests,
     // not -- as vmcnt(0), it does not count LDS-DMA -- in front of the coordinates)
 #pragma unroll
     for (int k = 0; k < kPX; k++)
         asm volatile("" ::"v"(rc.slon[k]), "v"(rc.qlon[k]));
     asm volatile("" ::"v"(rc.sl), "v"(rc.cl), "v"(rc.hl));
-#endif
     const uint32_t lds_tab = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)tabw;
     const uint32_t box_bytes = (uint32_t)nwp * 1024u;
     // (one image: two boxes -- half the LDS of a pair's workgroup, 7 workgroups per CU at 67 VGPRs)
@@ -1950,112 +1973,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
         const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
-#if V1C_RAW_RC_LDS
-    // The row / column table values of the tile by LDS-DMA too (1.4 KB per workgroup instead of 88 bytes per lane through the vector
-    // cache -- a third of the kernel's L1 accesses -- and no load the box requests would have to wait behind): wave 0 the 64 columns'
-    // sin / 1 - cos, waves 1-3 the 16 rows' sin, cos, 1 - cos.  One request per wave, in front of the boxes.
-    const uint32_t lds_rc = (uint32_t)(uintptr_t)(lds_u32_ptr)(const uint32_t*)rcw;
-    if (wave == 0) {
-        const double* ps = (lane < 32 ? P.col_s : P.col_h) + (tx * kTW + (lane & 31) * 2);
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)ps, (lds_void_ptr)(uintptr_t)lds_rc, 16, 0, 0);
-    } else if (lane < 8) {
-        const int ro = ty * 16 + lane * 2;
-        if (wave == 1)
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_s + ro), (lds_void_ptr)(uintptr_t)(lds_rc + 1024u), 16, 0, 0);
-        else if (wave == 2)
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_c + ro), (lds_void_ptr)(uintptr_t)(lds_rc + 1152u), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_h + ro), (lds_void_ptr)(uintptr_t)(lds_rc + 1280u), 16, 0, 0);
-    }
-#endif
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
     const uint32_t row_off = (uint32_t)t.x0 * 3u;
-    const int jm = mirror_h - t.j;             // the band's row
+    const int mirror_h = a.mirror_h;
+    const int jm = mirror_h - t.j;              // the band's row
     const bool band_row = jm < g.dst_h;         // (false for row 0 of the image only)
     LaneCoords L;
     uint32_t p0[kPX], p1[kPX];
-    if (NE == 2 && V1C_MIRROR_BIG && fit == 2) {
-        // boxes of up to two buffers: the eyes one after the other, each with the buffers of both (a rolled loop: the second code path
-        // must not cost the pair path registers); the coordinates serve both eyes
-#pragma unroll 1
-        for (int e = 0; e < 2; e++) {
-            const uint8_t* __restrict__ se = e ? src1 : src0;
-            const uint32_t pe = e ? pitch1 : pitch0;
-            if (e)  // every wave has sampled eye 0's boxes
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int nb = raw_box_dma(b, mb, se, pe, lane, wave, raw_b);
-            const int nq = raw_box_dma(q, mq, se, pe, lane, wave, raw_q);
-            if (e == 0) {
-                wait_vm_barrier(nb + nq);  // table slice
-#if V1C_RAW_RC_LDS
-    {
-        typedef const __attribute__((address_space(3))) double* lds_f64_ptr;
-        const lds_f64_ptr pr = (lds_f64_ptr)(uintptr_t)(lds_rc + 1024u + (uint32_t)(tid >> 4) * 8u);
-        rc.sl = pr[0], rc.cl = pr[16], rc.hl = pr[32];
-        const lds_f64_ptr pc = (lds_f64_ptr)(uintptr_t)(lds_rc + (uint32_t)(tid & 15) * (kPX * 8u));
-#pragma unroll
-        for (int k = 0; k < kPX; k++)
-            rc.slon[k] = pc[k], rc.qlon[k] = pc[kTW + k];
-    }
-#endif
-                if (mpoly)
-                    lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
-                else
-                    lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
-            }
-            wait_vm_barrier(nq);  // (behind the tile's box: the band's requests; eye 0's stores are older than both)
-            gather_one_raw(b, raw_b, L.sx, L.sy, p0);
-            wait_vm_barrier_imm<0>();
-            uint8_t* de = e ? ua.u[1].dst : ua.u[0].dst;
-            const uint32_t dp = (uint32_t)(e ? ua.u[1].dst_pitch : ua.u[0].dst_pitch);
-            const bool al = e ? dst_rows_dword_aligned(ua, 1) : dst_rows_dword_aligned(ua, 0);
-            store4<1>(de + (__umul24((uint32_t)t.j, dp) + row_off), p0, 0xFu, al);
-            gather_one_raw(q, raw_q, L.sx, L.sy2, p1);
-            if (band_row)
-                store4<1>(de + (__umul24((uint32_t)jm, dp) + row_off), p1, 0xFu, al);
-        }
-        return;
-    }
-    const int nb = raw_box_dma(b, mb, src0, pitch0, lane, wave, raw_b);  // this wave's requests per box of the tile ...
+    const int nb = raw_box_dma(b, mb, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, raw_b);  // this wave's requests per box of the tile ...
     if (NE == 2)
-        raw_box_dma(b, mb, src1, pitch1, lane, wave, raw_b + box_bytes);
-    const int nq = raw_box_dma(q, mq, src0, pitch0, lane, wave, raw_q);  // ... and of the mirrored band
+        raw_box_dma(b, mb, U[NE - 1].src, (uint32_t)U[NE - 1].src_pitch, lane, wave, raw_b + box_bytes);
+    const int nq = raw_box_dma(q, mq, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, raw_q);  // ... and of the mirrored band
     if (NE == 2)
-        raw_box_dma(q, mq, src1, pitch1, lane, wave, raw_q + box_bytes);
+        raw_box_dma(q, mq, U[NE - 1].src, (uint32_t)U[NE - 1].src_pitch, lane, wave, raw_q + box_bytes);
     // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
     // what the barrier publishes -- vmcnt counts in issue order -- then joins.
-    wait_vm_barrier(NE * (nb + nq));  // table slice (and row / column values) landed (this wave's box loads may still be in flight)
-#if V1C_RAW_RC_LDS
-    {
-        typedef const __attribute__((address_space(3))) double* lds_f64_ptr;
-        const lds_f64_ptr pr = (lds_f64_ptr)(uintptr_t)(lds_rc + 1024u + (uint32_t)(tid >> 4) * 8u);
-        rc.sl = pr[0], rc.cl = pr[16], rc.hl = pr[32];
-        const lds_f64_ptr pc = (lds_f64_ptr)(uintptr_t)(lds_rc + (uint32_t)(tid & 15) * (kPX * 8u));
-#pragma unroll
-        for (int k = 0; k < kPX; k++)
-            rc.slon[k] = pc[k], rc.qlon[k] = pc[kTW + k];
-    }
-#endif
+    wait_vm_barrier(NE * (nb + nq));  // table slice landed (this wave's box loads may still be in flight)
     if (mpoly)
-        lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, nullptr, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     else
-        lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, nullptr, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
     wait_vm_barrier(NE * nq);  // the tile's boxes
     if constexpr (NE == 2) {
         gather_pair_raw(b, raw_b, box_bytes, L.sx, L.sy, p0, p1);
         // the mirrored band's boxes: waited for BEFORE the tile's stores are issued (stores count in vmcnt too)
         wait_vm_barrier_imm<0>();
-        store_pair_row(ua, t, t.j, p0, p1);
+        store_pair_row(U, t, t.j, p0, p1);
         gather_pair_raw(q, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
         if (band_row)
-            store_pair_row(ua, t, jm, p0, p1);
+            store_pair_row(U, t, jm, p0, p1);
     } else {
         gather_one_raw(b, raw_b, L.sx, L.sy, p0);
         wait_vm_barrier_imm<0>();
-        store4<1>(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), p0, 0xFu, dst_rows_dword_aligned(ua, 0));
+        store4<1>(U[0].dst + (__umul24((uint32_t)t.j, (uint32_t)U[0].dst_pitch) + row_off), p0, 0xFu, dst_rows_dword_aligned(U, 0));
         gather_one_raw(q, raw_q, L.sx, L.sy2, p1);
         if (band_row)
-            store4<1>(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(ua, 0));
+            store4<1>(U[0].dst + (__umul24((uint32_t)jm, (uint32_t)U[0].dst_pitch) + row_off), p1, 0xFu, dst_rows_dword_aligned(U, 0));
     }
 }
 
@@ -2087,34 +2040,36 @@ __device__ __forceinline__ void gather_taps_raw(const uint32_t (&ta)[kPX], const
 // registers (74 against 68 VGPRs, 94 against 66 SGPRs) and LDS (its cell buffers) otherwise set the occupancy of a launch that never
 // runs it: 7 instead of 6 workgroups per CU
 template <int VAR_W, int REST = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_SEQ_WAVES : V1C_SEQ_WAVES + 1, 8))) void k_ray_lin3_pair_mirror_seq(
-    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
-    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int cap_kb,
-    unsigned rest_rows)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_SEQ_WAVES : V1C_SEQ_WAVES + 1, 8))) void k_ray_lin3_pair_mirror_seq(TileArgs a_)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
-    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 raw boxes of cap_kb KB (or the general code's cell buffers)
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 raw boxes of a.kb KB (or the general code's cell buffers)
+    args_cref a = kernel_args();
     const int tid = threadIdx.x;
+    const unsigned rest_rows = REST ? a.rest_rows : 0u;
     if constexpr (REST) {
         if (blockIdx.y < rest_rows) {
             const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-            if (lin >= (unsigned)n_rest)
+            if (lin >= (unsigned)a.n_rest)
                 return;
-            const uint32_t v = rest_list[lin];
-            shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
-                                                      half_dwords, tabw, (glb_u32_ptr)c.itab);
+            const uint32_t v = a.rest_list[lin];
+            shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
+                                                      a.half_dwords, tabw, (glb_u32_ptr) nullptr);
             return;
         }
     }
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     int tx, ty;
-    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
+    xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
     RowCol rc;
     load_rowcol<0>(P, t.xc, t.jc, rc);
-    const TileBox b = load_tile_box(boxes, t.box_tile), q = load_tile_box(mboxes, t.box_tile);
+    const TileBox b = load_tile_box(a.boxes, t.box_tile), q = load_tile_box(a.mboxes, t.box_tile);
+    const int cap_kb = a.kb;
     if (mirror_raw_fit(b, q, cap_kb, g.src_h, g.src_w) != 1)
         return;
     const bool mpoly = (b.interior & 2) != 0;
@@ -2131,8 +2086,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
-    const int nb = raw_box_dma(b, mb, ua.u[0].src, (uint32_t)ua.u[0].src_pitch, lane, wave, raw_b);
-    const int nq = raw_box_dma(q, mq, ua.u[0].src, (uint32_t)ua.u[0].src_pitch, lane, wave, raw_q);
+    const int nb = raw_box_dma(b, mb, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, raw_b);
+    const int nq = raw_box_dma(q, mq, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, raw_q);
     wait_vm_barrier(nb + nq);  // table slice
     const uint32_t pitch_b = (uint32_t)raw_units_per_row(b.cpr) * 16u, pitch_q = (uint32_t)raw_units_per_row(q.cpr) * 16u;
     uint32_t ta_b[kPX], ta_q[kPX];
@@ -2140,9 +2095,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
     {
         LaneCoords L;
         if (mpoly)
-            lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+            lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, nullptr, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
         else
-            lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
+            lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, nullptr, rc, kPX, (const double*)tabw, b.idx0, b.nidx, L);
 #pragma unroll
         for (int k = 0; k < kPX; k++) {
             const uint32_t ixb = (uint32_t)((L.sx[k] >> 5) - b.x0), ixq = (uint32_t)((L.sx[k] >> 5) - q.x0);
@@ -2153,212 +2108,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
         }
     }
     const uint32_t row_off = (uint32_t)t.x0 * 3u;
-    const int jm = mirror_h - t.j;
+    const int jm = a.mirror_h - t.j;
     const bool band_row = jm < g.dst_h;
     uint32_t pix[kPX];
     // ---- eye 0 ----
     wait_vm_barrier(nq);  // tile box
     gather_taps_raw(ta_b, W_b, pitch_b, pix);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // band box landed; every wave has sampled the tile box
-    raw_box_dma(b, mb, ua.u[1].src, (uint32_t)ua.u[1].src_pitch, lane, wave, raw_b);
-    store4<1>(ua.u[0].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 0));
+    raw_box_dma(b, mb, U[1].src, (uint32_t)U[1].src_pitch, lane, wave, raw_b);
+    store4<1>(U[0].dst + (__umul24((uint32_t)t.j, (uint32_t)U[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(U, 0));
     gather_taps_raw(ta_q, W_q, pitch_q, pix);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has sampled the band box
-    raw_box_dma(q, mq, ua.u[1].src, (uint32_t)ua.u[1].src_pitch, lane, wave, raw_q);
+    raw_box_dma(q, mq, U[1].src, (uint32_t)U[1].src_pitch, lane, wave, raw_q);
     if (band_row)
-        store4<1>(ua.u[0].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 0));
+        store4<1>(U[0].dst + (__umul24((uint32_t)jm, (uint32_t)U[0].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(U, 0));
     // ---- eye 1 (behind its tile box: eye 0's tile store and its band's nq requests; the predicated band store is not counted) ----
     wait_vm_barrier(nq + 1);
     gather_taps_raw(ta_b, W_b, pitch_b, pix);
     wait_vm_barrier_imm<0>();
-    store4<1>(ua.u[1].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 1));
+    store4<1>(U[1].dst + (__umul24((uint32_t)t.j, (uint32_t)U[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(U, 1));
     gather_taps_raw(ta_q, W_q, pitch_q, pix);
     if (band_row)
-        store4<1>(ua.u[1].dst + (__umul24((uint32_t)jm, (uint32_t)ua.u[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(ua, 1));
+        store4<1>(U[1].dst + (__umul24((uint32_t)jm, (uint32_t)U[1].dst_pitch) + row_off), pix, 0xFu, dst_rows_dword_aligned(U, 1));
 }
 
-// ---- two tile pairs per workgroup: the second pair's boxes are in flight while the first one is sampled ----
-// k_ray_lin3_pair_mirror_raw's workgroup is a serial chain: requests -> coordinates -> gather + stores; its loads are in flight only during
-// the first third of its life, and what keeps HBM busy meanwhile is the other five workgroups of the CU.  Here a workgroup serves
-// the tile pairs of TWO vertically adjacent tile rows (ty, ty + 1 and the bands that mirror them) with the SAME four box buffers:
-//   requests: tables (both pairs), boxes a (tile of pair 0), a' (its mirrored band)
-//   coordinates 0 | gather a | -> slots of a are free: request b (tile of pair 1) | store a | gather a' | -> request b' | store a'
-//   coordinates 1 | gather b | store b | gather b' | store b'
-// so b and b' fly behind the stores of pair 0 and the coordinates of pair 1 at no cost in LDS or registers (LDS-DMA needs
-// neither staging registers nor a second set of buffers), the prologue (kernel arguments, tile boxes, XCD mapping) is paid once
-// per two pairs, and the row / column table values come through LDS (one 16-byte DMA unit per 2 columns / rows of the
-// workgroup instead of 88 bytes per lane from the vector cache: the column values serve both pairs).
-// The last `gridDim.y - rest_rows - rows2` rows of workgroups serve ONE tile row each: short workgroups at the end of the
-// dispatch order halve the launch's tail.  vmcnt bookkeeping as in k_ray_lin3_pair_mirror_raw; stores are counted as
-// kStoresPerPairRow requests per store_pair_row (tests/test_vmcnt_protocol.py checks the disassembly for exactly that).
-#ifndef V1C_PIPE_WAVES
-#define V1C_PIPE_WAVES 5  // waves per SIMD k_ray_lin3_pair_mirror_pipe is compiled for (at least)
-#endif
-constexpr int kStoresPerPairRow = 2;  // store_pair_row: one global_store_dwordx3 per eye (a LOWER bound is what the waits need)
-constexpr int kPipeColBytes = 2 * kTW * 8, kPipeRowBytes = 3 * 32 * 8;  // column values (sin, 1 - cos) of 64 columns; row values (sin, cos, 1 - cos) of 32 rows
-
-// s_waitcnt vmcnt(n) lgkmcnt(0) + s_barrier: as wait_vm_barrier, and this wave's LDS reads have returned (the barrier hands the
-// buffers they read to the next DMA requests)
-__device__ __forceinline__ void wait_vm_lgkm_barrier(int n)
-{
-    V1C_WAIT_JUMP(" lgkmcnt(0)");
-}
-
-// the lane's row / column values from the workgroup's LDS copy (`rows` = [3][32] doubles: sin, cos, 1 - cos of the latitude of the
-// rows of both tile rows; `cols` = [2][64]: sin, 1 - cos of the longitude of the tile's columns)
-__device__ __forceinline__ void rowcol_from_lds(uint32_t lds_cols, uint32_t lds_rows, int lx, int row, RowCol& rc)
-{
-    typedef const __attribute__((address_space(3))) double* lds_f64_ptr;
-    const lds_f64_ptr pr = (lds_f64_ptr)(uintptr_t)(lds_rows + (uint32_t)row * 8u);
-    rc.sl = pr[0], rc.cl = pr[32], rc.hl = pr[64];
-    const lds_f64_ptr pc = (lds_f64_ptr)(uintptr_t)(lds_cols + (uint32_t)lx * (kPX * 8u));
-#pragma unroll
-    for (int k = 0; k < kPX; k++)
-        rc.slon[k] = pc[k], rc.qlon[k] = pc[kTW + k];
-}
-
-template <int VAR_W>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_PIPE_WAVES, 8))) void k_ray_lin3_pair_mirror_pipe(
-    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, const TileBox* __restrict__ mboxes, int half_dwords, int mirror_h,
-    unsigned tiles_x_magic, const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp,
-    unsigned rest_rows, unsigned rows2, unsigned tab_off, unsigned cols_off, unsigned tab_rest_off)
-{
-    constexpr int NT = 256;
-    // dynamic LDS: 4 box buffers of nwp KB | tab_off: the table slices of both pairs | cols_off: column values | row values
-    // (the general pair code of the rest rows: its cell buffers at 0, its table slice at tab_rest_off)
-    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-    const int tid = threadIdx.x;
-    if (blockIdx.y < rest_rows) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin >= (unsigned)n_rest)
-            return;
-        const uint32_t v = rest_list[lin];
-        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(c, ua, boxes, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, half_dwords,
-                                                  (double*)((uint8_t*)dyn_box + tab_rest_off), (glb_u32_ptr)c.itab);
-        return;
-    }
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
-    int tx, gy;
-    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, gy, gridDim.y - rest_rows, rest_rows);
-    // group row gy: the first rows2 serve tile rows 1 + 2 gy and 2 + 2 gy, the others one tile row each
-    const bool two = (unsigned)gy < rows2;
-    const int ty0 = two ? 1 + 2 * gy : 1 + (int)rows2 + gy;
-    const int tile0 = ty0 * (int)gridDim.x + tx;
-    const TileBox bA = load_tile_box(boxes, tile0), qA = load_tile_box(mboxes, tile0);
-    int tile1 = tile0 + (two ? (int)gridDim.x : 0);
-    const TileBox bB = load_tile_box(boxes, tile1), qB = load_tile_box(mboxes, tile1);
-    const bool okA = mirror_raw_static_ok(bA, qA, nwp, g.src_h, g.src_w);
-    const bool okB = two && mirror_raw_static_ok(bB, qB, nwp, g.src_h, g.src_w);
-    if (!okA && !okB)
-        return;
-    // pair 0 = the first eligible one, pair 1 = tile row ty0 + 1 when both are
-    const TileBox b0 = okA ? bA : bB, q0 = okA ? qA : qB;
-    const int jo0 = okA ? 0 : 16;      // rows of pair 0 relative to ty0 * 16
-    const bool second = okA && okB;
-    const int nidx1 = bB.nidx, idx01 = bB.idx0;
-    const bool mpoly1 = (bB.interior & 2) != 0;
-    // (the boxes of pair 1 are loaded again where they are used: 16 scalar registers that would otherwise live through pair 0)
-    asm volatile("" : "+s"(tile1));
-    const int lx = tid & (kLanesX - 1), ly = tid >> 4;
-    const int x0 = (tx * kLanesX + lx) * kPX, jbase = ty0 * 16 + ly;
-    TileIds t;  // (store_pair_row reads x0 only)
-    t.x0 = x0;
-    const uint8_t* __restrict__ src0 = ua.u[0].src;
-    const uint8_t* __restrict__ src1 = ua.u[1].src;
-    const uint32_t pitch0 = (uint32_t)ua.u[0].src_pitch, pitch1 = (uint32_t)ua.u[1].src_pitch;
-    const bool mpoly0 = (b0.interior & 2) != 0;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box;
-    const uint32_t box_bytes = (uint32_t)nwp * 1024u;
-    const uint32_t raw_b = lds0, raw_q = lds0 + 2u * box_bytes;
-    const uint32_t lds_tab0 = lds0 + tab_off, lds_tab1 = lds_tab0 + (uint32_t)b0.nidx * (kRadialCoefs * 8u);
-    const uint32_t lds_cols = lds0 + cols_off, lds_rows = lds_cols + kPipeColBytes;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    // ---- requests of the prologue: table slices (every wave: 16 entries each), column values (wave 0), row values (waves 1-3) ----
-    {
-        const uint8_t* gp = (const uint8_t*)((mpoly0 ? P.radial_m : P.radial) + (size_t)b0.idx0 * kRadialCoefs) + (uint32_t)tid * 16u;
-        if (tid < b0.nidx * 4)
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab0 + (uint32_t)wave * 1024u), 16, 0, 0);
-    }
-    if (second) {
-        const uint8_t* gp = (const uint8_t*)((mpoly1 ? P.radial_m : P.radial) + (size_t)idx01 * kRadialCoefs) + (uint32_t)tid * 16u;
-        if (tid < nidx1 * 4)
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab1 + (uint32_t)wave * 1024u), 16, 0, 0);
-    }
-    if (wave == 0) {
-        const double* ps = (lane < 32 ? P.col_s : P.col_h) + (tx * kTW + (lane & 31) * 2);
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)ps, (lds_void_ptr)(uintptr_t)lds_cols, 16, 0, 0);
-    } else if (lane < 16) {  // (three code paths: a pointer selected by the wave index ends up as an indexed array in scratch)
-        const int ro = ty0 * 16 + lane * 2;
-        if (wave == 1)
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_s + ro), (lds_void_ptr)(uintptr_t)lds_rows, 16, 0, 0);
-        else if (wave == 2)
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_c + ro), (lds_void_ptr)(uintptr_t)(lds_rows + 256u), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(P.row_h + ro), (lds_void_ptr)(uintptr_t)(lds_rows + 512u), 16, 0, 0);
-    }
-    // ---- boxes of pair 0 ----
-    const RawLanes mb0 = raw_lanes(b0.cpr, lane), mq0 = raw_lanes(q0.cpr, lane);
-    const int na = raw_box_dma(b0, mb0, src0, pitch0, lane, wave, raw_b);
-    raw_box_dma(b0, mb0, src1, pitch1, lane, wave, raw_b + box_bytes);
-    const int nm = raw_box_dma(q0, mq0, src0, pitch0, lane, wave, raw_q);
-    raw_box_dma(q0, mq0, src1, pitch1, lane, wave, raw_q + box_bytes);
-    wait_vm_barrier(2 * na + 2 * nm);  // tables, row / column values landed (the box requests behind them may be in flight)
-    LaneCoords L;
-    {
-        RowCol rc;
-        rowcol_from_lds(lds_cols, lds_rows, lx, jo0 + ly, rc);
-        const double* tab = (const double*)((const uint8_t*)dyn_box + tab_off);
-        if (mpoly0)
-            lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, tab, b0.idx0, b0.nidx, L);
-        else
-            lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, tab, b0.idx0, b0.nidx, L);
-    }
-    wait_vm_barrier(2 * nm);  // the tile's two boxes
-    uint32_t p0[kPX], p1[kPX];
-    const TileBox b1 = load_tile_box(boxes, tile1);
-    gather_pair_raw(b0, raw_b, box_bytes, L.sx, L.sy, p0, p1);
-    // the mirrored band's boxes (waited for before the tile's stores are issued: stores count in vmcnt too); every wave has
-    // read its taps of the tile's boxes: their buffers take the tile of pair 1
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    int nb = 0;
-    if (second) {
-        const RawLanes mb1 = raw_lanes(b1.cpr, lane);
-        nb = raw_box_dma(b1, mb1, src0, pitch0, lane, wave, raw_b);
-        raw_box_dma(b1, mb1, src1, pitch1, lane, wave, raw_b + box_bytes);
-    }
-    const int j0 = jbase + jo0;
-    store_pair_row(ua, t, j0, p0, p1);
-    const TileBox q1 = load_tile_box(mboxes, tile1);
-    gather_pair_raw(q0, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
-    if (!second) {
-        store_pair_row(ua, t, mirror_h - j0, p0, p1);
-        return;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the band's buffers take the band of pair 1
-    const RawLanes mq1 = raw_lanes(q1.cpr, lane);
-    const int nq = raw_box_dma(q1, mq1, src0, pitch0, lane, wave, raw_q);
-    raw_box_dma(q1, mq1, src1, pitch1, lane, wave, raw_q + box_bytes);
-    store_pair_row(ua, t, mirror_h - j0, p0, p1);
-    {
-        RowCol rc;
-        rowcol_from_lds(lds_cols, lds_rows, lx, 16 + ly, rc);
-        const double* tab = (const double*)((const uint8_t*)dyn_box + tab_off) + (size_t)b0.nidx * kRadialCoefs;
-        if (mpoly1)
-            lane_coords<VAR_W, 0, 2, 0, 1, 1, 1>(c, ua, 0, rc, kPX, tab, idx01, nidx1, L);
-        else
-            lane_coords<VAR_W, 0, 2, 0, 1, 0, 1>(c, ua, 0, rc, kPX, tab, idx01, nidx1, L);
-    }
-    // behind the boxes of tile 1: store a, the band's 2 nq requests, store a'
-    wait_vm_barrier(2 * nq + 2 * kStoresPerPairRow);
-    gather_pair_raw(b1, raw_b, box_bytes, L.sx, L.sy, p0, p1);
-    wait_vm_barrier_imm<kStoresPerPairRow>();  // behind the band's boxes: store a'
-    const int j1 = jbase + 16;
-    store_pair_row(ua, t, j1, p0, p1);
-    gather_pair_raw(q1, raw_q, box_bytes, L.sx, L.sy2, p0, p1);
-    store_pair_row(ua, t, mirror_h - j1, p0, p1);
-    (void)nb;
-}
+// (Round 3 also built k_ray_lin3_pair_mirror_pipe here -- two tile rows per workgroup, the second pair's boxes requested into the
+// buffers the first pair had just been sampled from -- bit-exact and 5 % slower than one pair per workgroup at equal occupancy
+// (profiles/r03a_mid): "the workgroups do not wait for their boxes".  Removed in round 4 with its A/B switch.)
 
 // ---- batches (units sharing one map) with the boxes by LDS-DMA: k_ray_lin3_batch_lean's loop on raw boxes ----
 // V1C_LEAN_RING box buffers of nwp KB in a ring: unit u is sampled from its buffer while the boxes of the next ring - 1 units
@@ -2372,38 +2148,40 @@ __host__ __device__ inline bool lean_raw_static_ok(const TileBox& b, int nwp, in
 }
 
 template <int VAR_W, int ROT, int OWN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean_raw(
-    KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes, int n_units, int upb, int half_dwords, unsigned tiles_x_magic,
-    const uint32_t* __restrict__ rest_list, int n_rest, unsigned strip_len, unsigned strip_magic, int nwp)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean_raw(TileArgs a_)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
+    args_cref a = kernel_args();
     const int tid = threadIdx.x;
     int zl = (int)blockIdx.z;
-    if (rest_list != nullptr)
-        zl -= 1;  // slice 0: the tiles this path leaves out (as in k_ray_lin3_batch_lean)
+    if (a.rest_list != nullptr)
+        zl -= 1;  // slice 0: the tiles this path leaves out, two units per workgroup through the pair code
     if (zl < 0) {
-        const unsigned pairs = (unsigned)(n_units + 1) / 2u;
+        const unsigned pairs = (unsigned)(a.n_units + 1) / 2u;
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin >= (unsigned)n_rest * pairs)
+        if (lin >= (unsigned)a.n_rest * pairs)
             return;
         const unsigned ti = lin / pairs, zg = lin - ti * pairs;
-        const uint32_t v = rest_list[ti];
-        shared_map_tile<VAR_W, ROT, 2, OWN, 1, NT, 0>(c, ua, boxes, n_units, 2, (int)zg, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
-                                                      half_dwords, tabw, (glb_u32_ptr)c.itab);
+        const uint32_t v = a.rest_list[ti];
+        shared_map_tile<VAR_W, ROT, 2, OWN, 1, NT, 0>(a, a.n_units, 2, (int)zg, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
+                                                      a.half_dwords, tabw, (glb_u32_ptr) nullptr);
         return;
     }
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     int tx, ty;
-    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+    xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty);
+    const int upb = a.upb, nwp = a.kb;
     const int z0 = zl * upb;
     const TileIds t = tile_ids(g, z0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
-    const int nu = min(upb, n_units - z0);
+    const int nu = min(upb, a.n_units - z0);
     RowCol rc;
     load_rowcol<ROT>(P, t.xc, t.jc, rc);
-    const TileBox b = load_tile_box(boxes, t.box_tile);
+    const TileBox b = load_tile_box(a.boxes, t.box_tile);
     if (!lean_raw_static_ok(b, nwp, g.src_h, g.src_w))
         return;
     const bool mpoly = OWN == 0 && (b.interior & 2) != 0;
@@ -2429,7 +2207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     for (int i = 0; i < R; i++) {
         done_at[i] = 0;
         if (i < nu) {
-            issued += raw_box_dma(b, ml, ua.u[z0 + i].src, (uint32_t)ua.u[z0 + i].src_pitch, lane, wave, raw0 + (uint32_t)i * box_bytes);
+            issued += raw_box_dma(b, ml, U[z0 + i].src, (uint32_t)U[z0 + i].src_pitch, lane, wave, raw0 + (uint32_t)i * box_bytes);
             done_at[i] = issued;
         }
     }
@@ -2440,9 +2218,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     {
         LaneCoords L;
         if (OWN == 0 && mpoly)
-            lane_coords<VAR_W, ROT, 2, 0, 1, 1>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+            lane_coords<VAR_W, ROT, 2, 0, 1, 1>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
         else
-            lane_coords<VAR_W, ROT, 2, OWN, 1, 0>(c, ua, z0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+            lane_coords<VAR_W, ROT, 2, OWN, 1, 0>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
 #pragma unroll
         for (int k = 0; k < kPX; k++) {
             const uint32_t ix = (uint32_t)((L.sx[k] >> 5) - b.x0);
@@ -2462,7 +2240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
         if (u >= 1 && u - 1 + R < nu) {
             const int z = z0 + u - 1 + R;
             const uint32_t prev = cur == 0 ? (uint32_t)(R - 1) * box_bytes : cur - box_bytes;
-            issued += raw_box_dma(b, ml, ua.u[z].src, (uint32_t)ua.u[z].src_pitch, lane, wave, raw0 + prev);
+            issued += raw_box_dma(b, ml, U[z].src, (uint32_t)U[z].src_pitch, lane, wave, raw0 + prev);
 #pragma unroll
             for (int i = 0; i < R; i++)
                 done_at[i] = (slot == 0 ? R - 1 : slot - 1) == i ? issued : done_at[i];
@@ -2477,7 +2255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
             pix[k] = blend3<3>(__builtin_amdgcn_alignbyte(a1, a0, a), __builtin_amdgcn_alignbyte(a2, a1, a), __builtin_amdgcn_alignbyte(b1, b0, a),
                                __builtin_amdgcn_alignbyte(b2, b1, a), W[k]);
         }
-        store_interior(ua, z0 + u, t, pix);
+        store_interior(U, z0 + u, t, pix);
         issued += 1;  // the unit's store (at least one instruction; more only make the next wait longer than needed)
         cur = cur == (uint32_t)(R - 1) * box_bytes ? 0u : cur + box_bytes;
         slot = slot == R - 1 ? 0 : slot + 1;
@@ -2495,11 +2273,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
 // table), full tiles whose box lies inside the source and fits a buffer; every other (unit, tile) goes through rot_unit_tile.
 // Waits: a box is followed by at least the other unit's requests / by the first unit's store (lower bounds: loads the
 // coordinates make in between only make a wait longer).
-#ifndef V1C_ROTPAIR_SEPARABLE
-#define V1C_ROTPAIR_SEPARABLE 0  // 1 (A/B builds): k_ray_lin3_rot_pair_raw takes per-column vectors of the rotated ray through LDS instead of rotating every
-                                 // ray in its lane: 17 instead of 33 fp64 operations per lane and unit, bit-exact, and 18 % SLOWER (C5 3.03 against 2.565 ms,
-                                 // profiles/r03b_final/ab_rot_separable.log): a serial load -> compute -> barrier prologue and 12 LDS reads per lane and unit
-#endif
+// (The separable form of the rotated ray -- per-column vectors T_k = R_k0 sin(lon) + R_k2 cos(lon) through LDS, 17 instead of 33 fp64
+// operations per lane and unit -- was built in round 3, bit-exact and 18 % slower (profiles/r03b_final/ab_rot_separable.log: a serial
+// load -> compute -> barrier prologue and 12 LDS reads per lane and unit); removed in round 4.)
 #ifndef V1C_ROTPAIR_WAVES
 #define V1C_ROTPAIR_WAVES 5
 #endif
@@ -2561,29 +2337,32 @@ __device__ __forceinline__ void gather_one_raw(const TileBox& b, uint32_t raw, c
 // NC = 1: the host has bounded every pixel's fixed-point coordinates inside the cvRound trick's range (launch_ray_lin3_tile's
 // `coords_bounded`): the speculative coordinates need no clamps (2 v_med3_f32 per pixel of a launch that is bound by vector issue)
 template <int VAR_W, int MP, int NC = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR_WAVES, 8))) void k_ray_lin3_rot_pair_raw(
-    KernelCtx c, UnitArgs ua, int n_units, int slot_bytes, unsigned tiles_x_magic, unsigned strip_len, unsigned strip_magic)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR_WAVES, 8))) void k_ray_lin3_rot_pair_raw(TileArgs a_)
 {
     constexpr int NT = 256;
     // dynamic LDS: two box buffers of slot_bytes (rot_unit_tile: its BGRx box of kBoxBytes + 16) | kRotPairRedInts ints
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
+    args_cref a = kernel_args();
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     const int tid = threadIdx.x;
     int btx = blockIdx.x, bty = blockIdx.y;
-    if (strip_len)
-        xcd_tile(tiles_x_magic, strip_len, strip_magic, btx, bty);
+    if (a.strip_len)
+        xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, btx, bty);
     const int zA = 2 * (int)blockIdx.z, zB = zA + 1;
-    const bool hasB = zB < n_units;
+    const bool hasB = zB < a.n_units;
+    const int slot_bytes = a.kb;
     const uint32_t red_off = (uint32_t)max(2 * slot_bytes, kBoxBytes + 16);
     int* red = (int*)((uint8_t*)dyn_box + red_off);
-    const glb_u32_ptr wtab = (glb_u32_ptr)c.itab;
+    const glb_u32_ptr wtab = (glb_u32_ptr) nullptr;  // (bilinear: no weight table)
     const bool tile_full = ((btx + 1) * kTW <= g.dst_w) & ((bty + 1) * (NT / kLanesX) <= g.dst_h);
     if (!tile_full) {
-        rot_unit_tile<VAR_W, 1, 2, 0, MP>(c, ua, zA, btx, bty, red, dyn_box, wtab);
+        rot_unit_tile<VAR_W, 1, 2, 0, MP>(a, zA, btx, bty, red, dyn_box, wtab);
         if (hasB) {
             __syncthreads();
-            rot_unit_tile<VAR_W, 1, 2, 0, MP>(c, ua, zB, btx, bty, red, dyn_box, wtab);
+            rot_unit_tile<VAR_W, 1, 2, 0, MP>(a, zB, btx, bty, red, dyn_box, wtab);
         }
         return;
     }
@@ -2591,36 +2370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box;
     RowCol rc;
-#if V1C_ROTPAIR_SEPARABLE
-    // The rotated ray in its separable form: per tile column and unit T_k = R_k0 sin(lon) + R_k2 cos(lon) (k = 0, 1, 2), computed once
-    // by wave 0 (unit A) and wave 1 (unit B) -- a lane per column -- and handed over through LDS; a pixel then costs 3 FMAs
-    // (v'_k = cos(lat) T_k + sin(lat) R_k1) instead of 6, a lane-unit 17 fp64 operations for the ray instead of 33, and the lanes load
-    // 2 row values instead of 2 + 8 row / column values each.
-    double* colT = (double*)((uint8_t*)dyn_box + red_off + kRotPairRedInts * sizeof(int));  // [2 units][3][64 columns]
-    rc.sl = P.row_s[t.jc], rc.cl = P.row_c[t.jc], rc.hl = 0.0;
-    if (wave == 0 || (wave == 1 && hasB)) {
-        const int z = wave ? zB : zA;
-        const double sc = P.col_s[btx * kTW + lane], cc = P.col_c[btx * kTW + lane];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double r0 = ua.u[z].has_rot ? ua.u[z].rot[3 * k] : P.rot[3 * k];
-            const double r2 = ua.u[z].has_rot ? ua.u[z].rot[3 * k + 2] : P.rot[3 * k + 2];
-            colT[(wave * 3 + k) * kTW + lane] = fma(r0, sc, r2 * cc);
-        }
-    }
-    __syncthreads();  // (nothing is in flight yet)
-    auto unit_cols = [&](int unit) {
-        const double* p = colT + unit * 3 * kTW + (tid & 15) * kPX;
-#pragma unroll
-        for (int k = 0; k < kPX; k++)
-            rc.slon[k] = p[k], rc.qlon[k] = p[kTW + k], rc.tlon[k] = p[2 * kTW + k];
-    };
-    constexpr int RM = 2;
-#else
     load_rowcol<1>(P, t.xc, t.jc, rc);
-    auto unit_cols = [&](int) {};
-    constexpr int RM = 1;
-#endif
     // box of all 1024 pixels of a unit -> is the tile interior, does its raw box fit a buffer
     auto raw_box = [&](const BoxAll& ba, int z, TileBox& b) -> bool {
         b.x0 = ba.xmin & ~3, b.y0 = ba.ymin;
@@ -2628,7 +2378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
         b.idx0 = b.nidx = 0, b.interior = 1, b.magic = 0;
         const int upr = raw_units_per_row(b.cpr);
         const bool inside = (ba.xmin >= 0) & (ba.xmax < g.src_w - 2) & (ba.ymin >= 0) & (ba.ymax < g.src_h - 1);
-        const bool aligned = ((((uintptr_t)ua.u[z].src) | (uintptr_t)ua.u[z].src_pitch) & 3u) == 0;
+        const bool aligned = ((((uintptr_t)U[z].src) | (uintptr_t)U[z].src_pitch) & 3u) == 0;
         return inside & aligned & (b.cpr <= kMaxCpr) & (b.nrows * upr * 16 <= slot_bytes) &
                !((b.y0 + b.nrows >= g.src_h) & (b.x0 * 3 + upr * 16 > g.src_w * 3));
     };
@@ -2636,45 +2386,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     TileBox bA, bB;
     bool fastA, fastB = false;
     int nB = 0;
-    unit_cols(0);
-    lane_coords<VAR_W, RM, 2, 0, (NC ? 1 : 2), MP>(c, ua, zA, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LA);
+    lane_coords<VAR_W, 1, 2, 0, (NC ? 1 : 2), MP>(c, U[zA].rot, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LA);
     fastA = raw_box(reduce_box_all_nofence<NT / 64>(LA, red, tid), zA, bA);
     if (fastA) {
         const RawLanes m = raw_lanes(bA.cpr, lane);
-        raw_box_dma(bA, m, ua.u[zA].src, (uint32_t)ua.u[zA].src_pitch, lane, wave, lds0);
+        raw_box_dma(bA, m, U[zA].src, (uint32_t)U[zA].src_pitch, lane, wave, lds0);
     }
     if (hasB) {
-        // (unit B's kernel arguments -- 18 scalar registers of rotation matrix alone -- are loaded here, not hoisted in front of
-        // unit A's coordinates: the kernel is at the scalar register limit)
-        int zb = zB;
-        asm volatile("" : "+s"(zb));
-        unit_cols(1);
-        lane_coords<VAR_W, RM, 2, 0, (NC ? 1 : 2), MP>(c, ua, zb, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
+        lane_coords<VAR_W, 1, 2, 0, (NC ? 1 : 2), MP>(c, U[zB].rot, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
         fastB = raw_box(reduce_box_all_nofence<NT / 64>(LB, red + 16, tid), zB, bB);
         if (fastB) {
             const RawLanes m = raw_lanes(bB.cpr, lane);
-            nB = raw_box_dma(bB, m, ua.u[zB].src, (uint32_t)ua.u[zB].src_pitch, lane, wave, lds0 + (uint32_t)slot_bytes);
+            nB = raw_box_dma(bB, m, U[zB].src, (uint32_t)U[zB].src_pitch, lane, wave, lds0 + (uint32_t)slot_bytes);
         }
     }
     uint32_t pix[kPX];
     if (fastA) {
         wait_vm_barrier(nB);  // A's box: behind it at least B's requests
         gather_one_raw(bA, lds0, LA.sx, LA.sy, pix);
-        store_interior(ua, zA, t, pix);
+        store_interior(U, zA, t, pix);
     }
     if (fastB) {
         wait_vm_barrier(fastA ? 1 : 0);  // B's box: behind it at least A's store
         gather_one_raw(bB, lds0 + (uint32_t)slot_bytes, LB.sx, LB.sy, pix);
-        store_interior(ua, zB, t, pix);
+        store_interior(U, zB, t, pix);
     }
     // the rest (rare: rays leaving the source, boxes beyond a buffer): one unit at a time through the general code
     if (!fastA) {
         __syncthreads();
-        rot_unit_tile<VAR_W, 1, 2, 0, MP>(c, ua, zA, btx, bty, red, dyn_box, wtab);
+        rot_unit_tile<VAR_W, 1, 2, 0, MP>(a, zA, btx, bty, red, dyn_box, wtab);
     }
     if (hasB && !fastB) {
         __syncthreads();
-        rot_unit_tile<VAR_W, 1, 2, 0, MP>(c, ua, zB, btx, bty, red, dyn_box, wtab);
+        rot_unit_tile<VAR_W, 1, 2, 0, MP>(a, zB, btx, bty, red, dyn_box, wtab);
     }
 }
 
@@ -2755,21 +2499,23 @@ __device__ __forceinline__ void store_cn(uint8_t* drow, const uint32_t (&pix)[kP
 }
 
 template <int VAR_W, int ROT, int CN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_ray_lin_cn(KernelCtx c, UnitArgs ua, const TileBox* __restrict__ boxes,
-                                                                                                 int n_units, unsigned tiles_x_magic,
-                                                                                                 unsigned strip_len, unsigned strip_magic, int kb)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_ray_lin_cn(TileArgs a_)
 {
     constexpr int K = 2;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // two box buffers of kb KB (+ 16 bytes: the gather's third dword)
-    const Geom& g = c.g;
-    const RayParams& P = c.ray;
+    args_cref a = kernel_args();
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     const int tid = threadIdx.x;
+    const int n_units = a.n_units, kb = a.kb;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int tx, ty;
-    xcd_tile(tiles_x_magic, strip_len, strip_magic, tx, ty);
+    xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty);
     const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, 16);
-    const TileBox b = load_tile_box(boxes, t.box_tile);
+    const TileBox b = load_tile_box(a.boxes, t.box_tile);
     const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
     const bool mpoly = (b.interior & 2) != 0;
     typedef double __attribute__((ext_vector_type(2))) d2;
@@ -2787,17 +2533,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const RawLanes m = raw_lanes_upr(max(upr, 1), lane);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, buf_bytes = (uint32_t)kb * 1024u;
     if (fits)  // the first unit's box flies behind the coordinates
-        raw_box_dma<CN>(b, m, ua.u[0].src, (uint32_t)ua.u[0].src_pitch, lane, wave, lds0);
+        raw_box_dma<CN>(b, m, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, lds0);
     const bool interior = tab_lds & (b.interior != 0);
     LaneCoords L;
     if (interior && mpoly)
-        lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, 0>(c, ua, 0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, 0>(c, U[0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (interior)
-        lane_coords<VAR_W, ROT, K, 0, 1, 0, 0, 0>(c, ua, 0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, 0, 1, 0, 0, 0>(c, U[0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else if (tab_lds)
-        lane_coords<VAR_W, ROT, K, 0, 0, 0, 0, 0>(c, ua, 0, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, 0, 0, 0, 0, 0>(c, U[0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
     else
-        lane_coords<VAR_W, ROT, K, 0, 0, 0, 0, 0>(c, ua, 0, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, 0, 0, 0, 0, 0>(c, U[0].rot, rc, t.npx, P.radial, 0, P.n_int, L);
     const bool incomplete = L.ok != (1u << t.npx) - 1;
     const uint32_t lpitch = (uint32_t)upr * 16u;
     uint32_t ta[kPX];
@@ -2810,14 +2556,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     for (int u = 0; u < n_units; u++) {
         if (incomplete)
-            c.tile_flags[t.flag_tile + u * t.flag_stride] = 1;
+            if (uint32_t* flags = a.tile_flags)
+                flags[t.flag_tile + u * t.flag_stride] = 1;
         uint32_t pix[kPX] = {0u, 0u, 0u, 0u};
         unsigned done = 0;
         if (fits) {
             // unit u's box has landed in every wave's share, and every wave is done reading unit u - 1's buffer
             wait_vm_barrier_imm<0>();
             if (u + 1 < n_units)
-                raw_box_dma<CN>(b, m, ua.u[u + 1].src, (uint32_t)ua.u[u + 1].src_pitch, lane, wave, lds0 + (uint32_t)((u + 1) & 1) * buf_bytes);
+                raw_box_dma<CN>(b, m, U[u + 1].src, (uint32_t)U[u + 1].src_pitch, lane, wave, lds0 + (uint32_t)((u + 1) & 1) * buf_bytes);
             const uint32_t base = lds0 + (uint32_t)(u & 1) * buf_bytes;
             uint32_t tb[kPX];
 #pragma unroll
@@ -2829,14 +2576,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const unsigned slow = L.ok & ~done;
         unsigned skip = 0;  // BORDER_TRANSPARENT: the destination keeps its bytes
         if (slow) {
-            const Image im{ua.u[u].src, ua.u[u].src_pitch, g.src_h, g.src_w};
+            const Image im{U[u].src, U[u].src_pitch, g.src_h, g.src_w};
+            const Geom gg = geom_copy(g);
 #pragma unroll 1
             for (int k = 0; k < kPX; k++) {
                 if (slow & (1u << k)) {
                     const int fsx = k == 0 ? L.sx[0] : k == 1 ? L.sx[1] : k == 2 ? L.sx[2] : L.sx[3];
                     const int fsy = k == 0 ? L.sy[0] : k == 1 ? L.sy[1] : k == 2 ? L.sy[2] : L.sy[3];
                     uint8_t px[4] = {0, 0, 0, 0};
-                    const bool st = sample_linear_t<CN>(im, g, taps_from_fixed(fsx, fsy), px);
+                    const bool st = sample_linear_t<CN>(im, gg, taps_from_fixed(fsx, fsy), px);
                     const uint32_t r = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
                     skip |= (st ? 0u : 1u) << k;
 #pragma unroll
@@ -2846,10 +2594,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
         }
         if (t.active) {
-            uint8_t* drow = ua.u[u].dst + (__umul24((uint32_t)t.j, (uint32_t)ua.u[u].dst_pitch) + (uint32_t)t.x0 * (uint32_t)CN);
-            store_cn<CN>(drow, pix, L.ok & ~skip, dst_rows_dword_aligned(ua, u));
+            uint8_t* drow = U[u].dst + (__umul24((uint32_t)t.j, (uint32_t)U[u].dst_pitch) + (uint32_t)t.x0 * (uint32_t)CN);
+            store_cn<CN>(drow, pix, L.ok & ~skip, dst_rows_dword_aligned(U, u));
         }
     }
+}
+
+// ---- host side: the argument block of a launch ----
+static TileArgs tile_args(const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags)
+{
+    TileArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ctx = cdev;
+    a.units = lu.dev;
+    a.tile_flags = flags;
+    a.n_units = lu.n;
+    if (!lu.dev)  // (lu.n <= kInlineUnits: plan.hip)
+        std::memcpy(a.inl, lu.host, sizeof(DevUnit) * (size_t)std::min(lu.n, kInlineUnits));
+    return a;
+}
+
+static bool units_dword_aligned(const LaunchUnits& lu)
+{
+    for (int k = 0; k < lu.n; k++)
+        if (((((uintptr_t)lu.host[k].src) | (uintptr_t)lu.host[k].src_pitch) & 3u) != 0)
+            return false;
+    return true;
+}
+
+// Units of a launch longer than the kernel-argument block holds: copied into a slot of the plan's device ring by launches of their
+// own (16 records each, carried in THEIR kernel arguments): stream-ordered, graph-capturable, no staging buffer to keep alive.
+__global__ __launch_bounds__(256) void k_put_units(DevUnit* dst, UnitArgs ua_, int n)
+{
+    typedef const V1C_CONST uint32_t* cu32;
+    const cu32 src = (cu32)((const V1C_CONST uint8_t*)__builtin_amdgcn_kernarg_segment_ptr() + 8);  // (behind `dst`)
+    const int words = n * (int)(sizeof(DevUnit) / 4);
+    for (int i = threadIdx.x; i < words; i += 256)
+        ((uint32_t*)dst)[i] = src[i];
+}
+
+hipError_t launch_put_units(DevUnit* dst, const DevUnit* host, int n, hipStream_t stream)
+{
+    static_assert(sizeof(DevUnit) % 4 == 0 && alignof(UnitArgs) == 8, "k_put_units reads its records at byte 8 of the kernel arguments");
+    for (int base = 0; base < n; base += kMaxUnitsPerLaunch) {
+        const int m = std::min(kMaxUnitsPerLaunch, n - base);
+        UnitArgs ua;
+        std::memset(&ua, 0, sizeof(ua));
+        std::memcpy(ua.u, host + base, sizeof(DevUnit) * (size_t)m);
+        hipLaunchKernelGGL(k_put_units, dim3(1), dim3(256), 0, stream, dst + base, ua, m);
+    }
+    return hipGetLastError();
 }
 
 static int taps_of(int interp)
@@ -2916,18 +2710,20 @@ int tile_cn_box_kb(const void* host_boxes, const Geom& g)
     return 16;
 }
 
-hipError_t launch_ray_lin_cn(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int kb, hipStream_t stream)
+hipError_t launch_ray_lin_cn(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,
+                             int kb, hipStream_t stream)
 {
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, 1);
-    const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
+    TileArgs a = tile_args(cdev, lu, flags);
+    a.boxes = (const TileBox*)boxes;
+    a.kb = kb;
+    a.tiles_x_magic = (unsigned)(0x100000000ull / grid.x) + 1u;
     // XCD interleave: strips of two tile rows (as the BGR launches)
     const unsigned two_rows = 2u * grid.x;
-    const unsigned slen = two_rows < ((grid.x * grid.y) >> 3) ? two_rows : 0u;
-    const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    a.strip_len = two_rows < ((grid.x * grid.y) >> 3) ? two_rows : 0u;
+    a.strip_magic = a.strip_len ? (unsigned)(0x100000000ull / a.strip_len) + 1u : 0u;
     const size_t lds = (size_t)2 * 1024 * (size_t)kb + 16;
-    const TileBox* bx = (const TileBox*)boxes;
-#define V1C_CN_LAUNCH(VW, R, CN) \
-    hipLaunchKernelGGL((k_ray_lin_cn<VW, R, CN>), grid, block, lds, stream, c, ua, bx, n_units, xmagic, slen, smagic, kb)
+#define V1C_CN_LAUNCH(VW, R, CN) hipLaunchKernelGGL((k_ray_lin_cn<VW, R, CN>), grid, block, lds, stream, a)
     const int sel = (c.ray.var_is_w ? 4 : 0) | (use_rot ? 2 : 0) | (c.g.cn == 4 ? 1 : 0);
     switch (sel) {
     case 0: V1C_CN_LAUNCH(0, 0, 1); break;
@@ -2997,7 +2793,7 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
             for (unsigned tx = 0; tx < d.x; tx++) {
                 const size_t i = (size_t)ty * d.x + tx;
                 const int fit = mirror_raw_fit(b[i], q[i], raw_nwp, g.src_h, g.src_w);
-                if (fit == 0 || (fit == 2 && (n_eyes == 1 || !V1C_MIRROR_BIG))) {
+                if (fit != 1) {
                     add(tx, ty);
                     if (ty < TYh) {  // its band: 15 rows of tile row TY - 1 - ty and (ty > 0) the first row of tile row TY - ty
                         add(tx, TY - 1 - ty);
@@ -3024,148 +2820,110 @@ bool tile_mirror_rest(const void* host_boxes, const void* host_mboxes, const Geo
     return rest.size() <= (size_t)d.x * (TYh - 1) && rest.size() * 4 <= (size_t)d.x * d.y;
 }
 
-// Table entries (per pair) the workgroups of k_ray_lin3_pair_mirror_pipe keep in LDS: the largest slice among the tile pairs that
-// launch serves
-int tile_mirror_pipe_tab(const void* host_boxes, const void* host_mboxes, const Geom& g, int raw_nwp)
+// lu.n = 2: apply_lr's pair; 1 (raw_nwp > 0): a single image through the one-eye instantiation of the LDS-DMA kernel
+// seq_kb > 0 (pairs): k_ray_lin3_pair_mirror_seq, two box buffers of seq_kb KB, the eyes one after the other
+hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, const void* boxes,
+                                       const void* mboxes, int half_dwords, int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp,
+                                       hipStream_t stream, int seq_kb)
 {
-    const TileBox* b = (const TileBox*)host_boxes;
-    const TileBox* q = (const TileBox*)host_mboxes;
-    const dim3 d = tile_grid(g, tile_threads(g), 1);
-    int m = 1;
-    for (unsigned ty = 1; ty < d.y / 2; ty++)
-        for (unsigned tx = 0; tx < d.x; tx++) {
-            const size_t i = (size_t)ty * d.x + tx;
-            if (mirror_raw_static_ok(b[i], q[i], raw_nwp, g.src_h, g.src_w))
-                m = std::max(m, b[i].nidx);
-        }
-    return m;
-}
-
-// `pipe_tab` > 0 (with raw_nwp > 0): k_ray_lin3_pair_mirror_pipe, two tile rows per workgroup, pipe_tab table entries per pair in LDS
-hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const UnitArgs& ua, const void* boxes, const void* mboxes, int half_dwords,
-                                       int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp, int pipe_tab, hipStream_t stream,
-                                       int n_eyes, int seq_kb)
-{
+    const int n_eyes = lu.n;
     const dim3 full = tile_grid(c.g, 256, 1);
-    const dim3 grid(full.x, full.y / 2 - 1, 2), block(256, 1, 1);
-    const size_t lds = std::max((size_t)half_dwords * 8 + 16, (size_t)4 * 1024 * (size_t)std::max(raw_nwp, 0));
-    const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
-    const unsigned per = (grid.x * grid.y) >> 3;
+    const dim3 block(256, 1, 1);
+    TileArgs a = tile_args(cdev, lu, flags);
+    a.boxes = (const TileBox*)boxes, a.mboxes = (const TileBox*)mboxes;
+    a.rest_list = rest_list, a.n_rest = n_rest;
+    a.half_dwords = half_dwords, a.mirror_h = mirror_h;
+    a.tiles_x_magic = (unsigned)(0x100000000ull / full.x) + 1u;
     static const unsigned strip_rows = [] {  // V1C_MIRROR_STRIP_ROWS=<n>: A/B override (0: one block per XCD)
         const char* e = tuning_env("V1C_MIRROR_STRIP_ROWS");
         return e ? (unsigned)std::atoi(e) : 2u;
     }();
-    unsigned slen = strip_rows && strip_rows * grid.x < per ? strip_rows * grid.x : 0u;  // two tile rows per strip (tile_xcd_strips)
-    const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
     static const unsigned block_rows = [] {  // V1C_MIRROR_BLOCK_ROWS=<n>: XCD blocks of gridDim.x / 8 columns x n tile rows (xcd_tile)
         const char* e = tuning_env("V1C_MIRROR_BLOCK_ROWS");
         return e ? (unsigned)std::atoi(e) : 0u;
     }();
-    if (block_rows && grid.x % 8 == 0 && raw_nwp > 0)
-        slen = 0x80000000u | std::min(block_rows, 0xffffu);
-    // k_ray_lin3_pair_mirror_raw: tile rows 0 .. TY / 2 (two more than the pairing of rows 1 .. TY / 2 - 1)
+    // the LDS-DMA kernels serve tile rows 0 .. TY / 2 (two more than the register-staged pairing of rows 1 .. TY / 2 - 1)
+    auto strips = [&](unsigned rows) {  // two tile rows per strip (tile_xcd_strips)
+        const unsigned per = (full.x * rows) >> 3;
+        unsigned slen = strip_rows && strip_rows * full.x < per ? strip_rows * full.x : 0u;
+        if (block_rows && full.x % 8 == 0 && raw_nwp > 0)
+            slen = 0x80000000u | std::min(block_rows, 0xffffu);
+        a.strip_len = slen;
+        a.strip_magic = (slen && !(slen & 0x80000000u)) ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    };
     const unsigned raw_rows = full.y / 2 + 1;
-    const unsigned raw_per = (grid.x * raw_rows) >> 3;
-    const unsigned raw_slen = (slen & 0x80000000u) ? slen : (strip_rows && strip_rows * grid.x < raw_per ? strip_rows * grid.x : 0u);
-    const unsigned raw_smagic = (raw_slen && !(raw_slen & 0x80000000u)) ? (unsigned)(0x100000000ull / raw_slen) + 1u : 0u;
+    const unsigned rest_rows = ((((unsigned)n_rest + full.x - 1) / full.x) + 7u) & ~7u;  // whole rows, a multiple of 8: the pair rows keep their XCDs
     if (seq_kb > 0 && n_eyes == 2) {  // the eyes one after the other: two buffers of seq_kb KB (rest list made for that size)
         static const bool norest_off = [] {  // V1C_SEQ_NOREST=0 (A/B): the instantiation with the general pair code for every plan
             const char* e = tuning_env("V1C_SEQ_NOREST");
             return e && e[0] == '0';
         }();
+        strips(raw_rows);
+        a.kb = seq_kb;
         if (n_rest == 0 && !norest_off) {  // nothing for the general pair code: the instantiation (and the LDS) without it
             const dim3 rgrid(full.x, raw_rows, 1);
             const size_t slds = (size_t)2 * 1024 * (size_t)seq_kb + 16;
+            a.rest_rows = 0;
             if (c.ray.var_is_w)
-                hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<1, 0>), rgrid, block, slds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                                   half_dwords, mirror_h, xmagic, rest_list, 0, raw_slen, raw_smagic, seq_kb, 0u);
+                hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<1, 0>), rgrid, block, slds, stream, a);
             else
-                hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<0, 0>), rgrid, block, slds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                                   half_dwords, mirror_h, xmagic, rest_list, 0, raw_slen, raw_smagic, seq_kb, 0u);
+                hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<0, 0>), rgrid, block, slds, stream, a);
             return hipGetLastError();
         }
-        const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
         const dim3 rgrid(full.x, raw_rows + rest_rows, 1);
         const size_t slds = std::max((size_t)half_dwords * 8 + 16, (size_t)2 * 1024 * (size_t)seq_kb);
+        a.rest_rows = rest_rows;
         if (c.ray.var_is_w)
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<1>), rgrid, block, slds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, seq_kb, rest_rows);
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<1>), rgrid, block, slds, stream, a);
         else
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<0>), rgrid, block, slds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, seq_kb, rest_rows);
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<0>), rgrid, block, slds, stream, a);
         return hipGetLastError();
     }
     if (raw_nwp > 0 && n_eyes == 1) {  // a single image: the LDS-DMA kernel's one-eye instantiation
-        const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
         const dim3 rgrid(full.x, raw_rows + rest_rows, 1);
         // two boxes; the general pair code serves one unit from one cell buffer
         const size_t lds = std::max((size_t)half_dwords * 4 + 16, (size_t)2 * 1024 * (size_t)raw_nwp);
+        strips(raw_rows);
+        a.kb = raw_nwp, a.rest_rows = rest_rows;
         if (c.ray.var_is_w)
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1, 1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1, 1>), rgrid, block, lds, stream, a);
         else
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0, 1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0, 1>), rgrid, block, lds, stream, a);
         return hipGetLastError();
     }
-    if (raw_nwp > 0 && pipe_tab > 0) {
-        // group rows: rows2 of them serve two tile rows, the last n1 one tile row each -- by default about one round of resident
-        // workgroups (6 per CU), so that the launch ends on short workgroups; V1C_PIPE_SINGLE_ROWS=<n>: A/B override
-        static const int single_rows = [] {
-            const char* e = tuning_env("V1C_PIPE_SINGLE_ROWS");
-            return e ? std::atoi(e) : -1;
-        }();
-        const unsigned M = grid.y;  // tile rows 1 .. TY / 2 - 1
-        unsigned n1 = single_rows >= 0 ? (unsigned)single_rows : (1536u + full.x - 1) / full.x;
-        n1 = std::min(n1, M);
-        if ((M - n1) & 1u)
-            n1 += 1;
-        const unsigned rows2 = (M - n1) / 2;
-        const unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
-        const dim3 pgrid(full.x, rows2 + n1 + rest_rows, 1);
-        const unsigned pper = (pgrid.x * (rows2 + n1)) >> 3;
-        const unsigned pslen = strip_rows && pgrid.x < pper ? pgrid.x : 0u;  // one group row (two tile rows) per strip
-        const unsigned psmagic = pslen ? (unsigned)(0x100000000ull / pslen) + 1u : 0u;
-        const unsigned tab_off = 4u * 1024u * (unsigned)raw_nwp;
-        const unsigned cols_off = tab_off + 2u * (unsigned)pipe_tab * (unsigned)(kRadialCoefs * 8);
-        const unsigned tab_rest_off = ((unsigned)half_dwords * 8u + 16u + 15u) & ~15u;
-        const size_t plds = std::max((size_t)cols_off + kPipeColBytes + kPipeRowBytes, (size_t)tab_rest_off + kTabSlice * kRadialCoefs * 8);
-        if (c.ray.var_is_w)
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_pipe<1>), pgrid, block, plds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, pslen, psmagic, raw_nwp, rest_rows, rows2, tab_off, cols_off, tab_rest_off);
-        else
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_pipe<0>), pgrid, block, plds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, pslen, psmagic, raw_nwp, rest_rows, rows2, tab_off, cols_off, tab_rest_off);
-        return hipGetLastError();
-    }
+#ifdef V1C_TUNING  // A/B partners of the seq kernel: the four-buffer LDS-DMA pair kernel (V1C_MIRROR_SEQ=0) and the register-staged one (V1C_MIRROR_RAW=0)
+    if (n_eyes != 2)
+        return hipErrorInvalidValue;
+    const size_t lds = std::max((size_t)half_dwords * 8 + 16, (size_t)4 * 1024 * (size_t)std::max(raw_nwp, 0));
     if (raw_nwp > 0) {
-        // (whole rows, a multiple of 8 of them: the pair rows keep their XCDs)
-        unsigned rest_rows = ((((unsigned)n_rest + grid.x - 1) / grid.x) + 7u) & ~7u;
         dim3 rgrid(full.x, raw_rows + rest_rows, 1);
+        strips(raw_rows);
+        a.kb = raw_nwp, a.rest_rows = rest_rows;
         // V1C_MIRROR_SKIP=1: timing experiment, the rest rows are not launched (their tiles stay unwritten); =2: ONLY the rest rows
         static const int skip = [] {
             const char* e = tuning_env("V1C_MIRROR_SKIP");
             return e ? std::atoi(e) : 0;
         }();
         if (skip == 1)
-            n_rest = 0, rest_rows = 0, rgrid.y = raw_rows;
+            a.n_rest = 0, a.rest_rows = 0, rgrid.y = raw_rows;
         if (skip == 2)
             rgrid.y = rest_rows;
         if (c.ray.var_is_w)
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1, 2>), rgrid, block, lds, stream, a);
         else
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0>), rgrid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                               half_dwords, mirror_h, xmagic, rest_list, n_rest, raw_slen, raw_smagic, raw_nwp, rest_rows);
+            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0, 2>), rgrid, block, lds, stream, a);
         return hipGetLastError();
     }
+    const dim3 grid(full.x, full.y / 2 - 1, 2);
+    strips(grid.y);
     if (c.ray.var_is_w)
-        hipLaunchKernelGGL((k_ray_lin3_pair_mirror<1>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                           half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic);
+        hipLaunchKernelGGL((k_ray_lin3_pair_mirror<1>), grid, block, lds, stream, a);
     else
-        hipLaunchKernelGGL((k_ray_lin3_pair_mirror<0>), grid, block, lds, stream, c, ua, (const TileBox*)boxes, (const TileBox*)mboxes,
-                           half_dwords, mirror_h, xmagic, rest_list, n_rest, slen, smagic);
+        hipLaunchKernelGGL((k_ray_lin3_pair_mirror<0>), grid, block, lds, stream, a);
     return hipGetLastError();
+#else
+    return hipErrorInvalidValue;  // (plan.hip selects the seq / one-eye forms only)
+#endif
 }
 
 // LDS dwords one box buffer must hold so that every stageable tile box of `host_boxes` fits
@@ -3306,26 +3064,26 @@ std::vector<uint32_t> tile_rest_list(const void* host_boxes, const Geom& g, int 
 
 // plan creation: fill `boxes` (device, tile_box_bytes()) for the plan's own rotation
 template <int K, int NT>
-static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxes, bool shared_entry, int mirror_h, hipStream_t stream)
+static void launch_boxes_k(const KernelCtx& c, const TileArgs& a, bool shared_entry, hipStream_t stream)
 {
     const dim3 block(NT, 1, 1), grid = tile_grid(c.g, NT, 1);
     const bool rot = c.ray.has_rot != 0;
     const bool nn = c.g.interp == V1C_INTER_NEAREST;
-#define V1C_BOXES(VW, RT)                                                                                         \
-    do {                                                                                                          \
-        if constexpr (K == 2) {                                                                                   \
-            if (nn) {                                                                                             \
-                if (shared_entry)                                                                                 \
-                    hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0, 1>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
-                else                                                                                              \
-                    hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1, 1>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
-                break;                                                                                            \
-            }                                                                                                     \
-        }                                                                                                         \
-        if (shared_entry)                                                                                         \
-            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
-        else                                                                                                      \
-            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1>), grid, block, 0, stream, c, ua, boxes, mirror_h); \
+#define V1C_BOXES(VW, RT)                                                                              \
+    do {                                                                                               \
+        if constexpr (K == 2) {                                                                        \
+            if (nn) {                                                                                  \
+                if (shared_entry)                                                                      \
+                    hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0, 1>), grid, block, 0, stream, a); \
+                else                                                                                   \
+                    hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1, 1>), grid, block, 0, stream, a); \
+                break;                                                                                 \
+            }                                                                                          \
+        }                                                                                              \
+        if (shared_entry)                                                                              \
+            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 0>), grid, block, 0, stream, a);           \
+        else                                                                                           \
+            hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1>), grid, block, 0, stream, a);           \
     } while (0)
     if (c.ray.var_is_w) {
         if (rot)
@@ -3342,23 +3100,29 @@ static void launch_boxes_k(const KernelCtx& c, const UnitArgs& ua, TileBox* boxe
 }
 
 // `shared_entry`: the value the launches consuming these boxes will pass to launch_ray_lin3_tile
-hipError_t launch_tile_boxes(const KernelCtx& c, void* boxes, bool shared_entry, hipStream_t stream, int mirror_h)
+// (`cdev` must hold the plan's tables already: the kernel reads them through it)
+hipError_t launch_tile_boxes(const KernelCtx& c, const KernelCtx* cdev, void* boxes, bool shared_entry, hipStream_t stream, int mirror_h)
 {
-    UnitArgs ua{};
+    TileArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ctx = cdev;
+    a.boxes = (const TileBox*)boxes;
+    a.mirror_h = mirror_h;
     switch (taps_of(c.g.interp)) {
-    case 2: launch_boxes_k<2, 256>(c, ua, (TileBox*)boxes, shared_entry, mirror_h, stream); break;
-    case 4: launch_boxes_k<4, 256>(c, ua, (TileBox*)boxes, shared_entry, mirror_h, stream); break;
-    case 8: launch_boxes_k<8, 256>(c, ua, (TileBox*)boxes, shared_entry, mirror_h, stream); break;
+    case 2: launch_boxes_k<2, 256>(c, a, shared_entry, stream); break;
+    case 4: launch_boxes_k<4, 256>(c, a, shared_entry, stream); break;
+    case 8: launch_boxes_k<8, 256>(c, a, shared_entry, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 template <int K>
-static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const TileBox* bx, int half_dwords,
-                          bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
+static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const TileBox* bx,
+                          int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
                           int lean_raw_nwp, hipStream_t stream, bool coords_bounded)
 {
+    const int n_units = lu.n;
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
     static const int upb_max = [] {  // V1C_UPB=<n>: A/B override of the units per workgroup
         const char* e = tuning_env("V1C_UPB");
@@ -3393,8 +3157,10 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     const bool nn = c.g.interp == V1C_INTER_NEAREST;  // through k_ray_lin3_tile<..., NN = 1> only
     bool lean = bx && K == 2 && !nn && !lean_off && rest_list != nullptr &&
                 (lean_pair ? (upb >= 2 && n_units % upb != 1) : (upb > 2 && (n_units % upb == 0 || n_units % upb > 2)));
-    for (int k = 0; k < n_units && lean; k++)
-        lean = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
+#ifndef V1C_TUNING
+    lean = lean && lean_raw_nwp > 0;  // (the register-staged lean kernel is an A/B partner: tuning build only)
+#endif
+    lean = lean && units_dword_aligned(lu);
     // (An LDS-DMA form of the plain pair kernel -- k_ray_lin3_pair_mirror_raw without the mirror image -- was built and removed:
     // bit-identical, but 0.0535 against 0.0511 ms on an unrotated 4080^2 pair and 0.0733 against 0.0684 ms on a rotated
     // 4096^2 pair (94 VGPRs): with one tile per workgroup the interleaved cells' single ds_read2_b64 per tap row wins.)
@@ -3410,14 +3176,18 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     }();
     const bool merged = !merge_off && n_rest > 0 && (size_t)n_rest * ((n_units + 1) / 2) <= (size_t)grid.x * grid.y;
     const dim3 merged_grid(grid.x, grid.y, grid.z + 1);
-    const unsigned xmagic = (unsigned)(0x100000000ull / grid.x) + 1u;
     static const unsigned nobox_strip_rows = [] {  // V1C_NOBOX_STRIP_ROWS=<n>: XCD strips of n tile rows for launches without boxes
         const char* e = tuning_env("V1C_NOBOX_STRIP_ROWS");
         return e ? (unsigned)std::atoi(e) : 0u;
     }();
-    const unsigned slen = bx ? (strip_len > 0 && (unsigned)strip_len < ((grid.x * grid.y) >> 3) ? (unsigned)strip_len : 0u)
-                             : (nobox_strip_rows * grid.x < ((grid.x * grid.y) >> 3) ? nobox_strip_rows * grid.x : 0u);
-    const unsigned smagic = slen ? (unsigned)(0x100000000ull / slen) + 1u : 0u;
+    TileArgs a = tile_args(cdev, lu, flags);
+    a.boxes = bx;
+    a.upb = upb, a.half_dwords = half_dwords;
+    a.tiles_x = (int)grid.x;
+    a.tiles_x_magic = (unsigned)(0x100000000ull / grid.x) + 1u;
+    a.strip_len = bx ? (strip_len > 0 && (unsigned)strip_len < ((grid.x * grid.y) >> 3) ? (unsigned)strip_len : 0u)
+                     : (nobox_strip_rows * grid.x < ((grid.x * grid.y) >> 3) ? nobox_strip_rows * grid.x : 0u);
+    a.strip_magic = a.strip_len ? (unsigned)(0x100000000ull / a.strip_len) + 1u : 0u;
     // units that override the rotation, bilinear, OWN = 0: two units per workgroup with their boxes by LDS-DMA (V1C_ROT_PAIR=0: A/B
     // switch, the one-unit-per-workgroup kernel)
     static const bool rot_pair_off = [] {
@@ -3432,15 +3202,15 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     if constexpr (K == 2) {
         if (!bx && shared_entry && !rot_pair_off && !nn) {
             const dim3 pgrid(grid.x, grid.y, (unsigned)((n_units + 1) / 2));
-            const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int) +
-                                (V1C_ROTPAIR_SEPARABLE ? 2 * 3 * kTW * sizeof(double) : 0);
+            const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int);
             const bool mp = mpoly_all && c.ray.radial_m != nullptr;
-#define V1C_ROTPAIR(VW, MPV)                                                                                                                       \
-    do {                                                                                                                                           \
-        if (coords_bounded)                                                                                                                        \
-            hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<VW, MPV, 1>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic); \
-        else                                                                                                                                       \
-            hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<VW, MPV, 0>), pgrid, block, plds, stream, c, ua, n_units, rot_pair_slot, xmagic, slen, smagic); \
+            a.kb = rot_pair_slot;
+#define V1C_ROTPAIR(VW, MPV)                                                                            \
+    do {                                                                                                \
+        if (coords_bounded)                                                                             \
+            hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<VW, MPV, 1>), pgrid, block, plds, stream, a);   \
+        else                                                                                            \
+            hipLaunchKernelGGL((k_ray_lin3_rot_pair_raw<VW, MPV, 0>), pgrid, block, plds, stream, a);   \
     } while (0)
             if (c.ray.var_is_w) {
                 if (mp)
@@ -3459,36 +3229,40 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
     }
     // Only combinations a plan can select are instantiated: the lean batch kernel and the tile-list form exist for
     // bilinear plans with boxes; launches without boxes (units that override the rotation) always rotate.
+#ifdef V1C_TUNING
+#define V1C_LEAN_STAGED(VW, RT, OW) hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), merged ? merged_grid : grid, block, lean_lds, stream, la)
+#else
+#define V1C_LEAN_STAGED(VW, RT, OW) (void)0
+#endif
 #define V1C_TILE_P(VW, RT, BX, OW, PR)                                                                                                \
     do {                                                                                                                              \
         if constexpr (K == 2 && BX == 1) {                                                                                            \
             if (lean) {                                                                                                               \
                 /* (running the remaining tiles on a side stream, forked and joined with events so that their */                      \
                 /* latency-bound kernel overlaps the lean one, measured 4 % slower on C3 than back to back) */                        \
+                TileArgs la = a;                                                                                                      \
+                la.half_dwords = lean_half, la.kb = lean_raw_nwp;                                                                     \
+                la.rest_list = merged ? rest_list : (const uint32_t*)nullptr, la.n_rest = n_rest;                                     \
                 if (lean_raw_nwp > 0)                                                                                                 \
                     hipLaunchKernelGGL((k_ray_lin3_batch_lean_raw<VW, RT, OW>), merged ? merged_grid : grid, block,                   \
-                                       std::max(lean_lds, (size_t)V1C_LEAN_RING * 1024 * (size_t)lean_raw_nwp), stream, c, ua, bx, n_units, upb,  \
-                                       lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest, slen, smagic,        \
-                                       lean_raw_nwp);                                                                                 \
+                                       std::max(lean_lds, (size_t)V1C_LEAN_RING * 1024 * (size_t)lean_raw_nwp), stream, la);          \
                 else                                                                                                                  \
-                hipLaunchKernelGGL((k_ray_lin3_batch_lean<VW, RT, OW>), merged ? merged_grid : grid, block, lean_lds, stream, c, ua,  \
-                                   bx, n_units, upb, lean_half, xmagic, merged ? rest_list : (const uint32_t*)nullptr, n_rest, slen,  \
-                                   smagic);                                                                                           \
-                if (n_rest > 0 && !merged)                                                                                            \
-                    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K, OW, 1, 1>), rest_grid, block, lds, stream, c, ua, bx, n_units,  \
-                                       2, half_dwords, xmagic, rest_list, (int)grid.x, 0u, 0u);                                      \
+                    V1C_LEAN_STAGED(VW, RT, OW);                                                                                      \
+                if (n_rest > 0 && !merged) {                                                                                          \
+                    TileArgs ra = a;                                                                                                  \
+                    ra.upb = 2, ra.rest_list = rest_list, ra.strip_len = ra.strip_magic = 0u;                                         \
+                    hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, 1, K, OW, 1, 1>), rest_grid, block, lds, stream, ra);                 \
+                }                                                                                                                     \
                 break;                                                                                                                \
             }                                                                                                                         \
         }                                                                                                                             \
         if constexpr (K == 2) {                                                                                                       \
             if (nn) {                                                                                                                 \
-                hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR, 0, 1>), grid, block, lds, stream, c, ua, bx, n_units, upb, \
-                                   half_dwords, xmagic, (const uint32_t*)nullptr, (int)grid.x, slen, smagic);                        \
+                hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR, 0, 1>), grid, block, lds, stream, a);                      \
                 break;                                                                                                                \
             }                                                                                                                         \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, c, ua, bx, n_units, upb, half_dwords,  \
-                           xmagic, (const uint32_t*)nullptr, (int)grid.x, slen, smagic);                                             \
+        hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, a);                                    \
     } while (0)
 #define V1C_TILE_O(VW, RT, BX, OW)                       \
     do {                                                 \
@@ -3524,6 +3298,7 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 #undef V1C_TILE
 #undef V1C_TILE_O
 #undef V1C_TILE_P
+#undef V1C_LEAN_STAGED
 }
 
 // `boxes` may be null (the units override the rotation): then boxes are reduced in-kernel.
@@ -3534,15 +3309,16 @@ static void launch_tile_k(const KernelCtx& c, const UnitArgs& ua, int n_units, b
 // `mpoly_all` (boxes == null only): the m-polynomial table is valid on every interval these units reach.
 // `rest_list` / `n_rest` / `lean_half` (boxes != null; list may be null): device copy of tile_rest_list() and the box
 // buffer size (dwords) it was made for.
-hipError_t launch_ray_lin3_tile(const KernelCtx& c, const UnitArgs& ua, int n_units, bool use_rot, const void* boxes, int half_dwords,
-                                bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
-                                int lean_raw_nwp, hipStream_t stream, bool coords_bounded)
+// `flags`: the plan's tile-flag words when a fix-up pass follows this launch, else null.
+hipError_t launch_ray_lin3_tile(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,
+                                int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
+                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded)
 {
     const TileBox* bx = (const TileBox*)boxes;
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
-    case 4: launch_tile_k<4>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
-    case 8: launch_tile_k<8>(c, ua, n_units, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
+    case 2: launch_tile_k<2>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
+    case 4: launch_tile_k<4>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
+    case 8: launch_tile_k<8>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

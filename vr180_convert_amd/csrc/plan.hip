@@ -165,7 +165,19 @@ struct v1c_plan {
     bool ray_no_rot_safe = false; // no rotation: reachable m stays below the first flagged interval
     bool ray_plan_rot_safe = false;  // the chain's own rotation keeps every ray inside the validated table
     bool front_hemisphere = false;   // unrotated rays all have v_z >= 0
-    KernelCtx ctx{};
+    KernelCtx ctx{};                 // host copy (what the launchers' decisions read) ...
+    KernelCtx* ctx_dev = nullptr;    // ... and the plan-resident device copy the tile kernels read (kernels.hpp: TileArgs)
+    // Units of launches longer than the kernel-argument block holds (kInlineUnits) travel through this ring of device buffers of
+    // kRingUnits records each.  A slot is rewritten by launch_put_units in stream order; a launch on ANOTHER stream than the slot's
+    // last user first waits for that user's event.  Launches recorded into a graph take one of the capture slots instead, each
+    // handed out once: a graph owns what it replays.
+    static constexpr int kRingSlots = 4, kCaptureSlots = 4, kRingUnits = 256;
+    DevUnit* ring = nullptr;         // (kRingSlots + kCaptureSlots) x kRingUnits records
+    hipEvent_t ring_ev[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t ring_last[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool ring_used[kRingSlots] = {false, false, false, false};
+    int ring_next = 0, capture_next = 0;
+    std::mutex ring_mu;
     int tiles = 0;
     void* tile_boxes = nullptr;   // per-tile source boxes of the tiled kernel (plan rotation)
     int half_dwords = 256;        // LDS dwords per box buffer of the shared-map tile kernel
@@ -184,7 +196,6 @@ struct v1c_plan {
     const uint32_t* mirror_rest1 = nullptr;  // ... of single-image launches (one eye: its two boxes have a pair's four buffers)
     int n_mirror_rest1 = -1;                 // -1: no single-image mirror launch
     int mirror_raw_nwp = 0;  // > 0: the mirror launch brings its boxes in by LDS-DMA (k_ray_lin3_pair_mirror_raw), buffers of so many KB
-    int mirror_pipe_tab = 0;  // > 0: ... two tile rows per workgroup (k_ray_lin3_pair_mirror_pipe), so many table entries per pair in LDS
     int mirror_h = 0;
     bool disable_fast = false;    // V1C_DISABLE_FAST=1: always use the generic kernels (A/B testing)
     bool disable_coords_bounded = false;  // V1C_DISABLE_COORDS_BOUNDED=1: k_ray_lin3_rot_pair_raw with its clamps (A/B testing)
@@ -280,6 +291,9 @@ extern "C" int v1c_plan_destroy(v1c_plan* p)
         (void)hipFree(d);
     if (p->flags_ev)
         (void)hipEventDestroy(p->flags_ev);
+    for (hipEvent_t e : p->ring_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     delete p;
     return V1C_OK;
 }
@@ -446,6 +460,28 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 }
             }
 #endif
+            // the device copy of the context (complete from here on: geometry, tables, weight table) and the unit ring
+            {
+                void* dctx = nullptr;
+                e = hipMalloc(&dctx, sizeof(KernelCtx));
+                if (e == hipSuccess) {
+                    p->allocs.push_back(dctx);
+                    e = hipMemcpy(dctx, &p->ctx, sizeof(KernelCtx), hipMemcpyHostToDevice);
+                }
+                void* ring = nullptr;
+                if (e == hipSuccess)
+                    e = hipMalloc(&ring, sizeof(DevUnit) * (size_t)(v1c_plan::kRingSlots + v1c_plan::kCaptureSlots) * v1c_plan::kRingUnits);
+                if (e == hipSuccess)
+                    p->allocs.push_back(ring);
+                for (int k = 0; k < v1c_plan::kRingSlots && e == hipSuccess; k++)
+                    e = hipEventCreateWithFlags(&p->ring_ev[k], hipEventDisableTiming);
+                if (e != hipSuccess) {
+                    v1c_plan_destroy(p);
+                    return fail(V1C_E_HIP, std::string("plan context upload: ") + hipGetErrorString(e));
+                }
+                p->ctx_dev = (KernelCtx*)dctx;
+                p->ring = (DevUnit*)ring;
+            }
             // source boxes of the tiled kernel, computed once (BGR, constant border, linear/cubic/lanczos4)
             const Geom& g = p->ctx.g;
             if (cn_kernel_supports(g) && p->plan_shared_entry && !p->disable_shared_entry) {
@@ -454,7 +490,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 e = hipMalloc(&bx, tile_box_bytes(g));
                 if (e == hipSuccess) {
                     p->allocs.push_back(bx);
-                    e = launch_tile_boxes(p->ctx, bx, true, nullptr);
+                    e = launch_tile_boxes(p->ctx, p->ctx_dev, bx, true, nullptr);
                 }
                 std::vector<char> hb(tile_box_bytes(g));
                 if (e == hipSuccess)
@@ -475,7 +511,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 e = hipMalloc(&bx, tile_box_bytes(g));
                 if (e == hipSuccess) {
                     p->allocs.push_back(bx);
-                    e = launch_tile_boxes(p->ctx, bx, p->plan_shared_entry && !p->disable_shared_entry, nullptr);
+                    e = launch_tile_boxes(p->ctx, p->ctx_dev, bx, p->plan_shared_entry && !p->disable_shared_entry, nullptr);
                 }
                 if (e != hipSuccess) {
                     v1c_plan_destroy(p);
@@ -525,7 +561,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         e = hipMalloc(&mbx, tile_box_bytes(g));
                         if (e == hipSuccess) {
                             p->allocs.push_back(mbx);
-                            e = launch_tile_boxes(p->ctx, mbx, true, nullptr, g.dst_h);
+                            e = launch_tile_boxes(p->ctx, p->ctx_dev, mbx, true, nullptr, g.dst_h);
                         }
                         std::vector<char> hm(tile_box_bytes(g));
                         if (e == hipSuccess)
@@ -539,26 +575,20 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         const char* rawsw = tuning_env("V1C_MIRROR_RAW");
                         const int rawv = rawsw ? std::atoi(rawsw) : 1;
                         p->mirror_raw_nwp = rawv == 1 ? tile_mirror_raw_passes(hb.data(), hm.data(), g) : rawv > 1 ? std::min(rawv, 16) : 0;
-                        // V1C_MIRROR_PIPE=1 (A/B builds): two tile rows per workgroup (k_ray_lin3_pair_mirror_pipe).  Measured r03,
-                        // C2 / C1: 0.0497 / 0.0205 ms against 0.0472 / 0.0185 ms for k_ray_lin3_pair_mirror_raw
-                        const char* pipesw = tuning_env("V1C_MIRROR_PIPE");
-                        const bool pipe = p->mirror_raw_nwp > 0 && pipesw && pipesw[0] == '1';
                         // pairs: the eyes one after the other through two buffers of twice the size (k_ray_lin3_pair_mirror_seq: 99.8 % of
                         // the tile pairs fit, C2 -0.4 ... -2.6 %, C1 -1.6 ... -3 % against the four-buffer kernel on three boxes,
                         // DESIGN.md 4.4c); V1C_MIRROR_SEQ=0 (A/B): k_ray_lin3_pair_mirror_raw for pairs too; V1C_MIRROR_SEQ_KB=<n>: buffer size
                         const char* seqsw = tuning_env("V1C_MIRROR_SEQ");
                         const char* seqkb = tuning_env("V1C_MIRROR_SEQ_KB");
-                        if (p->mirror_raw_nwp > 0 && !pipe && !(seqsw && seqsw[0] == '0'))
+                        if (p->mirror_raw_nwp > 0 && !(seqsw && seqsw[0] == '0'))
                             p->mirror_seq_kb = seqkb ? std::min(std::max(std::atoi(seqkb), 2), 16) : tile_mirror_raw_passes(hb.data(), hm.data(), g, 998, 11);
                         if (tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest,
-                                             p->mirror_seq_kb > 0 ? p->mirror_seq_kb : p->mirror_raw_nwp, !pipe, 2)) {
+                                             p->mirror_seq_kb > 0 ? p->mirror_seq_kb : p->mirror_raw_nwp, true, 2)) {
                             if ((rc = upload(p, mrest, &p->mirror_rest))) {
                                 v1c_plan_destroy(p);
                                 return rc;
                             }
                             p->mirror_boxes = mbx, p->n_mirror_rest = (int)mrest.size(), p->mirror_h = g.dst_h;
-                            if (pipe)
-                                p->mirror_pipe_tab = tile_mirror_pipe_tab(hb.data(), hm.data(), g, p->mirror_raw_nwp);
                             std::vector<uint32_t> mrest1;
                             if (p->mirror_raw_nwp > 0 && tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest1, p->mirror_raw_nwp, true, 1)) {
                                 if ((rc = upload(p, mrest1, &p->mirror_rest1))) {
@@ -568,8 +598,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                                 p->n_mirror_rest1 = (int)mrest1.size();
                             }
                             if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
-                                std::fprintf(stderr, "[v1c] mirror launch: seq buffers %d KB; largest table slice %d entries\n", p->mirror_seq_kb,
-                                             tile_mirror_pipe_tab(hb.data(), hm.data(), g, p->mirror_raw_nwp));
+                                std::fprintf(stderr, "[v1c] mirror launch: seq buffers %d KB\n", p->mirror_seq_kb);
                         }
                         if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                             std::fprintf(stderr, "[v1c] mirror pair launch: %s, %zu of %zu tiles left to the pair kernel (raw wave-passes %d)\n",
@@ -638,8 +667,115 @@ static int fill_unit(const v1c_plan* p, const v1c_unit& in, DevUnit& out)
     out.src_pitch = in.src_pitch, out.dst_pitch = in.dst_pitch;
     out.has_rot = in.has_rot ? 1 : 0;
     out.pad = 0;
+    // `rot` always holds the EFFECTIVE rotation of the fused ray path -- the unit's override or the chain's composed one --: the tile
+    // kernels read it unconditionally (the generic kernels and the interpreter still look at has_rot)
+    const bool plan_rot = p->mode == MODE_RAY && p->ana.has_rot;
     for (int q = 0; q < 9; q++)
-        out.rot[q] = in.has_rot ? in.rot[q] : 0.0;
+        out.rot[q] = in.has_rot ? in.rot[q] : (plan_rot ? p->ana.rot[q] : 0.0);
+    return V1C_OK;
+}
+
+// the by-value argument block of the generic kernels (kernels.hip): up to kMaxUnitsPerLaunch records
+static UnitArgs unit_args(const DevUnit* du, int n)
+{
+    UnitArgs ua;
+    std::memset(&ua, 0, sizeof(ua));
+    std::memcpy(ua.u, du, sizeof(DevUnit) * (size_t)n);
+    return ua;
+}
+
+// What a launch of units [0, n) of `du` may use, decided from the plan and the units themselves
+struct LaunchPlan {
+    bool any_rot = false;        // some unit overrides the rotation: no plan-time boxes
+    bool fast = false;           // the hand-tuned tile kernels (32-bit source / destination offsets)
+    bool need_fixup = false;     // a fix-up pass must follow (pixels may land in flagged table intervals)
+    bool shared_entry = false;   // one table entry per lane, no per-pixel fallback in the kernel
+    bool mpoly_all = false;      // the m-polynomial table serves every interval the units reach
+    bool coords_bounded = false; // every |32 x|, |32 y| < 2^21
+};
+
+static LaunchPlan decide_launch(const v1c_plan* p, const DevUnit* du, int n)
+{
+    LaunchPlan d;
+    for (int k = 0; k < n; k++)
+        d.any_rot |= du[k].has_rot != 0;
+    const Geom& g = p->ctx.g;
+    d.fast = p->tile_boxes != nullptr && !p->disable_fast;
+    for (int k = 0; k < n && d.fast; k++)
+        d.fast = (uint64_t)g.src_h * (uint64_t)du[k].src_pitch < 0xFFFFFF00ull && du[k].src_pitch < (1 << 24) &&
+                 (uint64_t)g.dst_h * (uint64_t)du[k].dst_pitch < 0xFFFFFF00ull && du[k].dst_pitch < (1 << 24);
+    // the fix-up pass is skipped when no pixel can land in a flagged table interval: proven at
+    // plan time for the chain's own rotation, per unit for overriding rotations; likewise
+    // `shared_entry` (one table entry per lane, no per-pixel fallback in the kernel)
+    d.need_fixup = !(p->ray_no_rot_safe || p->ray_plan_rot_safe);
+    d.shared_entry = p->plan_shared_entry;
+    // the m-polynomial table (no fp64 index arithmetic) serves a launch of overriding rotations
+    // when every interval up to each unit's reach is valid at the level the lanes need
+    d.mpoly_all = d.any_rot && p->ctx.ray.radial_m != nullptr;
+    // every pixel's |32 x|, |32 y| provably below 2^21 (half the cvRound trick's range): |x32 - cx32| <= |G| |rx32| with G bounded
+    // over every table entry in reach -- only ever used together with shared_entry && !need_fixup
+    d.coords_bounded = d.any_rot && p->front_hemisphere;
+    if (d.any_rot) {
+        d.need_fixup = !p->front_hemisphere;
+        d.shared_entry = p->front_hemisphere;
+        for (int k = 0; k < n && !d.need_fixup; k++) {
+            const double* r = du[k].has_rot ? du[k].rot : p->ana.rot;
+            const bool rotated = du[k].has_rot || p->ana.has_rot;
+            const bool covered = rotated ? ray_reach_is_safe(p->table, rotated_reach(r)) : p->ray_no_rot_safe;
+            d.need_fixup = !covered;
+            if (d.coords_bounded) {
+                const RayParams& rp = p->ctx.ray;
+                const double gb = covered ? radial_table_g_bound(p->table, p->g_bounds, rotated ? rotated_reach(r) : p->m_reach_norot) : INFINITY;
+                d.coords_bounded = gb * std::fabs(rp.rx32) + std::fabs(rp.cx32) < 2097152.0 && gb * std::fabs(rp.ry32) + std::fabs(rp.cy32) < 2097152.0;
+            }
+            d.shared_entry = d.shared_entry && covered &&
+                             (rotated ? ray_entry_is_shared(p->table, rotated_reach(r), p->ray_step) : p->plan_shared_entry);
+            if (d.mpoly_all) {  // (same interval bound as mpoly_first_ok: reach + 2 for the fp32 index)
+                const double mr = rotated ? rotated_reach(r) : p->m_reach_norot;
+                const double u_reach = (p->table.var_is_w ? std::sqrt(mr / 2) : mr) * (1 + 1e-9);
+                d.mpoly_all = covered && std::min(p->table.n_int - 1, (int)(u_reach * p->table.inv_step) + 2) <= p->mp_valid_upto;
+            }
+        }
+        d.shared_entry = d.shared_entry && !d.need_fixup;
+        d.mpoly_all = d.mpoly_all && d.shared_entry;
+        d.coords_bounded = d.coords_bounded && d.shared_entry;
+    }
+    return d;
+}
+
+// device copy of the units of a launch longer than the kernel arguments hold: a ring slot (class comment of v1c_plan)
+static int ring_put(v1c_plan* p, hipStream_t st, const DevUnit* du, int n, const DevUnit** out, int* slot_out)
+{
+    std::lock_guard<std::mutex> lk(p->ring_mu);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess)
+        cap = hipStreamCaptureStatusNone;
+    int slot;
+    if (cap != hipStreamCaptureStatusNone) {
+        if (p->capture_next >= v1c_plan::kCaptureSlots)
+            return fail(V1C_E_UNSUPPORTED, "too many graph-captured launches of more than 16 units for one plan");
+        slot = v1c_plan::kRingSlots + p->capture_next++;
+        *slot_out = -1;
+    } else {
+        slot = p->ring_next;
+        p->ring_next = (p->ring_next + 1) % v1c_plan::kRingSlots;
+        if (p->ring_used[slot] && p->ring_last[slot] != st)
+            HIP_TRY(hipStreamWaitEvent(st, p->ring_ev[slot], 0));
+        *slot_out = slot;
+    }
+    DevUnit* dst = p->ring + (size_t)slot * v1c_plan::kRingUnits;
+    HIP_TRY(launch_put_units(dst, du, n, st));
+    *out = dst;
+    return V1C_OK;
+}
+
+static int ring_done(v1c_plan* p, hipStream_t st, int slot)
+{
+    if (slot < 0)
+        return V1C_OK;
+    std::lock_guard<std::mutex> lk(p->ring_mu);
+    HIP_TRY(hipEventRecord(p->ring_ev[slot], st));
+    p->ring_last[slot] = st, p->ring_used[slot] = true;
     return V1C_OK;
 }
 
@@ -651,106 +787,91 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
     if (!dg.ok)
         return fail(V1C_E_NODEVICE, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
-    for (int base = 0; base < n_units; base += kMaxUnitsPerLaunch) {
-        const int n = std::min(kMaxUnitsPerLaunch, n_units - base);
-        UnitArgs ua;
-        std::memset(&ua, 0, sizeof(ua));
-        bool any_rot = false;
-        for (int k = 0; k < n; k++) {
-            int rc = fill_unit(p, units[base + k], ua.u[k]);
+    DevUnit du_small[kMaxUnitsPerLaunch];
+    std::vector<DevUnit> du_big;
+    DevUnit* du = du_small;
+    if (n_units > kMaxUnitsPerLaunch) {
+        du_big.resize((size_t)n_units);
+        du = du_big.data();
+    }
+    for (int k = 0; k < n_units; k++) {
+        int rc = fill_unit(p, units[k], du[k]);
+        if (rc)
+            return rc;
+    }
+    for (int base = 0; base < n_units;) {
+        if (p->mode != MODE_RAY) {
+            const int n = std::min(kMaxUnitsPerLaunch, n_units - base);
+            HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, unit_args(du + base, n), n, st));
+            base += n;
+            continue;
+        }
+        // A launch of the tile kernels takes any number of units (beyond kInlineUnits through the ring) -- unless a fix-up pass
+        // must follow (its flag words cover kMaxUnitsPerLaunch unit slots) or the generic kernels serve it (by-value arguments)
+        int n = std::min(v1c_plan::kRingUnits, n_units - base);
+        LaunchPlan d = decide_launch(p, du + base, n);
+        const bool literal = d.any_rot && p->n_rot_stages > 1;
+        if (n > kMaxUnitsPerLaunch && (literal || !d.fast || d.need_fixup || p->ctx.g.cn != 3)) {
+            n = kMaxUnitsPerLaunch;
+            d = decide_launch(p, du + base, n);
+        }
+        const DevUnit* u = du + base;
+        base += n;
+        // units overriding one of SEVERAL rotate stages take the interpreter (rare); all other
+        // cases run the ray pass and, unless provably unnecessary, the fix-up pass
+        if (d.any_rot && p->n_rot_stages > 1) {
+            HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, unit_args(u, n), n, st));
+            continue;
+        }
+        std::unique_lock<std::mutex> flags_lk(p->flags_mu, std::defer_lock);
+        if (d.need_fixup) {
+            flags_lk.lock();
+            if (p->flags_pending && p->flags_stream != st)
+                HIP_TRY(hipStreamWaitEvent(st, p->flags_ev, 0));
+        }
+        uint32_t* flags = d.need_fixup ? p->ctx.tile_flags : nullptr;
+        LaunchUnits lu{u, nullptr, n};
+        int slot = -1;
+        if (d.fast && n > kInlineUnits) {
+            int rc = ring_put(p, st, u, n, &lu.dev, &slot);
             if (rc)
                 return rc;
-            any_rot |= ua.u[k].has_rot != 0;
         }
-        if (p->mode == MODE_RAY) {
-            // units overriding one of SEVERAL rotate stages take the interpreter (rare); all other
-            // cases run the ray pass and, unless provably unnecessary, the fix-up pass
-            if (any_rot && p->n_rot_stages > 1) {
-                HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, ua, n, st));
-                continue;
-            }
-            // hand-tuned tile kernels; 32-bit source and destination offsets
-            const Geom& g = p->ctx.g;
-            bool fast = p->tile_boxes != nullptr && !p->disable_fast;
-            for (int k = 0; k < n && fast; k++)
-                fast = (uint64_t)g.src_h * (uint64_t)ua.u[k].src_pitch < 0xFFFFFF00ull && ua.u[k].src_pitch < (1 << 24) &&
-                       (uint64_t)g.dst_h * (uint64_t)ua.u[k].dst_pitch < 0xFFFFFF00ull && ua.u[k].dst_pitch < (1 << 24);
-            // the fix-up pass is skipped when no pixel can land in a flagged table interval: proven at
-            // plan time for the chain's own rotation, per unit for overriding rotations; likewise
-            // `shared_entry` (one table entry per lane, no per-pixel fallback in the kernel)
-            bool need_fixup = !(p->ray_no_rot_safe || p->ray_plan_rot_safe);
-            bool shared_entry = p->plan_shared_entry;
-            // the m-polynomial table (no fp64 index arithmetic) serves a launch of overriding rotations
-            // when every interval up to each unit's reach is valid at the level the lanes need
-            bool mpoly_all = any_rot && p->ctx.ray.radial_m != nullptr;
-            // every pixel's |32 x|, |32 y| provably below 2^21 (half the cvRound trick's range): |x32 - cx32| <= |G| |rx32| with G bounded
-            // over every table entry in reach
-            bool coords_bounded = any_rot;
-            if (any_rot) {
-                need_fixup = !p->front_hemisphere;
-                shared_entry = p->front_hemisphere;
-                for (int k = 0; k < n && !need_fixup; k++) {
-                    const double* r = ua.u[k].has_rot ? ua.u[k].rot : p->ana.rot;
-                    const bool rotated = ua.u[k].has_rot || p->ana.has_rot;
-                    const bool covered = rotated ? ray_reach_is_safe(p->table, rotated_reach(r)) : p->ray_no_rot_safe;
-                    need_fixup = !covered;
-                    if (coords_bounded) {
-                        const RayParams& rp = p->ctx.ray;
-                        const double gb = covered ? radial_table_g_bound(p->table, p->g_bounds, rotated ? rotated_reach(r) : p->m_reach_norot) : INFINITY;
-                        coords_bounded = gb * std::fabs(rp.rx32) + std::fabs(rp.cx32) < 2097152.0 && gb * std::fabs(rp.ry32) + std::fabs(rp.cy32) < 2097152.0;
-                    }
-                    shared_entry = shared_entry && covered &&
-                                   (rotated ? ray_entry_is_shared(p->table, rotated_reach(r), p->ray_step) : p->plan_shared_entry);
-                    if (mpoly_all) {  // (same interval bound as mpoly_first_ok: reach + 2 for the fp32 index)
-                        const double mr = rotated ? rotated_reach(r) : p->m_reach_norot;
-                        const double u_reach = (p->table.var_is_w ? std::sqrt(mr / 2) : mr) * (1 + 1e-9);
-                        mpoly_all = covered && std::min(p->table.n_int - 1, (int)(u_reach * p->table.inv_step) + 2) <= p->mp_valid_upto;
-                    }
-                }
-                shared_entry = shared_entry && !need_fixup;
-                mpoly_all = mpoly_all && shared_entry;
-            }
-            std::unique_lock<std::mutex> flags_lk(p->flags_mu, std::defer_lock);
-            if (need_fixup) {
-                flags_lk.lock();
-                if (p->flags_pending && p->flags_stream != st)
-                    HIP_TRY(hipStreamWaitEvent(st, p->flags_ev, 0));
-            }
-            // a pair (apply_lr) of an unrotated chain: the tile + mirror-image launch
-            // (a single image -- apply() of one image, BASELINE config 1 -- takes the LDS-DMA form's one-eye instantiation)
-            bool mirror = fast && (n == 2 || (n == 1 && p->mirror_raw_nwp > 0 && p->n_mirror_rest1 >= 0)) && !any_rot &&
-                          p->mirror_boxes != nullptr && shared_entry && !p->disable_shared_entry;
-            for (int k = 0; k < n && mirror; k++)
-                mirror = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
-            if (mirror) {
-                HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, ua, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h,
-                                                    n == 1 ? p->mirror_rest1 : p->mirror_rest, n == 1 ? p->n_mirror_rest1 : p->n_mirror_rest,
-                                                    p->mirror_raw_nwp, p->mirror_pipe_tab, st, n, p->mirror_seq_kb));
-            } else if (fast && p->ctx.g.cn != 3) {
-                // grayscale / BGRA: k_ray_lin_cn (plan-time boxes: the plan's own rotation only; one table entry per lane)
-                bool cn_ok = p->cn_kb > 0 && !any_rot && shared_entry && !p->disable_shared_entry;
-                for (int k = 0; k < n && cn_ok; k++)
-                    cn_ok = ((((uintptr_t)ua.u[k].src) | (uintptr_t)ua.u[k].src_pitch) & 3u) == 0;
-                if (cn_ok)
-                    HIP_TRY(launch_ray_lin_cn(p->ctx, ua, n, p->ana.has_rot, p->tile_boxes, p->cn_kb, st));
-                else
-                    HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
-            } else if (fast) {
-                // precomputed tile boxes describe the plan's own rotation only
-                HIP_TRY(launch_ray_lin3_tile(p->ctx, ua, n, any_rot || p->ana.has_rot, any_rot ? nullptr : p->tile_boxes, p->half_dwords,
-                                             shared_entry && !p->disable_shared_entry, mpoly_all && !p->disable_mpoly,
-                                             any_rot ? nullptr : p->rest_list, p->n_rest, p->lean_half, p->strip_len, p->lean_raw_nwp, st,
-                                             coords_bounded && !p->disable_coords_bounded));
-            } else {
-                HIP_TRY(launch_remap(MODE_RAY, p->ctx, ua, n, st));
-            }
-            if (need_fixup) {
-                HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, ua, n, st));
-                HIP_TRY(hipEventRecord(p->flags_ev, st));
-                p->flags_stream = st, p->flags_pending = true;
-            }
+        const bool shared = d.shared_entry && !p->disable_shared_entry;
+        bool aligned = true;  // every source and its pitch dword-aligned (LDS-DMA kernels)
+        for (int k = 0; k < n && aligned; k++)
+            aligned = ((((uintptr_t)u[k].src) | (uintptr_t)u[k].src_pitch) & 3u) == 0;
+        // a pair (apply_lr) of an unrotated chain: the tile + mirror-image launch
+        // (a single image -- apply() of one image, BASELINE config 1 -- takes the LDS-DMA form's one-eye instantiation)
+        const bool mirror = d.fast && (n == 2 || (n == 1 && p->mirror_raw_nwp > 0 && p->n_mirror_rest1 >= 0)) && !d.any_rot &&
+                            p->mirror_boxes != nullptr && shared && aligned;
+        if (mirror) {
+            HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, p->ctx_dev, lu, flags, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h,
+                                                n == 1 ? p->mirror_rest1 : p->mirror_rest, n == 1 ? p->n_mirror_rest1 : p->n_mirror_rest,
+                                                p->mirror_raw_nwp, st, p->mirror_seq_kb));
+        } else if (d.fast && p->ctx.g.cn != 3) {
+            // grayscale / BGRA: k_ray_lin_cn (plan-time boxes: the plan's own rotation only; one table entry per lane)
+            if (p->cn_kb > 0 && !d.any_rot && shared && aligned)
+                HIP_TRY(launch_ray_lin_cn(p->ctx, p->ctx_dev, lu, flags, p->ana.has_rot, p->tile_boxes, p->cn_kb, st));
+            else
+                HIP_TRY(launch_remap(MODE_RAY, p->ctx, unit_args(u, n), n, st));
+        } else if (d.fast) {
+            // precomputed tile boxes describe the plan's own rotation only
+            HIP_TRY(launch_ray_lin3_tile(p->ctx, p->ctx_dev, lu, flags, d.any_rot || p->ana.has_rot, d.any_rot ? nullptr : p->tile_boxes,
+                                         p->half_dwords, shared, d.mpoly_all && !p->disable_mpoly, d.any_rot ? nullptr : p->rest_list, p->n_rest,
+                                         p->lean_half, p->strip_len, p->lean_raw_nwp, st, d.coords_bounded && !p->disable_coords_bounded));
         } else {
-            HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, ua, n, st));
+            HIP_TRY(launch_remap(MODE_RAY, p->ctx, unit_args(u, n), n, st));
+        }
+        if (slot >= 0) {
+            int rc = ring_done(p, st, slot);
+            if (rc)
+                return rc;
+        }
+        if (d.need_fixup) {
+            HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, unit_args(u, n), n, st));
+            HIP_TRY(hipEventRecord(p->flags_ev, st));
+            p->flags_stream = st, p->flags_pending = true;
         }
     }
     return V1C_OK;
