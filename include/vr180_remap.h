@@ -163,11 +163,15 @@ int v1c_plan_destroy(v1c_plan* plan);
  * "ray" path (separable tables + radial table), 2 = fused "planar" path.  For tests/bench. */
 int v1c_plan_path(const v1c_plan* plan);
 
-/* Enqueue the fused chain+gather for n_units independent units (one launch, grid.z = units).
- * Replaces: get_map() + the cv.remap list comprehension, remapper.py:381-398, and the SBS
- * concatenate of apply_lr, remapper.py:517-518 (via dst/dst_pitch).
- * `units` is a HOST array; it is copied into a plan-owned device ring slot asynchronously on
- * `stream`, so the call is launch-only (no allocation, no sync).                            */
+/* Enqueue the fused chain+gather for n_units independent units: ONE launch for up to 256 units
+ * (longer arrays: one launch per 256; 16 per launch where a fix-up pass or the generic kernels
+ * are needed).  Replaces: get_map() + the cv.remap list comprehension, remapper.py:381-398, and
+ * the SBS concatenate of apply_lr, remapper.py:517-518 (via dst/dst_pitch).
+ * `units` is a HOST array, read before the call returns: up to 16 units travel in the launch's
+ * kernel arguments; longer batches are copied into a slot of a plan-owned device ring by small
+ * launches on `stream` in front of the remap launch.  The call is launch-only (no allocation,
+ * no sync) and may be recorded into a graph (at most 4 recorded launches of more than 16 units
+ * per plan: each keeps its ring slot).  One plan may be run from several threads / streams.   */
 int v1c_plan_run(v1c_plan* plan, void* stream, const v1c_unit* units, int n_units);
 
 /* Evaluate only the coordinate chain on the output grid and store float32 maps (device
@@ -177,12 +181,16 @@ int v1c_plan_get_map(v1c_plan* plan, void* stream, float* xmap, float* ymap,
                      int64_t map_pitch, const double* rot_or_null);
 
 /* One-shot convenience: plan lookup/creation in an internal cache keyed on every argument
- * but the pointers, then v1c_plan_run on one unit.  Same replacement as above.              */
+ * but the pointers (the 32 most recently used plans are kept; an evicted plan is destroyed once
+ * no call uses it any more), then v1c_plan_run on one unit.  Same replacement as above.       */
 int v1c_remap_fused(int device, void* stream,
                     const uint8_t* src, int src_h, int src_w, int64_t src_pitch, int cn,
                     uint8_t* dst, int dst_h, int dst_w, int64_t dst_pitch,
                     const v1c_chain* chain, int interp, int border_mode,
                     const uint8_t border_val[4]);
+
+/* Number of plans the one-shot cache of v1c_remap_fused holds right now (<= 32).  For tests. */
+int v1c_fused_cache_size(void);
 
 /* cv2.remap with caller-supplied float32 maps (device pointers).  Replaces the cv.remap call
  * itself, remapper.py:388-398, for transformer chains the engine cannot lower (user-defined
@@ -194,11 +202,17 @@ int v1c_remap_lut(int device, void* stream,
                   int interp, int border_mode, const uint8_t border_val[4]);
 
 /* Auto-radius estimate of one device-resident image, get_radius() transformer.py:108-140
- * (centre row / column scan, threshold on the channel mean, sign quirk preserved).
+ * (centre row / column scan on the device, threshold on the channel mean, sign quirk preserved).
  * Synchronous: returns the value through *radius.  Returns V1C_E_INVALID with the message
  * "no black border" where the reference raises IndexError.                                  */
 int v1c_get_radius(int device, void* stream, const uint8_t* img, int h, int w,
                    int64_t pitch, int cn, int threshold, double* radius);
+/* The same scan with the result left on the device and nothing synchronised (graph-capturable):
+ * out_dev[0] = the radius, out_dev[1] = 0.0 -- or out_dev[0] = NaN, out_dev[1] = 1.0 where the
+ * reference raises IndexError.  `out_dev`: two doubles in device (or mapped host) memory.  The
+ * scan itself (both forms) is one small kernel: transformer.py:125-140 never leaves the GPU.  */
+int v1c_get_radius_async(int device, void* stream, const uint8_t* img, int h, int w,
+                         int64_t pitch, int cn, int threshold, double* out_dev);
 
 /* merge=True of apply_lr(), remapper.py:485-497: red/cyan anaglyph of two remapped eyes, both
  * (h, w, 3) uint8 on the device; `out` is (h, w, 3) float64 with row pitch out_pitch BYTES:

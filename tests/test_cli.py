@@ -106,11 +106,176 @@ def test_automatch_split_and_missing_cv2():
     assert [type(s).__name__ for s in tail.transformers] == ["PolynomialScaler", "InverseTransformer"]
     with pytest.raises(ValueError):
         cli.split_at_first_encoder(T.ZoomTransformer(2.0))
-    try:
-        import cv2  # noqa: F401
-    except Exception:  # noqa: BLE001
-        with pytest.raises(Exception, match="OpenCV"):
-            cli._points_from_option("fm0.5", Path("a"), Path("b"))
+
+
+class _FakeCv2:
+    """Records what the CLI's OpenCV front ends (calibration_cv.py) hand to cv2: a stand-in module, no arithmetic."""
+    WND_PROP_FULLSCREEN, WINDOW_FULLSCREEN, EVENT_LBUTTONDOWN = 0, 1, 1
+
+    def __init__(self, clicks=()):
+        self.calls, self.clicks, self.callback, self.shown = [], list(clicks), None, 0
+
+    # --- AKAZE + BFMatcher
+    def resize(self, image, size):
+        self.calls.append(("resize", size))
+        return np.zeros((size[1], size[0], 3), np.uint8)
+
+    def AKAZE_create(self):
+        fake = self
+
+        class Det:
+            def detectAndCompute(self, image, mask):
+                fake.calls.append(("detect", image.shape))
+                n = 12
+                kps = [type("KP", (), {"pt": (10.0 + 3 * i, 20.0 + 2 * i)})() for i in range(n)]
+                return kps, np.zeros((n, 61), np.uint8)
+        return Det()
+
+    def BFMatcher(self):
+        class BF:
+            def match(self, d1, d2):
+                return [type("M", (), {"queryIdx": i, "trainIdx": (i + 1) % len(d2)})() for i in range(len(d1))]
+        return BF()
+
+    def drawMatches(self, img_l, kp_l, img_r, kp_r, matches, out):
+        self.calls.append(("drawMatches", len(matches)))
+        return np.full((8, 16, 3), 7, np.uint8)
+
+    # --- window
+    def imread(self, p):
+        return np.zeros((4, 4, 3), np.uint8)
+
+    def namedWindow(self, *a):
+        self.calls.append(("namedWindow",) + a)
+
+    def setWindowProperty(self, *a):
+        pass
+
+    def setMouseCallback(self, title, cb):
+        self.callback = cb
+
+    def imshow(self, title, im):
+        self.shown += 1
+
+    def waitKey(self, ms):
+        x, y = self.clicks.pop(0)
+        self.callback(self.EVENT_LBUTTONDOWN, x, y, 0, None)
+
+    def destroyAllWindows(self):
+        self.calls.append(("destroyAllWindows",))
+
+
+def test_automatch_front_ends_report_a_missing_opencv(tmp_path, monkeypatch):
+    """Without cv2 (the GPU image): --automatch fm / gui say which package is missing; --savematch without fm is a usage error
+    instead of an option that silently does nothing."""
+    import builtins
+
+    from vr180_convert_amd.synth import pattern
+
+    real_import = builtins.__import__
+    monkeypatch.setattr(builtins, "__import__", lambda name, *a, **k: (_ for _ in ()).throw(ImportError("no cv2")) if name == "cv2" else real_import(name, *a, **k))
+    monkeypatch.delitem(sys.modules, "cv2", raising=False)
+    img = tmp_path / "a.png"
+    _io.imwrite(img, pattern(64, 64))
+    for opt in ("fm0.5", "gui"):
+        r = runner.invoke(cli.app, ["lr", str(img), str(img), "--radius", "max", "--size", "32x32", "--automatch", opt])
+        assert r.exit_code != 0 and "OpenCV" in (r.stdout + str(r.exception) + getattr(r, "stderr", "")), (opt, r.stdout, r.exception)
+    r = runner.invoke(cli.app, ["lr", str(img), str(img), "--radius", "max", "--size", "32x32", "--savematch"])
+    assert r.exit_code != 0 and "savematch" in (r.stdout + str(r.exception) + getattr(r, "stderr", ""))
+
+
+def test_automatch_fm_gui_and_savematch_glue_with_a_stand_in_cv2(tmp_path, monkeypatch):
+    """With cv2 importable the front ends work as in the reference (cli.py:255-304, 362-365): `fm<scale>` resizes, matches, un-scales
+    the points, fits robustly and -- with --savematch -- writes <out>.match<ext>; `gui<n>` collects 2 n clicks, even ones for the left
+    eye.  cv2 is a recording stand-in: the glue is what is under test."""
+    import vr180_convert_amd.remapper as R
+    from vr180_convert_amd import calibration_cv as CV
+    from vr180_convert_amd.synth import pattern
+
+    fake = _FakeCv2()
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    # match_points: scaled detection, points back in original pixels
+    a = np.zeros((100, 200, 3), np.uint8)
+    p1, p2, kp1, kp2, matches, s1, s2 = CV.match_points(a, a, scale=0.5)
+    assert fake.calls[:2] == [("resize", (100, 50)), ("resize", (100, 50))] and s1.shape == (50, 100, 3)
+    assert np.allclose(p1[0], (10.0 / 0.5, 20.0 / 0.5)) and np.allclose(p2[0], (13.0 / 0.5, 22.0 / 0.5)) and len(matches) == 12
+    # the window: one click per image, in order
+    fake.clicks = [(1, 2), (3, 4), (5, 6), (7, 8)]
+    assert CV.pick_points_gui([a, a, a, a]) == [(1, 2), (3, 4), (5, 6), (7, 8)] and fake.shown == 4
+    # the CLI around them
+    calls = []
+    monkeypatch.setattr(R, "apply_lr", lambda *args, **k: calls.append(k))
+    l, r_ = tmp_path / "L.png", tmp_path / "R.png"
+    _io.imwrite(l, pattern(128, 128)), _io.imwrite(r_, pattern(128, 128))
+    out = tmp_path / "o.png"
+    fake.calls.clear()
+    res = runner.invoke(cli.app, ["lr", str(l), str(r_), "--radius", "max", "--size", "64x64", "--automatch", "fm0.25", "--savematch", "--out-path", str(out)])
+    assert res.exit_code == 0, (res.stdout, res.exception)
+    assert ("resize", (32, 32)) in fake.calls and any(c[0] == "drawMatches" and c[1] <= 100 for c in fake.calls)
+    assert (tmp_path / "o.match.png").exists() and isinstance(calls[0]["transformer"] if "transformer" in calls[0] else None, (tuple, type(None)))
+    fake.clicks = [(60, 60), (62, 61), (70, 50), (73, 52), (40, 80), (42, 83)]
+    fake.shown = 0
+    res = runner.invoke(cli.app, ["lr", str(l), str(r_), "--radius", "max", "--size", "64x64", "--automatch", "gui3", "--out-path", str(out)])
+    assert res.exit_code == 0 and fake.shown == 6, (res.stdout, res.exception)
+
+
+def test_xmp_command_glue_with_a_stand_in_libxmp(tmp_path, monkeypatch):
+    """The xmp command (cli.py:439-540): left half written as <name>.xmp<ext>, the right half embedded base64 in GImage:Data, the
+    GPano block of a (height, width) side-by-side frame.  libxmp is a recording stand-in; without it the command names the package."""
+    import base64
+    import types
+
+    from vr180_convert_amd import calibration_cv as CV
+    from vr180_convert_amd.synth import pattern
+
+    sbs = np.concatenate([pattern(64, 96), pattern(64, 96)[:, ::-1]], axis=1)
+    p = tmp_path / "pair.png"
+    _io.imwrite(p, sbs)
+    res = runner.invoke(cli.app, ["xmp", str(p)])
+    if "libxmp" not in sys.modules:
+        assert res.exit_code != 0 and "python-xmp-toolkit" in (res.stdout + str(res.exception) + getattr(res, "stderr", ""))
+    props: dict = {}
+    state = {"files": [], "put": 0, "closed": 0, "ns": []}
+
+    class XMPMeta:
+        @staticmethod
+        def register_namespace(uri, prefix):
+            state["ns"].append((uri, prefix))
+
+        def set_property(self, ns, name, value):
+            props[(ns, name)] = value
+
+        def set_property_int(self, ns, name, value):
+            props[(ns, name)] = ("int", value)
+
+    class XMPFiles:
+        def __init__(self, file_path, open_forupdate):
+            state["files"].append((file_path, open_forupdate))
+
+        def can_put_xmp(self, meta):
+            return True
+
+        def put_xmp(self, meta):
+            state["put"] += 1
+
+        def close_file(self):
+            state["closed"] += 1
+
+    monkeypatch.setitem(sys.modules, "libxmp", types.SimpleNamespace(XMPFiles=XMPFiles, XMPMeta=XMPMeta))
+    res = runner.invoke(cli.app, ["xmp", str(p)])
+    assert res.exit_code == 0, (res.stdout, res.exception)
+    left = tmp_path / "pair.xmp.png"
+    assert state["files"] == [(left.as_posix(), True)] and state["put"] == 1 and state["closed"] == 1
+    assert np.array_equal(_io.imread(left), sbs[:, :96])
+    assert props[(CV.XMP_GPANO, "ProjectionType")] == "equirectangular" and props[(CV.XMP_GPANO, "FullPanoWidthPixels")] == ("int", 192)
+    assert props[(CV.XMP_GPANO, "CroppedAreaImageWidthPixels")] == ("int", 96.0) and props[(CV.XMP_GPANO, "CroppedAreaLeftPixels")] == ("int", 48.0)
+    assert props[(CV.XMP_GPANO, "FullPanoHeightPixels")] == ("int", 64) and props[(CV.XMP_GPANO, "InitialViewHeadingDegrees")] == ("int", 180)
+    assert props[(CV.XMP_GIMAGE, "Mime")] == "image/jpeg" and props[(CV.XMP_NOTE, "HasExtendedXMP")] == "06A56CB0A1A7FAFDA459CA3FAA14B474"
+    # the embedded right half decodes back to the right half
+    right_file = tmp_path / "right.png"
+    right_file.write_bytes(base64.b64decode(props[(CV.XMP_GIMAGE, "Data")]))
+    assert np.array_equal(_io.imread(right_file), sbs[:, 96:])
+    assert {pfx for _, pfx in state["ns"]} == {"GImage", "GPano", "xmpNote"}
 
 
 @pytest.mark.gpu

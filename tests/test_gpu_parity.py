@@ -1017,7 +1017,7 @@ def test_c4_full_size_eye_vs_oracle(V, oracle_mod, dev):
 
 
 def test_c5_full_size_units_vs_oracle(V, oracle_mod, dev):
-    """BASELINE config 5 at its real size: both eyes of a 7680 x 3840 SBS frame (2 x 3840^2), each with
+    """BASELINE config 5 at its real size: FOUR 7680 x 3840 SBS frames (8 units of 3840^2 in one launch), every eye with
     its own calibration rotation (cli.py:308-319 pseudo-half quaternions), bilinear -- through the
     rotations= path that shares one plan -- against the oracle evaluating each unit's own chain."""
     from vr180_convert_amd import transformer as T
@@ -1027,25 +1027,28 @@ def test_c5_full_size_units_vs_oracle(V, oracle_mod, dev):
     _all_cores(O)
     try:
         n = 3840
-        frame = noise_disc(n, 2 * n, 50)
+        fids = (7, 8, 100, 255)
+        host = [noise_disc(n, 2 * n, 50 + f) for f in fids]
         base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
-        quats = [CS.c5_spec(7, eye)[1][1] for eye in (0, 1)]
-        fr = torch.from_numpy(frame).to(dev)
-        out = torch.empty((n, 2 * n, 3), dtype=torch.uint8, device=dev)
-        assert V.remap_tensors(base, [fr[:, :n], fr[:, n:]], [out[:, :n], out[:, n:]], radius=n / 2, interpolation=1,
-                               rotations=quats) == ["ray"]
-        got = out.cpu().numpy()
-        for eye in (0, 1):
-            want = O.apply(CS.c5_spec(7, eye), [frame[:, eye * n:(eye + 1) * n]], size_output=(n, n), interpolation=1, radius="max")[0]
-            assert np.array_equal(got[:, eye * n:(eye + 1) * n], want), (eye, int((got[:, eye * n:(eye + 1) * n] != want).sum()))
+        quats = [CS.c5_spec(f, eye)[1][1] for f in fids for eye in (0, 1)]
+        frs = [torch.from_numpy(h).to(dev) for h in host]
+        outs = [torch.empty((n, 2 * n, 3), dtype=torch.uint8, device=dev) for _ in frs]
+        srcs = [v for fr in frs for v in (fr[:, :n], fr[:, n:])]
+        dsts = [v for o in outs for v in (o[:, :n], o[:, n:])]
+        assert V.remap_tensors(base, srcs, dsts, radius=n / 2, interpolation=1, rotations=quats) == ["ray"]
+        for k, f in enumerate(fids):
+            got = outs[k].cpu().numpy()
+            for eye in (0, 1):
+                want = O.apply(CS.c5_spec(f, eye), [host[k][:, eye * n:(eye + 1) * n]], size_output=(n, n), interpolation=1, radius="max")[0]
+                assert np.array_equal(got[:, eye * n:(eye + 1) * n], want), (f, eye, int((got[:, eye * n:(eye + 1) * n] != want).sum()))
     finally:
         O.set_threads(min(8, __import__("os").cpu_count() or 1))
 
 
 def test_c3_full_size_frames_vs_oracle(V, oracle_mod, dev):
     """BASELINE config 3 at its real size: SBS frames of 5760 x 2880 split into halves (remapper.py:448-456),
-    one shared equidistant map, bilinear, through the lean batch kernel (8 frames = 16 units in one launch);
-    three of the units against the oracle."""
+    one shared equidistant map, bilinear, through the lean batch kernel (8 frames = 16 units in one launch: one rank's
+    share of the 64 frames); ALL 16 units against the oracle."""
     from vr180_convert_amd import transformer as T
     from vr180_convert_amd.synth import noise_disc
 
@@ -1062,7 +1065,7 @@ def test_c3_full_size_frames_vs_oracle(V, oracle_mod, dev):
         assert V.remap_tensors(t, srcs, dsts, radius=n / 2, interpolation=1) == ["ray"]
         spec = [("equirect_enc", True), ("fisheye_dec", "equidistant")]
         xm, ym = O.get_map(spec, radius=n / 2, size_input=(n, n), size_output=(n, n))
-        for f, eye in ((0, 0), (3, 1), (7, 1)):
+        for f, eye in [(f, e) for f in range(8) for e in (0, 1)]:
             want = O.remap(host[f][:, eye * n:(eye + 1) * n], xm, ym, 1)
             got = outs[f][:, eye * n:(eye + 1) * n].cpu().numpy()
             assert np.array_equal(got, want), (f, eye)
@@ -1282,6 +1285,26 @@ def test_remap_sharded_on_the_devices_there_are(V, oracle_mod):
         w = np.concatenate([O.apply(CS.c5_spec(f, eye), [frames[f][:, eye * n:(eye + 1) * n]], size_output=(64, 64), interpolation=1,
                                     radius=n / 2)[0] for eye in (0, 1)], axis=1)
         assert np.array_equal(got[f], w), f
+
+
+def test_remap_sharded_32_frames_with_rotations_two_workers(V, oracle_mod):
+    """One rank's share of BASELINE config 5 -- 32 frames, a calibration rotation per eye -- through the dispatch an 8-GPU node
+    runs (remap_sharded: frames over workers, host ring, rotations= batches; here two workers share the one card), every
+    frame against the oracle."""
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    n, w, h = 192, 160, 144
+    frames = [noise_disc(n, 2 * n, 500 + f) for f in range(32)]
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    rots = [tuple(CS.c5_spec(f, eye)[1][1] for eye in (0, 1)) for f in range(32)]
+    got = V.remap_sharded(base, frames, size_output=(w, h), interpolation=1, radius=n / 2, rotations=rots, devices=[0, 0])
+    assert len(got) == 32
+    for f in range(32):
+        want = np.concatenate([O.apply(CS.c5_spec(f, eye), [frames[f][:, eye * n:(eye + 1) * n]], size_output=(w, h), interpolation=1,
+                                       radius=n / 2)[0] for eye in (0, 1)], axis=1)
+        assert np.array_equal(got[f], want), f
 
 
 @pytest.mark.parametrize("split,workload", [("eyes", "C1"), ("bands", "C1"), ("frames", "C1S")])

@@ -209,3 +209,32 @@ def test_io_many_round_trip(tmp_path):
     assert _io.imread(tmp_path / "missing.png") is None  # cv2.imread's contract
     _io.imwrite(tmp_path / "q.jpg", imgs[0])
     assert _io.imread(tmp_path / "q.jpg").shape == (37, 41, 3)
+
+
+def test_estimator_surface_of_the_transformers():
+    """The reference's TransformerBase is an sklearn BaseEstimator / TransformerMixin (transformer.py:11-18): get_params / set_params /
+    fit_transform and sklearn.base.clone work on the drop-in classes too."""
+    t = T.PolynomialScaler([0, 1, -0.1])
+    assert t.get_params() == {"coefs_reverse": [0, 1, -0.1]}
+    assert t.set_params(coefs_reverse=[0, 2]) is t and t.coefs_reverse == [0, 2]
+    with pytest.raises(ValueError, match="Invalid parameter"):
+        t.set_params(nope=1)
+    enc = T.FisheyeEncoder("equisolid")
+    assert enc.get_params() == {"mapping_type": "equisolid"}
+    inv = T.InverseTransformer(T.ZoomTransformer(2.0))
+    p = inv.get_params()
+    assert p["transformer__scale"] == 2.0 and isinstance(p["transformer"], T.ZoomTransformer)
+    inv.set_params(transformer__scale=4.0)
+    assert inv.transformer.scale == 4.0
+    x, y = np.array([0.5, 1.0]), np.array([0.25, -1.0])
+    fx, fy = T.ZoomTransformer(2.0).fit_transform(x, y)
+    assert np.array_equal(fx, x / 2.0) and np.array_equal(fy, y / 2.0)
+    chain = T.EquirectangularEncoder() * T.ZoomTransformer(1.5)
+    assert list(chain.get_params(deep=False)) == ["transformers"]
+    assert "ZoomTransformer(scale=1.5)" in repr(chain)
+    try:
+        from sklearn.base import clone
+    except Exception:  # noqa: BLE001
+        return
+    c = clone(T.ZoomTransformer(3.0))
+    assert isinstance(c, T.ZoomTransformer) and c.scale == 3.0

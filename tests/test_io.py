@@ -78,3 +78,60 @@ def test_npy_round_trip_and_unreadable_files(tmp_path):
     assert _io.imread(tmp_path / "missing.png") is None and _io.imread(tmp_path / "missing.npy") is None
     np.save(tmp_path / "float.npy", np.zeros((4, 4), np.float32))
     assert _io.imread(tmp_path / "float.npy") is None  # images are uint8
+
+
+def test_parallel_png_reader_refuses_forged_band_directories(tmp_path):
+    """A crafted file must come back as None (-> the general decoder), not as a huge allocation or an inflated zip bomb: header
+    dimensions far beyond what the compressed bytes could hold, and a band whose stream inflates to more than its rows."""
+    import struct
+    import zlib
+
+    from vr180_convert_amd import _png
+
+    img = (np.arange(64 * 48 * 3) % 251).astype(np.uint8).reshape(64, 48, 3)
+    good = _png.encode(img, level=1)
+    assert np.array_equal(_png.decode(good), img)
+
+    def chunks(data):
+        pos, out = 8, []
+        while pos < len(data):
+            n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+            out.append((kind, data[pos + 8:pos + 8 + n]))
+            pos += 12 + n
+        return out
+
+    def build(parts):
+        b = data_sig
+        for kind, body in parts:
+            b += struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+        return b
+
+    data_sig = good[:8]
+    parts = chunks(good)
+    # (1) header says 30000 x 30000 for the same few hundred compressed bytes, band directory stretched to match
+    forged = []
+    for kind, body in parts:
+        if kind == b"IHDR":
+            body = struct.pack(">IIBBBBB", 30000, 30000, 8, 2, 0, 0, 0)
+        elif kind == b"vrBD":
+            ver, ftype, nb = struct.unpack(">BBI", body[:6])
+            bands = [list(struct.unpack(">III", body[6 + 12 * k:18 + 12 * k])) for k in range(nb)]
+            bands[-1][1] = 30000
+            body = struct.pack(">BBI", ver, ftype, nb) + b"".join(struct.pack(">III", *b) for b in bands)
+        forged.append((kind, body))
+    assert _png.decode(build(forged)) is None
+    # (2) a band's deflate stream replaced by one that inflates to 50 MB of zeros
+    bomb = zlib.compressobj(9, zlib.DEFLATED, -15)
+    payload = bomb.compress(bytes(50 << 20)) + bomb.flush()
+    forged = []
+    for kind, body in parts:
+        if kind == b"IDAT":
+            body = body[:2] + payload + body[-4:]
+        elif kind == b"vrBD":
+            ver, ftype, nb = struct.unpack(">BBI", body[:6])
+            body = struct.pack(">BBI", ver, ftype, 1) + struct.pack(">III", 0, 64, 2)
+        forged.append((kind, body))
+    assert _png.decode(build(forged)) is None
+    p = tmp_path / "bomb.png"
+    p.write_bytes(build(forged))
+    assert _png.read(p) is None

@@ -1,0 +1,68 @@
+"""Register / scratch budget and kernel-argument layout of the product's gfx950 code objects, read from their metadata notes.
+
+Round 3 ended with two instantiations of the per-unit-rotation kernel in scratch and 32 kernels spilling scalar registers into vector
+lanes (the by-value KernelCtx + UnitArgs arguments pinned 98 of the 102 SGPRs).  Since round 4 the tile kernels read one TileArgs block
+through constant-address-space references (csrc/kernels.hpp); this test keeps it that way:
+
+* no kernel of the shipped library uses scratch or spills a register (the -DV1C_TUNING twin may: its general batch loop is an A/B form);
+* the tile kernels' one by-value argument sits at byte 0 of the kernel-argument segment and k_put_units' records at byte 8 -- the
+  kernels address them through ``__builtin_amdgcn_kernarg_segment_ptr()`` at exactly those offsets.
+"""
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+import yaml
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "vr180_convert_amd" / "csrc"
+LLVM = Path("/opt/rocm/lib/llvm/bin")
+
+
+def kernel_metadata(tmp: Path, obj: Path) -> list[dict]:
+    if not (LLVM / "llvm-readelf").exists():
+        pytest.skip("llvm-readelf not available")
+    shutil.copy(obj, tmp / "o.o")
+    subprocess.run([str(LLVM / "llvm-objdump"), "--offloading", "o.o"], cwd=tmp, check=True, capture_output=True, timeout=300)
+    code = [p for p in tmp.iterdir() if "gfx950" in p.name]
+    assert len(code) == 1
+    r = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", code[0].name], cwd=tmp, check=True, capture_output=True, text=True, timeout=300)
+    text = r.stdout
+    doc = text[text.index("---"):]
+    doc = doc[: doc.index("\n...")] if "\n..." in doc else doc
+    return yaml.safe_load(doc)["amdhsa.kernels"]
+
+
+@pytest.fixture(scope="module")
+def product_kernels(tmp_path_factory, product_lib):
+    out = []
+    for name in ("kernels_tile.o", "kernels.o"):
+        obj = CSRC / name
+        assert obj.exists(), f"{name} is built by __graft_entry__.build() / make"
+        out += kernel_metadata(tmp_path_factory.mktemp("meta"), obj)
+    return out
+
+
+def test_no_kernel_of_the_product_uses_scratch_or_spills(product_kernels):
+    assert len(product_kernels) > 100
+    bad = [(k[".name"], k[".private_segment_fixed_size"], k[".sgpr_spill_count"], k[".vgpr_spill_count"]) for k in product_kernels
+           if k[".private_segment_fixed_size"] or k[".sgpr_spill_count"] or k[".vgpr_spill_count"]]
+    # the literal interpreter (generic k_remap / k_get_map in MODE_LITERAL / MODE_FIXUP) keeps the lowered chain's op loop and libm calls:
+    # a slow path by construction, allowed its spills
+    bad = [b for b in bad if "k_remap" not in b[0] and "k_get_map" not in b[0]]
+    assert not bad, bad
+
+
+def test_tile_kernels_take_one_argument_block_at_offset_zero(product_kernels):
+    tile = [k for k in product_kernels if "8TileArgsE" in k[".name"]]
+    assert len(tile) > 100
+    for k in tile:
+        a0 = k[".args"][0]
+        assert a0[".value_kind"] == "by_value" and a0[".offset"] == 0, k[".name"]
+        assert all(a[".value_kind"].startswith("hidden_") for a in k[".args"][1:]), k[".name"]
+    sizes = {k[".args"][0][".size"] for k in tile}
+    assert len(sizes) == 1
+    put = [k for k in product_kernels if "k_put_units" in k[".name"]]
+    assert len(put) == 1
+    assert put[0][".args"][1][".value_kind"] == "by_value" and put[0][".args"][1][".offset"] == 8 and put[0][".args"][1][".size"] == 1792

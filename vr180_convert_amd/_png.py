@@ -20,6 +20,7 @@ from typing import Any
 import numpy as np
 
 _SIGNATURE = b"\x89PNG\r\n\x1a\n"
+MAX_IMAGE_BYTES = 1 << 31  # raw size the reader accepts (a 16384 x 8192 BGR side-by-side frame is 0.4 GB)
 
 
 def _chunk(kind: bytes, data: bytes) -> bytes:
@@ -156,17 +157,25 @@ def decode(data: bytes, *, threads: int | None = None):
         all(r0 < r1 and 2 <= off <= end for r0, r1, off in bands) and all(a[2] <= b[2] for a, b in zip(bands, bands[1:]))
     if not ok or len(idat) < 6:
         return None
+    # The file is not trusted: a forged band directory must not turn header dimensions into a huge allocation or a band into a zip bomb
+    # (Pillow, which this reader stands in for, refuses images beyond its decompression-bomb limit).  Deflate never expands beyond
+    # ~1032 : 1, so a genuine image's raw size is bounded by its compressed size too; every band is inflated to at most its own
+    # (r1 - r0) * stride bytes + 1.
+    if h * stride > MAX_IMAGE_BYTES or h * stride > 1100 * len(idat) + 1024:
+        return None
     lines = np.empty((h, stride), np.uint8)
     sums = [0] * nb
 
     def inflate(k: int) -> bool:
         r0, r1, off = bands[k]
         stop = bands[k + 1][2] if k + 1 < nb else end
+        want = (r1 - r0) * stride
         try:
-            raw = zlib.decompressobj(-15).decompress(idat[off:stop])
+            dec = zlib.decompressobj(-15)
+            raw = dec.decompress(idat[off:stop], want + 1)  # (bounded: a band that inflates to more is not one of ours)
         except zlib.error:
             return False
-        if len(raw) != (r1 - r0) * stride:
+        if len(raw) != want or dec.unconsumed_tail:
             return False
         sums[k] = zlib.adler32(raw)
         lines[r0:r1] = np.frombuffer(raw, np.uint8).reshape(r1 - r0, stride)
@@ -219,5 +228,5 @@ def read(path: Any, **kw: Any):
     """``decode`` of a file; ``None`` when it is not one of this writer's PNGs (or cannot be read)."""
     try:
         return decode(Path(path).read_bytes(), **kw)
-    except OSError:
+    except (OSError, MemoryError):
         return None

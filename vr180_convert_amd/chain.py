@@ -44,6 +44,51 @@ class TransformerBase(metaclass=ABCMeta):
     def inverse_transform(self, x: NDArray, y: NDArray, **kwargs: Any) -> tuple[NDArray, NDArray]:
         """Map coordinates backward."""
 
+    # ---- the estimator surface the reference inherits from sklearn.base.BaseEstimator / TransformerMixin (transformer.py:11-18) ----
+    # (restated here, without the dependency: parameters = the constructor's arguments, nested ones as <name>__<sub>)
+    @classmethod
+    def _param_names(cls) -> list[str]:
+        import inspect
+
+        if cls.__init__ is object.__init__:
+            return []
+        sig = inspect.signature(cls.__init__)
+        return sorted(p.name for p in sig.parameters.values() if p.name != "self" and p.kind not in (p.VAR_KEYWORD, p.VAR_POSITIONAL))
+
+    def get_params(self, deep: bool = True) -> dict:
+        """Constructor parameters by name; with ``deep`` also those of parameter values that are estimators themselves."""
+        out: dict = {}
+        for name in self._param_names():
+            value = getattr(self, name)
+            if deep and hasattr(value, "get_params") and not isinstance(value, type):
+                out.update((f"{name}__{k}", v) for k, v in value.get_params().items())
+            out[name] = value
+        return out
+
+    def set_params(self, **params: Any) -> "TransformerBase":
+        """Set constructor parameters (``name`` or nested ``name__sub``); unknown names raise ValueError.  Returns self."""
+        valid = self.get_params(deep=True)
+        nested: dict = {}
+        for key, value in params.items():
+            name, delim, sub = key.partition("__")
+            if name not in valid:
+                raise ValueError(f"Invalid parameter {name!r} for estimator {self}. Valid parameters are: {self._param_names()!r}.")
+            if delim:
+                nested.setdefault(name, {})[sub] = value
+            else:
+                setattr(self, name, value)
+                valid[name] = value
+        for name, sub in nested.items():
+            valid[name].set_params(**sub)
+        return self
+
+    def fit(self, *args: Any, **kwargs: Any) -> "TransformerBase":
+        """Nothing to learn (the reference leaves ``fit`` commented out, transformer.py:21-22); present so that ``fit_transform`` works."""
+        return self
+
+    def fit_transform(self, x: NDArray, y: NDArray, **kwargs: Any) -> tuple[NDArray, NDArray]:
+        return self.fit(x, y, **kwargs).transform(x, y, **kwargs)
+
     def __mul__(self, other: "TransformerBase") -> "MultiTransformer":
         # flattening composition, left operand applied first (transformer.py:71-81)
         left = self.transformers if isinstance(self, MultiTransformer) else [self]

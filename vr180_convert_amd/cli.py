@@ -3,15 +3,16 @@ rules of the reference's typer app (reference cli.py:116-559; entry points ``vr1
 pyproject.toml:25-27), so that ``v1c lr left.jpg right.jpg --transformer "..."`` runs unchanged -- the remap
 itself happens on the MI355X through ``apply`` / ``apply_lr``.
 
-What needs OpenCV or libxmp beyond image codecs -- AKAZE feature matching (``--automatch fm``, cli.py:255-262), the
-point-picking window (``--automatch gui``, cli.py:82-113) and the ``xmp`` command (cli.py:439-540) -- is not mirrored (no box
-of this engine's pool could ever execute it): those options report a clear error; explicit points
-(``--automatch "x,y;x,y;..."``) need nothing.
+What is OpenCV or libxmp from end to end -- AKAZE feature matching (``--automatch fm[scale]``, cli.py:255-262, with ``--savematch``),
+the point-picking window (``--automatch gui[n]``, cli.py:82-113) and the ``xmp`` command (cli.py:439-540) -- lives in
+``calibration_cv.py`` behind lazy imports: with the library installed the options work as in the reference, without it they report
+which package is missing (the GPU image of this engine ships neither); explicit points (``--automatch "x,y;x,y;..."``) need nothing.
 """
 from __future__ import annotations
 
 import hashlib
 import logging
+import re
 from datetime import datetime, timezone
 from pathlib import Path
 from typing import Any, List, Optional, Sequence
@@ -23,7 +24,7 @@ from typing_extensions import Annotated
 from . import _abi, _io
 from . import quat as _quat
 from . import transformer as _T
-from .calibration import calibration_rotators, match_lr, rotation_match
+from .calibration import calibration_rotators, match_lr, rotation_match, rotation_match_robust
 from .chain import MultiTransformer
 
 LOG = logging.getLogger(__name__)
@@ -118,26 +119,49 @@ def split_at_first_encoder(t: Any) -> tuple[MultiTransformer, MultiTransformer]:
     return MultiTransformer(t.transformers[: cut + 1]), MultiTransformer(t.transformers[cut + 1:])
 
 
-def _points_from_option(automatch: str, left: Path, right: Path):
-    """Matched pixel positions of the two eyes for ``--automatch``; returns (points_l, points_r).  The reference's ``fm`` (AKAZE
-    feature matching, remapper.py:194-248) and ``gui`` (click window, cli.py:82-113) front ends are pure OpenCV calls; no box of
-    this engine's pool has cv2 or a display, so they are not mirrored: the points are passed explicitly."""
-    if automatch.startswith("fm") or automatch.startswith("gui"):
-        raise typer.BadParameter("--automatch fm / gui need OpenCV (AKAZE matching / a click window), which this engine does not ship: "
-                                 'pass the matched points explicitly, e.g. --automatch "xl,yl;xr,yr;xl,yl;xr,yr"')
-    flat = [(int(c.split(",")[0]), int(c.split(",")[1])) for c in automatch.split(";")]
-    return flat[::2], flat[1::2]  # even entries: left eye, odd entries: right eye
+def _option_number(automatch: str, prefix: str, pattern: str, default: float) -> float:
+    """``fm0.5`` -> 0.5, ``gui3`` -> 3, the bare keyword -> ``default`` (cli.py:258-262, 268-274)."""
+    m = re.match(prefix + pattern, automatch)
+    return float(m.group(1)) if m and m.group(1) else default
 
 
-def calibrated_pair(transformer: Any, automatch: str, left: Path, right: Path, radius: Any) -> tuple[Any, Any]:
+def calibrated_pair(transformer: Any, automatch: str, left: Path, right: Path, radius: Any, match_image_path: Optional[Path] = None) -> tuple[Any, Any]:
     """``--automatch``: estimate the rotation between the eyes from matched points and give each eye half of it
-    (cli.py:234-319): (left chain, right chain).  A point list of the reference's ``--automatch "xl,yl;xr,yr;..."`` form takes the
-    plain least-squares fit (``rotation_match``); the robust fit (``rotation_match_robust``) belongs to the feature matcher's
-    outlier-ridden points and is available to callers of the Python API."""
+    (cli.py:234-319): (left chain, right chain).  The points come from the option itself (``"xl,yl;xr,yr;..."``: even entries the
+    left eye, odd entries the right; plain least-squares fit ``rotation_match``), from clicks (``gui[n]``: n pairs, default 2) or from
+    AKAZE feature matching (``fm[scale]``: outlier-ridden, hence ``rotation_match_robust``; ``match_image_path`` = where
+    ``--savematch`` wants 100 of the surviving matches drawn)."""
     head, tail = split_at_first_encoder(transformer)
-    points_l, points_r = _points_from_option(automatch, left, right)
+    matched = None
+    if automatch.startswith("fm") or automatch.startswith("gui"):
+        from . import calibration_cv as _cvx
+
+        try:
+            img_l, img_r = _io.imread(left), _io.imread(right)
+            if automatch.startswith("fm"):
+                matched = _cvx.match_points(img_l, img_r, scale=_option_number(automatch, "fm", r"([\d\.]+)", 1))
+                points_l, points_r = matched[0], matched[1]
+            else:
+                n_pairs = int(_option_number(automatch, "gui", r"(\d+)", 2))
+                clicks = _cvx.pick_points_gui([img_l, img_r] * n_pairs)
+                LOG.info("Automatched position: " + ";".join(",".join(map(str, p)) for p in clicks))
+                points_l, points_r = clicks[::2], clicks[1::2]
+        except _cvx.OptionalDependencyMissing as e:
+            raise typer.BadParameter(f'--automatch {automatch}: {e}; or pass the matched points explicitly, e.g. '
+                                     '--automatch "xl,yl;xr,yr;xl,yl;xr,yr"') from e
+    else:
+        flat = [(int(c.split(",")[0]), int(c.split(",")[1])) for c in automatch.split(";")]
+        points_l, points_r = flat[::2], flat[1::2]  # even entries: left eye, odd entries: right eye
     vl, vr = match_lr(tail, points_l, points_r, in_paths=[left, right], radius=radius)
-    q = rotation_match(vl, vr)
+    if matched is not None:
+        q, discarded = rotation_match_robust(vl, vr)
+        if match_image_path is not None:
+            from . import calibration_cv as _cvx
+
+            _, _, kp_l, kp_r, matches, small_l, small_r = matched
+            _io.imwrite(match_image_path, _cvx.draw_match_image(small_l, kp_l, small_r, kp_r, matches, discarded))
+    else:
+        q = rotation_match(vl, vr)
     LOG.info(f"Automatched quaternion: {q}")
     q_left, q_right = calibration_rotators(q)
     return head * _T.Euclidean3DRotator(q_left) * tail, head * _T.Euclidean3DRotator(q_right) * tail
@@ -172,8 +196,9 @@ def lr(
         help="Autosearch timestamp calibration (right timestamp -= this) (in seconds)")] = 0.0,
     swap: Annotated[bool, typer.Option(help="Swap left and right images as well as transformer, etc.")] = False,
     name_unique: Annotated[bool, typer.Option(help="Make output name unique")] = False,
-    automatch: Annotated[str, typer.Option(help='Calibrate rotation. e.g. "0,0;0,0;1,1;1,1". "fm" / "gui" need OpenCV')] = "",
-    savematch: Annotated[bool, typer.Option(help="Save the match image (only with automatch=fm)")] = False,
+    automatch: Annotated[str, typer.Option(help='Calibrate rotation. e.g. "0,0;0,0;1,1;1,1", "gui[n]" (click n point pairs) or '
+                                                 '"fm[scale]" (AKAZE feature matching); the last two need OpenCV')] = "",
+    savematch: Annotated[bool, typer.Option(help="Save the match image <out>.match<ext> (only with automatch=fm)")] = False,
 ) -> None:
     """Remap a pair of fisheye images to a pair of SBS equirectangular images."""
     from .remapper import apply_lr
@@ -192,8 +217,11 @@ def lr(
     tag = unique_suffix(transformer, size, interpolation, border_mode, border_value, radius, merge,
                         r_earlier_l, swap) if name_unique else ""
     out = output_path(out_path, left_path, right_path, tag)
+    if savematch and not automatch.startswith("fm"):
+        raise typer.BadParameter("--savematch draws the feature matches of --automatch fm: there is nothing to save without it")
     if automatch != "":
-        chain = calibrated_pair(chain, automatch, left_path, right_path, radius_)
+        match_image = out.with_suffix(f".match{out.suffix}") if savematch else None  # cli.py:362-365
+        chain = calibrated_pair(chain, automatch, left_path, right_path, radius_, match_image)
         LOG.info(f"Automatched transformer: {chain}")
     apply_lr(chain, left_path=left_path, right_path=right_path, out_path=out, radius=radius_, size_output=parse_size(size),
              interpolation=interp, boarder_mode=border, boarder_value=border_value, merge=merge)
@@ -247,8 +275,18 @@ def xmp(
 ) -> None:
     """Write the left half as <name>.xmp<ext> with the right half embedded as Google VR180 photo metadata
     (GPano / GImage XMP, cli.py:439-540).  Needs python-xmp-toolkit (libxmp / exempi)."""
-    raise typer.BadParameter("the xmp command writes Google VR180 photo metadata through python-xmp-toolkit (libxmp + the exempi library), "
-                             "which this engine does not ship: run the reference's `vr180-convert xmp` on the output of `lr`")
+    import subprocess as sp
+
+    from . import calibration_cv as _cvx
+
+    for in_path in in_paths:
+        if wslpath:  # cli.py:477-482
+            in_path = Path(sp.run(["wslpath", "-u", "-a", str(in_path)], capture_output=True).stdout.decode().strip())  # noqa: S603, S607
+        try:
+            written = _cvx.write_vr180_xmp(in_path)
+        except _cvx.OptionalDependencyMissing as e:
+            raise typer.BadParameter(str(e)) from e
+        LOG.info(f"Saved {written}")
 
 
 def main(argv: Optional[Sequence[str]] = None) -> None:

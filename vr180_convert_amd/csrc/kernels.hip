@@ -321,4 +321,51 @@ hipError_t launch_anaglyph(const uint8_t* left, int64_t left_pitch, const uint8_
     return hipGetLastError();
 }
 
+// ---- get_radius(), transformer.py:108-140 ----
+// One workgroup walks the centre row (w > h) or the centre column: black[i] = mean over the channels < threshold (:133, the float64 mean
+// of uint8 values: sum / cn), d[i] = black[i + 1] - black[i] (:134), radius = (last i with d == -1  -  first i with d == +1) / 2 (:137-139;
+// the sign quirk of the reference -- a disc on black gives a NEGATIVE value -- is kept); no +1 or no -1 anywhere: the reference indexes an
+// empty array (IndexError) -> out[1] = 1, out[0] = NaN.
+__global__ __launch_bounds__(256) void k_get_radius(const uint8_t* __restrict__ line, int64_t step, int n, int cn, int threshold,
+                                                    double* __restrict__ out)
+{
+    __shared__ int first_rise, last_fall;
+    if (threadIdx.x == 0)
+        first_rise = 0x7fffffff, last_fall = -1;
+    __syncthreads();
+    auto black = [&](int i) {
+        const uint8_t* p = line + (int64_t)i * step;
+        int s = 0;
+        for (int k = 0; k < cn; k++)
+            s += p[k];
+        return ((double)s / (double)cn) < (double)threshold ? 1 : 0;
+    };
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = threadIdx.x; i + 1 < n; i += 256) {
+        const int d = black(i + 1) - black(i);
+        if (d == 1)
+            lo = min(lo, i);
+        if (d == -1)
+            hi = max(hi, i);
+    }
+    if (lo != 0x7fffffff)
+        atomicMin(&first_rise, lo);
+    if (hi >= 0)
+        atomicMax(&last_fall, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool ok = first_rise != 0x7fffffff && last_fall >= 0;
+        out[0] = ok ? (double)(last_fall - first_rise) / 2.0 : NAN;
+        out[1] = ok ? 0.0 : 1.0;
+    }
+}
+
+hipError_t launch_get_radius(const uint8_t* img, int h, int w, int64_t pitch, int cn, int threshold, double* out, hipStream_t stream)
+{
+    const bool use_row = w > h;  // transformer.py:126-129
+    const uint8_t* line = use_row ? img + (int64_t)(h / 2) * pitch : img + (int64_t)(w / 2) * cn;
+    hipLaunchKernelGGL(k_get_radius, dim3(1), dim3(256), 0, stream, line, use_row ? (int64_t)cn : pitch, use_row ? w : h, cn, threshold, out);
+    return hipGetLastError();
+}
+
 }  // namespace v1c

@@ -119,4 +119,7 @@ int tile_lean_raw_passes(const void* host_boxes, const Geom& g);
 hipError_t launch_anaglyph(const uint8_t* left, int64_t left_pitch, const uint8_t* right, int64_t right_pitch, int h, int w,
                            double* out, int64_t out_pitch, hipStream_t stream);
 
+// get_radius() (transformer.py:108-140) on the device: out[0] = radius, out[1] = 0 / 1 (no black border)
+hipError_t launch_get_radius(const uint8_t* img, int h, int w, int64_t pitch, int cn, int threshold, double* out, hipStream_t stream);
+
 }  // namespace v1c

@@ -1087,13 +1087,13 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
     const int z0 = zg * upb;
     const TileIds t = tile_ids(g, z0, tid, tx, ty, tiles_x, NT / kLanesX);
     const int nu = min(upb, n_units - z0);
-    // (the first two units' pointers are read here, next to the tile box, not behind it: every
-    // dependent scalar load of the prologue is a wait)
-    const uint8_t* __restrict__ usrc0 = U[z0].src;
-    const uint32_t upitch0 = (uint32_t)U[z0].src_pitch;
+    // (PAIR: the first two units' pointers are read here, next to the tile box, not behind it: every dependent scalar load of the
+    // prologue is a wait; the batch loop reads each unit's record where it issues its loads -- it has no scalar registers to spare)
     const int z1 = min(z0 + 1, n_units - 1);
-    const uint8_t* __restrict__ usrc1 = U[z1].src;
-    const uint32_t upitch1 = (uint32_t)U[z1].src_pitch;
+    const uint8_t* __restrict__ usrc0 = PAIR ? U[z0].src : nullptr;
+    const uint32_t upitch0 = PAIR ? (uint32_t)U[z0].src_pitch : 0u;
+    const uint8_t* __restrict__ usrc1 = PAIR ? U[z1].src : nullptr;
+    const uint32_t upitch1 = PAIR ? (uint32_t)U[z1].src_pitch : 0u;
     // everything the tile needs from global memory is requested up front: the boxes of the first
     // two units, the radial-table slice and the row / column table entries (one exposed latency)
     TileBox b;
@@ -1111,8 +1111,8 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
     make_chunk_map<NT>(b, tid, M);
 
     auto issue = [&](int z, Staged& S) -> bool {  // start the box loads of unit z; false: it must gather from global memory
-        const uint8_t* __restrict__ src = z == z0 ? usrc0 : z == z0 + 1 ? usrc1 : U[z].src;
-        const uint32_t spitch = z == z0 ? upitch0 : z == z0 + 1 ? upitch1 : (uint32_t)U[z].src_pitch;
+        const uint8_t* __restrict__ src = !PAIR ? U[z].src : z == z0 ? usrc0 : z == z0 + 1 ? usrc1 : U[z].src;
+        const uint32_t spitch = !PAIR ? (uint32_t)U[z].src_pitch : z == z0 ? upitch0 : z == z0 + 1 ? upitch1 : (uint32_t)U[z].src_pitch;
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
         const bool fits = box_fits(b, src, spitch, 4 * NT, LEAN ? 2 * half_dwords : half_dwords);
         if (fits) {
@@ -3132,11 +3132,13 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
     // balanced groups (10 units: 5 + 5, not 8 + 2): no short tail group, and every group of a batch
     // has more than two units, which the lean batch kernel wants
     const int n_groups = (n_units + upb_max - 1) / upb_max;
-    const int upb = bx ? (n_units + n_groups - 1) / n_groups : 1;
+    int upb = bx ? (n_units + n_groups - 1) / n_groups : 1;
     // the template's PAIR slot: with boxes "at most 2 units per workgroup", without (one unit per
     // workgroup anyway) "the m-polynomial table serves every pixel of every unit" (bilinear, OWN = 0)
-    const bool pair = bx ? upb <= 2 : (K == 2 && shared_entry && mpoly_all && c.ray.radial_m != nullptr);
-    const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
+    // (decided below for launches with boxes)
+    bool pair = bx ? upb <= 2 : (K == 2 && shared_entry && mpoly_all && c.ray.radial_m != nullptr);
+    const dim3 block(256, 1, 1);
+    dim3 grid = tile_grid(c.g, 256, (n_units + upb - 1) / upb);
     static const size_t lds_pad = [] {  // V1C_LDS_PAD=<bytes>: occupancy experiments (fewer workgroups per CU)
         const char* e = tuning_env("V1C_LDS_PAD");
         return e ? (size_t)std::atoi(e) : (size_t)0;
@@ -3161,6 +3163,16 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
     lean = lean && lean_raw_nwp > 0;  // (the register-staged lean kernel is an A/B partner: tuning build only)
 #endif
     lean = lean && units_dword_aligned(lu);
+    // Whatever does not take the lean batch kernel (NEAREST, bicubic / Lanczos4, unaligned sources, one or two units left over) is served
+    // TWO units per workgroup by the pair code: round 1 measured the general loop -- up to 8 units per workgroup, 100 - 124 VGPRs -- no
+    // faster pair by pair (C3 277 against 267 us), and its 24 instantiations were the last kernels that spilled scalar registers into
+    // vector lanes (9 - 12 each).  They exist in the tuning build only, behind V1C_UPB=<n>.
+    static const bool upb_forced = tuning_env("V1C_UPB") != nullptr;
+    if (bx && !lean && !upb_forced && upb > 2) {
+        upb = 2;
+        pair = true;
+        grid = tile_grid(c.g, 256, (n_units + 1) / 2);
+    }
     // (An LDS-DMA form of the plain pair kernel -- k_ray_lin3_pair_mirror_raw without the mirror image -- was built and removed:
     // bit-identical, but 0.0535 against 0.0511 ms on an unrotated 4080^2 pair and 0.0733 against 0.0684 ms on a rotated
     // 4096^2 pair (94 VGPRs): with one tile per workgroup the interleaved cells' single ds_read2_b64 per tap row wins.)
@@ -3264,11 +3276,16 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
         }                                                                                                                             \
         hipLaunchKernelGGL((k_ray_lin3_tile<VW, RT, BX, K, OW, PR>), grid, block, lds, stream, a);                                    \
     } while (0)
+#ifdef V1C_TUNING
+    constexpr bool kBatchLoop = true;
+#else
+    constexpr bool kBatchLoop = false;  // (launches with boxes always run the pair instantiation: see `upb` above)
+#endif
 #define V1C_TILE_O(VW, RT, BX, OW)                       \
     do {                                                 \
-        if (pair)                                        \
+        if (pair || (BX && lean))  /* (a lean launch: decided inside V1C_TILE_P) */ \
             V1C_TILE_P(VW, RT, BX, OW, (BX || !OW) ? 1 : 0); \
-        else                                             \
+        else if constexpr (BX == 0 || kBatchLoop)        \
             V1C_TILE_P(VW, RT, BX, OW, 0);               \
     } while (0)
 #define V1C_TILE(VW, RT)                \

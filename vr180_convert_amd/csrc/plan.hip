@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -911,8 +913,19 @@ struct PlanKey {
     bool operator<(const PlanKey& o) const { return bytes < o.bytes; }
 };
 
+// Plans of the one-shot entry point: at most kFusedCacheSize, least recently used first out (a caller sweeping radii or sizes would
+// otherwise keep every plan's tables, tile boxes and unit ring alive).  Entries are shared_ptrs: a call in flight on another thread
+// keeps its plan alive past its eviction; v1c_plan_destroy (hipFree: device-synchronising) runs when the last holder lets go.
+static constexpr size_t kFusedCacheSize = 32;
 static std::mutex g_cache_mu;
-static std::map<PlanKey, v1c_plan*> g_cache;
+static std::list<std::pair<PlanKey, std::shared_ptr<v1c_plan>>> g_cache_lru;  // front = most recently used
+static std::map<PlanKey, std::list<std::pair<PlanKey, std::shared_ptr<v1c_plan>>>::iterator> g_cache;
+
+extern "C" int v1c_fused_cache_size(void)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    return (int)g_cache.size();
+}
 
 extern "C" int v1c_remap_fused(int device, void* stream, const uint8_t* src, int src_h, int src_w, int64_t src_pitch,
                                int cn, uint8_t* dst, int dst_h, int dst_w, int64_t dst_pitch, const v1c_chain* chain,
@@ -926,28 +939,42 @@ extern "C" int v1c_remap_fused(int device, void* stream, const uint8_t* src, int
     const int dims[9] = {device, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, 0};
     key.bytes.append((const char*)dims, sizeof(dims));
     key.bytes.append((const char*)(border_val ? border_val : (const uint8_t*)"\0\0\0\0"), 4);
-    v1c_plan* p = nullptr;
+    std::shared_ptr<v1c_plan> p;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         auto it = g_cache.find(key);
-        if (it != g_cache.end())
-            p = it->second;
+        if (it != g_cache.end()) {
+            g_cache_lru.splice(g_cache_lru.begin(), g_cache_lru, it->second);  // most recently used
+            p = it->second->second;
+        }
     }
     if (!p) {
-        rc = v1c_plan_create(&p, device, chain, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, border_val);
+        v1c_plan* raw = nullptr;
+        rc = v1c_plan_create(&raw, device, chain, src_h, src_w, dst_h, dst_w, cn, interp, border_mode, border_val);
         if (rc)
             return rc;
-        std::lock_guard<std::mutex> lk(g_cache_mu);
-        auto ins = g_cache.emplace(key, p);
-        if (!ins.second) {  // another thread won the race
-            v1c_plan_destroy(p);
-            p = ins.first->second;
+        p.reset(raw, [](v1c_plan* q) { (void)v1c_plan_destroy(q); });
+        std::vector<std::shared_ptr<v1c_plan>> evicted;  // (destroyed outside the lock)
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            auto it = g_cache.find(key);
+            if (it != g_cache.end()) {  // another thread won the race: use its plan
+                p = it->second->second;
+            } else {
+                g_cache_lru.emplace_front(key, p);
+                g_cache[key] = g_cache_lru.begin();
+                while (g_cache.size() > kFusedCacheSize) {
+                    evicted.push_back(g_cache_lru.back().second);
+                    g_cache.erase(g_cache_lru.back().first);
+                    g_cache_lru.pop_back();
+                }
+            }
         }
     }
     v1c_unit u;
     std::memset(&u, 0, sizeof(u));
     u.src = src, u.dst = dst, u.src_pitch = src_pitch, u.dst_pitch = dst_pitch;
-    return v1c_plan_run(p, stream, &u, 1);
+    return v1c_plan_run(p.get(), stream, &u, 1);
 }
 
 extern "C" int v1c_remap_lut(int device, void* stream, const uint8_t* src, int src_h, int src_w, int64_t src_pitch,
@@ -1015,43 +1042,49 @@ extern "C" int v1c_anaglyph(int device, void* stream, const uint8_t* left, int64
     return V1C_OK;
 }
 
-// get_radius(), transformer.py:108-140.  One row (or column) of the image: copied to the host and
-// scanned there -- O(max(W, H)) bytes, synchronous by nature (the reference returns a float).
+// get_radius(), transformer.py:108-140: the scan of the centre row (landscape) or column runs on the device (kernels.hip: k_get_radius);
+// out_dev[0] = (last fall - first rise) / 2 with the reference's sign quirk, out_dev[1] = 0, or 1 where the reference raises IndexError
+// (no black border; out_dev[0] = NaN).  Nothing is synchronised, nothing is allocated: graph-capturable.
+extern "C" int v1c_get_radius_async(int device, void* stream, const uint8_t* img, int h, int w, int64_t pitch, int cn, int threshold,
+                                    double* out_dev)
+{
+    if (!img || !out_dev || h <= 0 || w <= 0 || cn <= 0 || cn > 4 || pitch < (int64_t)w * cn)
+        return fail(V1C_E_INVALID, "v1c_get_radius_async: bad arguments");
+    DeviceGuard dg(device);
+    if (!dg.ok)
+        return fail(V1C_E_NODEVICE, "hipSetDevice failed");
+    HIP_TRY(launch_get_radius(img, h, w, pitch, cn, threshold, out_dev, (hipStream_t)stream));
+    return V1C_OK;
+}
+
+// ... and with the value handed to the caller, as the reference returns it (a float): the kernel writes its two doubles into
+// page-locked host memory of the calling thread, the call synchronises the stream.
 extern "C" int v1c_get_radius(int device, void* stream, const uint8_t* img, int h, int w, int64_t pitch, int cn,
                               int threshold, double* radius)
 {
-    if (!img || !radius || h <= 0 || w <= 0 || cn <= 0 || pitch < (int64_t)w * cn)
+    if (!img || !radius || h <= 0 || w <= 0 || cn <= 0 || cn > 4 || pitch < (int64_t)w * cn)
         return fail(V1C_E_INVALID, "v1c_get_radius: bad arguments");
     DeviceGuard dg(device);
     if (!dg.ok)
         return fail(V1C_E_NODEVICE, "hipSetDevice failed");
-    hipStream_t st = (hipStream_t)stream;
-    const bool use_row = w > h;  // transformer.py:126-129
-    const int n = use_row ? w : h;
-    std::vector<uint8_t> line((size_t)n * cn);
-    if (use_row) {
-        HIP_TRY(hipMemcpyAsync(line.data(), img + (int64_t)(h / 2) * pitch, (size_t)w * cn, hipMemcpyDeviceToHost, st));
-    } else {
-        HIP_TRY(hipMemcpy2DAsync(line.data(), cn, img + (int64_t)(w / 2) * cn, pitch, cn, h, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    int first_rise = -1, last_fall = -1, prev = 0;
-    for (int i = 0; i < n; i++) {
-        double s = 0;
-        for (int k = 0; k < cn; k++)
-            s += line[(size_t)i * cn + k];
-        const int black = (s / cn) < threshold;  // np.mean(axis=-1) < threshold, :133
-        if (i > 0) {
-            const int d = black - prev;  // np.diff, :134
-            if (d == 1 && first_rise < 0)
-                first_rise = i - 1;  // np.where(d == 1)[0][0], :137
-            if (d == -1)
-                last_fall = i - 1;  // np.where(d == -1)[0][-1], :138
+    struct Pinned {
+        double* p = nullptr;
+        ~Pinned()
+        {
+            if (p)
+                (void)hipHostFree(p);
         }
-        prev = black;
-    }
-    if (first_rise < 0 || last_fall < 0)
+    };
+    static thread_local Pinned host;  // (mapped: the kernel stores straight into it)
+    if (!host.p)
+        HIP_TRY(hipHostMalloc((void**)&host.p, 2 * sizeof(double), hipHostMallocMapped | hipHostMallocPortable));
+    double* dptr = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&dptr, host.p, 0));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_get_radius(img, h, w, pitch, cn, threshold, dptr, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (host.p[1] != 0.0)
         return fail(V1C_E_INVALID, "no black border");  // the reference raises IndexError here
-    *radius = (last_fall - first_rise) / 2.0;  // :139 (sign quirk preserved)
+    *radius = host.p[0];
     return V1C_OK;
 }

@@ -286,36 +286,40 @@ class BandJob:
     chains: list
     units: list
     srcs: list
-    src_hw: tuple[int, int]
+    src_hws: list      # (H, W) of every band's own source
     dst_w: int
     cn: int
 
 
 def build_band_job(transformer: Any, bands: Sequence[tuple[int, int, int, int]], sources: dict, outputs: dict, *, radius: float,
-                   size_output: tuple[int, int], device: Any = None) -> BandJob:
+                   size_output: tuple[int, int], device: Any = None, size_input: tuple[int, int] | None = None) -> BandJob:
     """Host logic of one rank of a row-band split (a single pair on 4 / 8 GPUs).  ``sources[(frame, eye)]``: the
     whole source eye (every rank uploads the eyes of its bands itself; nothing is exchanged); ``outputs[(frame, eye, r0, r1)]``:
-    the (r1 - r0, W, C) view the band is written into.  No device is involved: the gloo tests run exactly this."""
+    the (r1 - r0, W, C) view the band is written into.  ``size_input``: the (H, W) the Denormalize centre is taken from -- the
+    frame's LEFT eye, ``images[0]`` of the call (remapper.py:385) -- whichever eyes' bands this rank holds (default: the first
+    band's source, right when both eyes share a shape).  No device is involved: the gloo tests run exactly this."""
     from . import remapper as R
     from .chain import lower_for_get_map
 
     bands = list(bands)
     if not bands:
-        return BandJob([], [], [], [], (0, 0), int(size_output[0]), 0)
+        return BandJob([], [], [], [], [], int(size_output[0]), 0)
     w = int(size_output[0])
     first = sources[(bands[0][0], bands[0][1])]
-    src_hw = (int(first.shape[0]), int(first.shape[1]))
+    centre_hw = (int(first.shape[0]), int(first.shape[1])) if size_input is None else (int(size_input[0]), int(size_input[1]))
     cn = int(first.shape[2])
-    chains, units, srcs = [], [], []
+    chains, units, srcs, src_hws = [], [], [], []
     for f, e, r0, r1 in bands:
         src, dst = sources[(f, e)], outputs[(f, e, r0, r1)]
-        if tuple(int(v) for v in src.shape[:2]) != src_hw or tuple(int(v) for v in dst.shape[:2]) != (r1 - r0, w):
-            raise ValueError("band sources must share a shape and band outputs must be (r1 - r0, W, C) views")
-        # (size_input: the shape the Denormalize centre is taken from -- images[0] of the call, remapper.py:385)
-        chains.append(lower_for_get_map(transformer[e] if isinstance(transformer, tuple) else transformer, radius=radius, size_input=src_hw, size_output=tuple(size_output), row_band=(r0, r1)))
+        src_hw = (int(src.shape[0]), int(src.shape[1]))  # every band against its OWN source (the eyes of a frame may differ in shape)
+        if int(src.shape[2]) != cn or tuple(int(v) for v in dst.shape[:2]) != (r1 - r0, w):
+            raise ValueError("band sources must share a channel count and band outputs must be (r1 - r0, W, C) views")
+        chains.append(lower_for_get_map(transformer[e] if isinstance(transformer, tuple) else transformer, radius=radius, size_input=centre_hw,
+                                        size_output=tuple(size_output), row_band=(r0, r1)))
         units.append(R.marshal_units([src], [dst], None, src_hw=src_hw, dst_wh=(w, r1 - r0), cn=cn, device=device))
         srcs.append(src)
-    return BandJob(bands, chains, units, srcs, src_hw, w, cn)
+        src_hws.append(src_hw)
+    return BandJob(bands, chains, units, srcs, src_hws, w, cn)
 
 
 def run_band_job(job: BandJob, *, interpolation: int, boarder_mode: int = 0, boarder_value: Any = 0, launch: Callable | None = None) -> list[str]:
@@ -324,12 +328,12 @@ def run_band_job(job: BandJob, *, interpolation: int, boarder_mode: int = 0, boa
     from . import remapper as R
 
     paths = []
-    for (f, e, r0, r1), chain, units, src in zip(job.bands, job.chains, job.units, job.srcs):
+    for (f, e, r0, r1), chain, units, src, src_hw in zip(job.bands, job.chains, job.units, job.srcs, job.src_hws):
         if launch is not None:
             launch(chain, units, (f, e, r0, r1))
             paths.append("custom")
             continue
-        plan = R._plan_for(chain, src_hw=job.src_hw, dst_wh=(job.dst_w, r1 - r0), cn=job.cn, interpolation=interpolation,
+        plan = R._plan_for(chain, src_hw=src_hw, dst_wh=(job.dst_w, r1 - r0), cn=job.cn, interpolation=interpolation,
                            border_mode=boarder_mode, border_value=boarder_value, device=src.device)
         plan.run_units(units, 1)
         paths.append(plan.path)
@@ -361,7 +365,8 @@ def _remap_banded(transformer, eyes, radii, outs, devs, *, size_output, interpol
                     if boarder_mode == 5:  # BORDER_TRANSPARENT: skipped pixels must be deterministic
                         for d in outputs.values():
                             d.zero_()
-                    job = build_band_job(transformer, bands, sources, outputs, radius=radii[f], size_output=size_output, device=dev)
+                    job = build_band_job(transformer, bands, sources, outputs, radius=radii[f], size_output=size_output, device=dev,
+                                         size_input=eyes[f][0].shape[:2])
                     run_band_job(job, interpolation=interpolation, boarder_mode=boarder_mode, boarder_value=boarder_value)
                     for (_, e, r0, r1), d in outputs.items():
                         np.copyto(outs[f][r0:r1, e * w:(e + 1) * w], d.cpu().numpy())
