@@ -3143,8 +3143,6 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
         const char* e = tuning_env("V1C_LDS_PAD");
         return e ? (size_t)std::atoi(e) : (size_t)0;
     }();
-    // two box buffers (+ the K x K pair path's exchange buffer: 1 KB per wave, see shared_map_tile)
-    const size_t lds = bx ? (size_t)half_dwords * 8 + 16 + (K != 2 && pair ? kKxkExchangeBytes : 0) + lds_pad : 0;
     // batches (more than two units per workgroup) of a bilinear plan: the interior tiles go to the lean
     // kernel, everything else stays with the general one (same grid; each skips the other's tiles)
     static const bool lean_off = [] {
@@ -3173,6 +3171,8 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
         pair = true;
         grid = tile_grid(c.g, 256, (n_units + 1) / 2);
     }
+    // two box buffers (+ the K x K pair path's exchange buffer: 1 KB per wave, see shared_map_tile)
+    const size_t lds = bx ? (size_t)half_dwords * 8 + 16 + (K != 2 && pair ? kKxkExchangeBytes : 0) + lds_pad : 0;
     // (An LDS-DMA form of the plain pair kernel -- k_ray_lin3_pair_mirror_raw without the mirror image -- was built and removed:
     // bit-identical, but 0.0535 against 0.0511 ms on an unrotated 4080^2 pair and 0.0733 against 0.0684 ms on a rotated
     // 4096^2 pair (94 VGPRs): with one tile per workgroup the interleaved cells' single ds_read2_b64 per tap row wins.)
