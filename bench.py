@@ -363,6 +363,8 @@ def main() -> None:
     ap.add_argument("--no-condition", action="store_true",
                     help="skip the 0.5 s clock / launch-queue conditioning (the --pmc child passes: counters do not depend on clocks)")
     args = ap.parse_args()
+    if args.no_condition:  # (the counter passes: a few launches are all they need)
+        args.no_sustained = True
 
     PMC_CHILD_ARGS[:] = ["--split", args.split]
     rank = int(os.environ.get("RANK", "0"))

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 WL=$1; shift
 for L in "$@"; do
   D=$(mktemp -d /tmp/ktime.XXXX)
-  V1C_LIB=$L rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --workload $WL --steps 40 --warmup 5 > /dev/null 2>&1
+  V1C_LIB=$L rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --workload $WL --steps 40 --warmup 5 --no-sustained > /dev/null 2>&1
   f=$(find $D -name '*kernel_trace.csv' | head -1)
   python3 - "$f" "$L" <<'PY'
 import csv, sys, collections

@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
 run() { tag=$1; abl=$2; shift 2
-  V1C_ABL=$abl rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc/$tag -o p -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --steps 3 --warmup 1 --no-condition --workload ${WL:-C2} > /dev/null 2>&1
+  V1C_ABL=$abl rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc/$tag -o p -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --steps 3 --warmup 1 --no-condition --no-sustained --workload ${WL:-C2} > /dev/null 2>&1
   f=$(find gpurun_out/pmc/$tag -name '*counter_collection.csv' | head -1)
   python3 - "$f" "$tag" <<'PY'
 import csv,sys,collections

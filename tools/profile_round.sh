@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 for W in $WLS; do
   EXTRA="--no-cpu-baseline --no-cold-extra"; [ "$W" = C2 ] && EXTRA=""
   python3 bench.py --workload $W $EXTRA > $OUT/${W}_bench_line.json 2> /dev/null
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o trace -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --workload $W --steps 200 --warmup 20 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o trace -- python3 bench.py --no-cpu-baseline --traffic none --no-cold-extra --workload $W --steps 200 --warmup 20 --no-sustained > /dev/null 2>&1
   find $OUT/trace_$W -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/${W}_kernel_stats.csv
   rm -rf $OUT/trace_$W
   echo "== $W" > $OUT/pmc_$W.log

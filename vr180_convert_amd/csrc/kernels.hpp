@@ -58,6 +58,10 @@ struct TileArgs {
     int half_dwords, n_rest;     // LDS dwords per box buffer of the general pair / batch code; entries of rest_list
     unsigned tiles_x_magic, strip_len, strip_magic, rest_rows;  // xcd_tile(); rows of workgroups in front of the grid that serve rest_list
     int mirror_h, kb, tiles_x, pad;  // kb: box buffer KB of the LDS-DMA kernels (bytes for k_ray_lin3_rot_pair_raw)
+    // copies of what a workgroup needs for its FIRST vector loads (the row / column table entries of its tile): with the pointers here
+    // those loads go out one scalar round trip earlier, next to the reads of the plan's context instead of behind them
+    const double *col_s, *col_c, *col_h, *row_s, *row_c, *row_h;  // = ctx->ray.*
+    int dst_w, dst_h, pad2[2];                                     // = ctx->g.*
     DevUnit inl[kInlineUnits];
 };
 

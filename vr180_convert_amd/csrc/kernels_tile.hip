@@ -66,6 +66,53 @@ __device__ __forceinline__ units_cptr args_units(args_cref a)
 {
     return a.units ? (units_cptr)a.units : (units_cptr)a.inl;
 }
+// ---- scalar-load clauses ----
+// A constant-address-space load sits where its value is first used -- right for everything a slow path reads, wrong for what every
+// workgroup needs in its prologue: a chain of five or six dependent scalar loads, each a round trip to L2 or HBM (the argument block
+// is fresh memory every launch) in front of the first box request, and more of them behind the first barrier (the Denormalize constants
+// of the coordinates).  A launch that fits the machine in one round of workgroups (config 1: 1056 of 1792 slots) IS that chain.  The
+// touch_* helpers read a group of values at one point (the empty asm statement needs them in registers), so the compiler issues their
+// loads there as one clause and waits once; later reads of the same fields are the same loads (common subexpressions: the address
+// space is constant).  V1C_TOUCH=0 (A/B builds): every load where it is used.
+#ifndef V1C_TOUCH
+#define V1C_TOUCH 1
+#endif
+// everything of the argument block's header a fast path reads (and the grid size: a hidden kernel argument)
+__device__ __forceinline__ void touch_args(args_cref a)
+{
+#if V1C_TOUCH
+    asm volatile("" ::"s"(a.ctx), "s"(a.units), "s"(a.boxes), "s"(a.mboxes), "s"(a.n_units), "s"(a.upb), "s"(a.tiles_x_magic), "s"(a.strip_len),
+                 "s"(a.strip_magic), "s"(a.rest_rows), "s"(a.mirror_h), "s"(a.kb), "s"(gridDim.x), "s"(gridDim.y), "s"(a.col_s), "s"(a.col_c),
+                 "s"(a.col_h), "s"(a.row_s), "s"(a.row_c), "s"(a.row_h), "s"(a.dst_w), "s"(a.dst_h));
+#endif
+}
+// the second round: the plan's constants of the coordinate evaluation, the table pointers of the prologue and the pointers / pitches of
+// the first NU units of the workgroup, all in ONE statement (two statements are two waits)
+template <int ROT, int NU>
+__device__ __forceinline__ void touch_plan_and_units(ctx_cref c, units_cptr U, int z0, int z1)
+{
+#if V1C_TOUCH
+    ray_cref P = c.ray;
+    if (NU == 2)
+        asm volatile("" ::"s"(P.rx32), "s"(P.ry32), "s"(P.cx32), "s"(P.cy32), "s"(P.inv_step), "s"(P.inv_step_f), "s"(P.n_int), "s"(P.radial),
+                     "s"(P.radial_m), "s"(c.g.src_h), "s"(c.g.src_w), "s"(U[z0].src), "s"(U[z0].dst), "s"(U[z0].src_pitch), "s"(U[z0].dst_pitch),
+                     "s"(U[z1].src), "s"(U[z1].dst), "s"(U[z1].src_pitch), "s"(U[z1].dst_pitch));
+    else
+        asm volatile("" ::"s"(P.rx32), "s"(P.ry32), "s"(P.cx32), "s"(P.cy32), "s"(P.inv_step), "s"(P.inv_step_f), "s"(P.n_int), "s"(P.radial),
+                     "s"(P.radial_m), "s"(c.g.src_h), "s"(c.g.src_w), "s"(U[z0].src), "s"(U[z0].dst), "s"(U[z0].src_pitch), "s"(U[z0].dst_pitch));
+#endif
+}
+
+// the table a tile's slice is cut from.  (Two loaded VALUES and a select: left alone the compiler selects between the two ADDRESSES and
+// loads through the result -- a dependent scalar load, i.e. one more round trip, in front of the slice's request.)
+__device__ __forceinline__ const double* radial_table(ray_cref P, bool mpoly)
+{
+    const double* m = P.radial_m;
+    const double* r = P.radial;
+    asm volatile("" : "+s"(m), "+s"(r));
+    return mpoly ? m : r;
+}
+
 // a generic copy of the geometry for the border-aware samplers of v1c_core.hpp (slow paths only)
 __device__ __forceinline__ Geom geom_copy(geom_cref g)
 {
@@ -156,6 +203,18 @@ struct TileBox {
     int magic;     // ceil(2^20 / cpr): floor(ch / cpr) == (ch * magic) >> 20 for ch < 16k, cpr <= 64 (chunk map)
 };
 
+// (plan-time data, never written by a remap launch: read through the constant address space -- scalar loads; a plain pointer that
+// itself came out of memory would make them vector loads)
+__device__ __forceinline__ TileBox load_tile_box(const TileBox* boxes, int tile)
+{
+    typedef int __attribute__((ext_vector_type(4))) i32x4;
+    const V1C_CONST i32x4* bp = (const V1C_CONST i32x4*)(boxes + __builtin_amdgcn_readfirstlane(tile));
+    const i32x4 b0 = bp[0], b1 = bp[1];
+    TileBox b;
+    b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y, b.interior = b1.z, b.magic = b1.w;
+    return b;
+}
+
 // ceil(2^20 / cpr) for cpr = 1 .. kMaxCpr (a wave-uniform table read instead of an integer division,
 // which the compiler expands to ~25 vector instructions)
 struct ChunkMagicLut {
@@ -199,8 +258,10 @@ struct RowCol {
     double slon[kPX], qlon[kPX];  // columns: sin(lon) and 1-cos(lon) (no rotation) or cos(lon) (rotation)
 };
 
-template <int ROT>
-__device__ __forceinline__ void load_rowcol(ray_cref P, int xc, int jc, RowCol& rc)
+// `P`: where the six table pointers are read from -- the plan's context (c.ray) or the launch's argument block, which carries
+// copies so that these loads need not wait for the context (kernels.hpp: TileArgs)
+template <int ROT, typename Tables>
+__device__ __forceinline__ void load_rowcol(const Tables& P, int xc, int jc, RowCol& rc)
 {
     rc.sl = P.row_s[jc], rc.cl = P.row_c[jc], rc.hl = P.row_h[jc];
     const double* __restrict__ ps = P.col_s + xc;
@@ -826,7 +887,9 @@ struct TileIds {
 };
 
 // tile (tx, ty) of a grid of tiles_x columns; the tile is 64 px wide and `th` = threads/16 rows high
-__device__ __forceinline__ TileIds tile_ids(geom_cref g, int z, int tid, int tx, int ty, int tiles_x, int th)
+// `g`: anything with dst_w / dst_h -- the plan's geometry or the argument block's copy of the two
+template <typename Dst>
+__device__ __forceinline__ TileIds tile_ids(const Dst& g, int z, int tid, int tx, int ty, int tiles_x, int th)
 {
     TileIds t;
     const int lx = tid % kLanesX, ly = tid / kLanesX;
@@ -1096,10 +1159,7 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
     const uint32_t upitch1 = PAIR ? (uint32_t)U[z1].src_pitch : 0u;
     // everything the tile needs from global memory is requested up front: the boxes of the first
     // two units, the radial-table slice and the row / column table entries (one exposed latency)
-    TileBox b;
-    const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(t.box_tile));
-    const int4 b0 = bp[0], b1 = bp[1];
-    b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y, b.interior = b1.z, b.magic = b1.w;
+    const TileBox b = load_tile_box(boxes, t.box_tile);
     const bool tail = box_touches_image_end(b, g);
     // lean batch path (further down): bilinear, more than two units, an interior tile whose table slice
     // and box fit -- the box is the same for all units, only the alignment of a source can differ
@@ -1134,7 +1194,7 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
     d2 tv = {0.0, 0.0};
     const bool mpoly = OWN == 0 && (b.interior & 2) != 0;  // slice of the polynomials in m instead
     if (tab_lds && tid < b.nidx * 4)
-        tv = ((const d2*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs))[tid];
+        tv = ((const d2*)(radial_table(P, mpoly) + (size_t)b.idx0 * kRadialCoefs))[tid];
     RowCol rc;
     load_rowcol<ROT>(P, t.xc, t.jc, rc);
     V1C_STAMP(0);  // setup + issue of all loads
@@ -1542,7 +1602,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
     if (BOXES) {
         int tx, ty, tiles_x;
         if (LIST) {
-            const uint32_t v = a.rest_list[blockIdx.x];
+            const uint32_t v = ((const V1C_CONST uint32_t*)a.rest_list)[blockIdx.x];
             tx = (int)(v & 0xffffu), ty = (int)(v >> 16);
             tiles_x = a.tiles_x;
         } else {
@@ -1586,7 +1646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
         if (lin >= (unsigned)a.n_rest * pairs)
             return;
         const unsigned ti = lin / pairs, zg = lin - ti * pairs;
-        const uint32_t v = a.rest_list[ti];
+        const uint32_t v = ((const V1C_CONST uint32_t*)a.rest_list)[ti];
         shared_map_tile<VAR_W, ROT, 2, OWN, 1, 256, 0>(a, a.n_units, 2, (int)zg, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
                                                        a.half_dwords, tabw, (glb_u32_ptr) nullptr);
         return;
@@ -1655,15 +1715,6 @@ __host__ __device__ inline bool mirror_raw_static_ok(const TileBox& b, const Til
            raw_box_ok(b.x0, b.y0, b.cpr, b.nrows, nwp, src_h, src_w) && raw_box_ok(q.x0, q.y0, q.cpr, q.nrows, nwp, src_h, src_w);
 }
 
-__device__ __forceinline__ TileBox load_tile_box(const TileBox* __restrict__ boxes, int tile)
-{
-    const int4* bp = (const int4*)(boxes + __builtin_amdgcn_readfirstlane(tile));
-    const int4 b0 = bp[0], b1 = bp[1];
-    TileBox b;
-    b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y, b.interior = b1.z, b.magic = b1.w;
-    return b;
-}
-
 // taps of both eyes of a lane's 4 pixels from the interleaved cells of box `b` (fixed-point rows `sy`), blend, store
 // into output row `j`
 __device__ __forceinline__ void sample_pair_cells(units_cptr U, const TileIds& t, int j, const TileBox& b, const uint32_t* boxw,
@@ -1709,7 +1760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
         if (lin >= (unsigned)a.n_rest)
             return;
-        const uint32_t v = a.rest_list[lin];
+        const uint32_t v = ((const V1C_CONST uint32_t*)a.rest_list)[lin];
         shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, a.half_dwords,
                                                   tabw, (glb_u32_ptr) nullptr);
         return;
@@ -1740,7 +1791,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     d2 tv = {0.0, 0.0};
     const bool mpoly = (b.interior & 2) != 0;
     if (tid < b.nidx * 4)
-        tv = ((const d2*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs))[tid];
+        tv = ((const d2*)(radial_table(P, mpoly) + (size_t)b.idx0 * kRadialCoefs))[tid];
     RowCol rc;
     load_rowcol<0>(P, t.xc, t.jc, rc);
     stage_store_pair(M, S0, S1, dyn_box);
@@ -1927,6 +1978,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 NE raw boxes (or the general code's cell buffers)
     args_cref a = kernel_args();
+    touch_args(a);
     const int tid = threadIdx.x;
     // grid: first `rest_rows` rows of workgroups for the tiles this path leaves out (general pair code: they take longest, so
     // they are dispatched first -- dispatched last they were a tail: C1 0.0188 -> 0.0245 ms), then the rows of tile pairs
@@ -1935,7 +1987,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
         if (lin >= (unsigned)a.n_rest)
             return;
-        const uint32_t v = a.rest_list[lin];
+        const uint32_t v = ((const V1C_CONST uint32_t*)a.rest_list)[lin];
         shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, NE, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, a.half_dwords,
                                                   tabw, (glb_u32_ptr) nullptr);
         return;
@@ -1948,11 +2000,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
     // tile rows 0 .. TY / 2: row 0 of the image has no mirror image (its band row would be row H: not stored), row H / 2 is its
     // own (tile row TY / 2 and its band rewrite rows their neighbours write too -- with the same bytes)
-    const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
+    const TileIds t = tile_ids(a, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
+    // the row / column table entries depend on nothing but the argument block: requested first, in flight during the second round of
+    // scalar loads (one clause: the two tile boxes, the plan's constants and table pointers, the unit(s))
     RowCol rc;
-    // the row / column table entries do not depend on the box: requested first, so that waiting for them never waits for a box
-    load_rowcol<0>(P, t.xc, t.jc, rc);
+    load_rowcol<0>(a, t.xc, t.jc, rc);
     const TileBox b = load_tile_box(a.boxes, t.box_tile), q = load_tile_box(a.mboxes, t.box_tile);
+    touch_plan_and_units<0, NE>(c, U, 0, NE - 1);
     const int nwp = a.kb;
     if (mirror_raw_fit(b, q, nwp, g.src_h, g.src_w) != 1)
         return;
@@ -1970,7 +2024,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {  // table slice: nidx * 4 units of 16 bytes, one pass (units past the slice: clamped, they land in the unused tail of tabw)
         const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
-        const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
+        const uint8_t* gp = (const uint8_t*)(radial_table(P, mpoly) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
@@ -2046,6 +2100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 raw boxes of a.kb KB (or the general code's cell buffers)
     args_cref a = kernel_args();
+    touch_args(a);
     const int tid = threadIdx.x;
     const unsigned rest_rows = REST ? a.rest_rows : 0u;
     if constexpr (REST) {
@@ -2053,7 +2108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
             const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
             if (lin >= (unsigned)a.n_rest)
                 return;
-            const uint32_t v = a.rest_list[lin];
+            const uint32_t v = ((const V1C_CONST uint32_t*)a.rest_list)[lin];
             shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
                                                       a.half_dwords, tabw, (glb_u32_ptr) nullptr);
             return;
@@ -2065,10 +2120,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
     ray_cref P = c.ray;
     int tx, ty;
     xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
-    const TileIds t = tile_ids(g, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
+    const TileIds t = tile_ids(a, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
     RowCol rc;
-    load_rowcol<0>(P, t.xc, t.jc, rc);
+    load_rowcol<0>(a, t.xc, t.jc, rc);
     const TileBox b = load_tile_box(a.boxes, t.box_tile), q = load_tile_box(a.mboxes, t.box_tile);
+    touch_plan_and_units<0, 2>(c, U, 0, 1);
     const int cap_kb = a.kb;
     if (mirror_raw_fit(b, q, cap_kb, g.src_h, g.src_w) != 1)
         return;
@@ -2082,7 +2138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {
         const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
-        const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
+        const uint8_t* gp = (const uint8_t*)(radial_table(P, mpoly) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
@@ -2154,6 +2210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
     args_cref a = kernel_args();
+    touch_args(a);
     const int tid = threadIdx.x;
     int zl = (int)blockIdx.z;
     if (a.rest_list != nullptr)
@@ -2164,7 +2221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
         if (lin >= (unsigned)a.n_rest * pairs)
             return;
         const unsigned ti = lin / pairs, zg = lin - ti * pairs;
-        const uint32_t v = a.rest_list[ti];
+        const uint32_t v = ((const V1C_CONST uint32_t*)a.rest_list)[ti];
         shared_map_tile<VAR_W, ROT, 2, OWN, 1, NT, 0>(a, a.n_units, 2, (int)zg, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
                                                       a.half_dwords, tabw, (glb_u32_ptr) nullptr);
         return;
@@ -2177,11 +2234,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty);
     const int upb = a.upb, nwp = a.kb;
     const int z0 = zl * upb;
-    const TileIds t = tile_ids(g, z0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
+    const TileIds t = tile_ids(a, z0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
     const int nu = min(upb, a.n_units - z0);
     RowCol rc;
-    load_rowcol<ROT>(P, t.xc, t.jc, rc);
+    load_rowcol<ROT>(a, t.xc, t.jc, rc);
     const TileBox b = load_tile_box(a.boxes, t.box_tile);
+    touch_plan_and_units<ROT, 1>(c, U, z0, z0);
     if (!lean_raw_static_ok(b, nwp, g.src_h, g.src_w))
         return;
     const bool mpoly = OWN == 0 && (b.interior & 2) != 0;
@@ -2196,7 +2254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     const RawLanes ml = raw_lanes(b.cpr, lane);
     {
         const uint32_t u = min((uint32_t)tid, (uint32_t)(b.nidx * 4 - 1));
-        const uint8_t* gp = (const uint8_t*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
+        const uint8_t* gp = (const uint8_t*)(radial_table(P, mpoly) + (size_t)b.idx0 * kRadialCoefs) + u * 16u;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)gp, (lds_void_ptr)(uintptr_t)(lds_tab + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u), 16, 0, 0);
     }
     // Requests are counted per wave in issue order (vmcnt's order): `issued` so far, `done_at[i]` = the count right behind the
@@ -2343,6 +2401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     // dynamic LDS: two box buffers of slot_bytes (rot_unit_tile: its BGRx box of kBoxBytes + 16) | kRotPairRedInts ints
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
     args_cref a = kernel_args();
+    touch_args(a);
     ctx_cref c = args_ctx(a);
     const units_cptr U = args_units(a);
     geom_cref g = c.g;
@@ -2357,7 +2416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     const uint32_t red_off = (uint32_t)max(2 * slot_bytes, kBoxBytes + 16);
     int* red = (int*)((uint8_t*)dyn_box + red_off);
     const glb_u32_ptr wtab = (glb_u32_ptr) nullptr;  // (bilinear: no weight table)
-    const bool tile_full = ((btx + 1) * kTW <= g.dst_w) & ((bty + 1) * (NT / kLanesX) <= g.dst_h);
+    const bool tile_full = ((btx + 1) * kTW <= a.dst_w) & ((bty + 1) * (NT / kLanesX) <= a.dst_h);
     if (!tile_full) {
         rot_unit_tile<VAR_W, 1, 2, 0, MP>(a, zA, btx, bty, red, dyn_box, wtab);
         if (hasB) {
@@ -2366,11 +2425,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
         }
         return;
     }
-    const TileIds t = tile_ids(g, zA, tid, btx, bty, gridDim.x, NT / kLanesX);
+    const TileIds t = tile_ids(a, zA, tid, btx, bty, gridDim.x, NT / kLanesX);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box;
     RowCol rc;
-    load_rowcol<1>(P, t.xc, t.jc, rc);
+    load_rowcol<1>(a, t.xc, t.jc, rc);  // (in flight during the scalar round below)
+    touch_plan_and_units<1, 2>(c, U, zA, hasB ? zB : zA);
     // box of all 1024 pixels of a unit -> is the tile interior, does its raw box fit a buffer
     auto raw_box = [&](const BoxAll& ba, int z, TileBox& b) -> bool {
         b.x0 = ba.xmin & ~3, b.y0 = ba.ymin;
@@ -2521,7 +2581,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     typedef double __attribute__((ext_vector_type(2))) d2;
     d2 tv = {0.0, 0.0};
     if (tab_lds && tid < b.nidx * 4)
-        tv = ((const d2*)((mpoly ? P.radial_m : P.radial) + (size_t)b.idx0 * kRadialCoefs))[tid];
+        tv = ((const d2*)(radial_table(P, mpoly) + (size_t)b.idx0 * kRadialCoefs))[tid];
     RowCol rc;
     load_rowcol<ROT>(P, t.xc, t.jc, rc);
     if (tab_lds && tid < b.nidx * 4)
@@ -2601,7 +2661,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 }
 
 // ---- host side: the argument block of a launch ----
-static TileArgs tile_args(const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags)
+static TileArgs tile_args(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags)
 {
     TileArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -2609,6 +2669,9 @@ static TileArgs tile_args(const KernelCtx* cdev, const LaunchUnits& lu, uint32_t
     a.units = lu.dev;
     a.tile_flags = flags;
     a.n_units = lu.n;
+    a.col_s = c.ray.col_s, a.col_c = c.ray.col_c, a.col_h = c.ray.col_h;
+    a.row_s = c.ray.row_s, a.row_c = c.ray.row_c, a.row_h = c.ray.row_h;
+    a.dst_w = c.g.dst_w, a.dst_h = c.g.dst_h;
     if (!lu.dev)  // (lu.n <= kInlineUnits: plan.hip)
         std::memcpy(a.inl, lu.host, sizeof(DevUnit) * (size_t)std::min(lu.n, kInlineUnits));
     return a;
@@ -2714,7 +2777,7 @@ hipError_t launch_ray_lin_cn(const KernelCtx& c, const KernelCtx* cdev, const La
                              int kb, hipStream_t stream)
 {
     const dim3 block(256, 1, 1), grid = tile_grid(c.g, 256, 1);
-    TileArgs a = tile_args(cdev, lu, flags);
+    TileArgs a = tile_args(c, cdev, lu, flags);
     a.boxes = (const TileBox*)boxes;
     a.kb = kb;
     a.tiles_x_magic = (unsigned)(0x100000000ull / grid.x) + 1u;
@@ -2829,7 +2892,7 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const KernelCtx* cdev
     const int n_eyes = lu.n;
     const dim3 full = tile_grid(c.g, 256, 1);
     const dim3 block(256, 1, 1);
-    TileArgs a = tile_args(cdev, lu, flags);
+    TileArgs a = tile_args(c, cdev, lu, flags);
     a.boxes = (const TileBox*)boxes, a.mboxes = (const TileBox*)mboxes;
     a.rest_list = rest_list, a.n_rest = n_rest;
     a.half_dwords = half_dwords, a.mirror_h = mirror_h;
@@ -3108,6 +3171,9 @@ hipError_t launch_tile_boxes(const KernelCtx& c, const KernelCtx* cdev, void* bo
     a.ctx = cdev;
     a.boxes = (const TileBox*)boxes;
     a.mirror_h = mirror_h;
+    a.col_s = c.ray.col_s, a.col_c = c.ray.col_c, a.col_h = c.ray.col_h;
+    a.row_s = c.ray.row_s, a.row_c = c.ray.row_c, a.row_h = c.ray.row_h;
+    a.dst_w = c.g.dst_w, a.dst_h = c.g.dst_h;
     switch (taps_of(c.g.interp)) {
     case 2: launch_boxes_k<2, 256>(c, a, shared_entry, stream); break;
     case 4: launch_boxes_k<4, 256>(c, a, shared_entry, stream); break;
@@ -3192,7 +3258,7 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
         const char* e = tuning_env("V1C_NOBOX_STRIP_ROWS");
         return e ? (unsigned)std::atoi(e) : 0u;
     }();
-    TileArgs a = tile_args(cdev, lu, flags);
+    TileArgs a = tile_args(c, cdev, lu, flags);
     a.boxes = bx;
     a.upb = upb, a.half_dwords = half_dwords;
     a.tiles_x = (int)grid.x;
