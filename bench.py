@@ -82,6 +82,14 @@ WORKLOADS = {
                 desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, bilinear (k_ray_lin_cn since r03; not a BASELINE config)"),
     "C2A": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=4,
                 desc="L+R 4096x4096 BGRA -> 8192x4096 SBS, PolynomialScaler, bilinear (k_ray_lin_cn since r03; not a BASELINE config)"),
+    "C2GN": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=0, cn=1,
+                 desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, INTER_NEAREST (k_ray_lin_cn since r04; not a BASELINE config)"),
+    "C2AN": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=0, cn=4,
+                 desc="L+R 4096x4096 BGRA -> 8192x4096 SBS, PolynomialScaler, INTER_NEAREST (k_ray_lin_cn since r04; not a BASELINE config)"),
+    "C2GL": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=4, cn=1,
+                 desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, INTER_LANCZOS4 (k_ray_lin_cn K = 8 since r04; not a BASELINE config)"),
+    "C2AL": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=4, cn=4,
+                 desc="L+R 4096x4096 BGRA -> 8192x4096 SBS, PolynomialScaler, INTER_LANCZOS4 (k_ray_lin_cn K = 8 since r04; not a BASELINE config)"),
     "C2C": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=2,
                 desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_CUBIC (the K x K tile kernel with 4 x 4 taps; not a BASELINE config)"),
     "C2L": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=4,

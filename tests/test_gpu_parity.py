@@ -239,14 +239,17 @@ def test_nearest_through_the_tile_kernels(V, oracle_mod, dev):
         assert np.array_equal(dsts[f].cpu().numpy(), want), f
 
 
-def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev):
-    """Grayscale and BGRA sources (cv2.remap takes whatever array the caller passes, remapper.py:388-398) run k_ray_lin_cn:
-    plain and rotated chains, every border mode (TRANSPARENT over a pre-filled destination), batches of 1 - 5 units sharing the map,
+@pytest.mark.parametrize("interp", [1, 0, 2, 4])
+def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev, interp):
+    """Grayscale and BGRA sources (cv2.remap takes whatever array the caller passes, remapper.py:388-398) run k_ray_lin_cn: INTER_LINEAR
+    and (round 4) INTER_NEAREST, INTER_CUBIC, INTER_LANCZOS4: plain and rotated chains, every border mode (TRANSPARENT over a pre-filled
+    destination: bilinear in the tile kernel, the others in the generic one), batches of 1 - 5 units sharing the map, units with a
+    rotation of their own (boxes reduced in the kernel),
     odd output sizes, sources that are pitched views, a radius larger than the source (rays leaving it) -- every byte against the oracle."""
     from vr180_convert_amd.synth import noise_disc
 
     O = oracle_mod
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(777 + interp)
     specs = ([("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI],
              [("equirect_enc", True), ("rot", CS.ry(0.3)), ("poly", [0, 1, -0.1]), CS.EQUI])
     for cn in (1, 4):
@@ -262,11 +265,11 @@ def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev):
                 fill = rng.integers(0, 256, (ho, wo, cn), dtype=np.uint8)
                 dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in range(n)]
                 radius = 140.0 if border != 4 else 190.0
-                modes = V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=radius, interpolation=1, boarder_mode=border, boarder_value=bval)
+                modes = V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=radius, interpolation=interp, boarder_mode=border, boarder_value=bval)
                 assert modes == ["ray"], modes
                 xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
                 for k in range(n):
-                    want = O.remap(imgs[k], xm, ym, 1, border, bval, dst=fill.copy())
+                    want = O.remap(imgs[k], xm, ym, interp, border, bval, dst=fill.copy())
                     got = dsts[k].cpu().numpy()
                     assert np.array_equal(got, want), (cn, si, border, k, int((got != want).sum()))
     # seeded random geometries: odd / tiny / non-square sizes, radii beyond the source, negative radii, 1 - 6 units
@@ -284,20 +287,36 @@ def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev):
         imgs = [rng.integers(0, 256, (hs, ws, cn), dtype=np.uint8) for _ in range(n)]
         fill = rng.integers(0, 256, (ho, wo, cn), dtype=np.uint8)
         dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in range(n)]
-        V.remap_tensors(CS.to_product(spec), [torch.from_numpy(i).to(dev) for i in imgs], dsts, radius=radius, interpolation=1,
+        V.remap_tensors(CS.to_product(spec), [torch.from_numpy(i).to(dev) for i in imgs], dsts, radius=radius, interpolation=interp,
                         boarder_mode=border, boarder_value=bval)
         xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
         for k in range(n):
-            want = O.remap(imgs[k], xm, ym, 1, border, bval, dst=fill.copy())
+            want = O.remap(imgs[k], xm, ym, interp, border, bval, dst=fill.copy())
             got = dsts[k].cpu().numpy()
             assert np.array_equal(got, want), (case, cn, spec, (wo, ho), (ws, hs), border, radius, k, int((got != want).sum()))
+    # units that override the rotation (per-frame calibration on gray / BGRA frames): k_ray_lin_cn<..., BOXES = 0>
+    from vr180_convert_amd import transformer as T
+
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    for cn in (1, 4):
+        for (hs, ws, wo, ho, radius, border) in ((256, 256, 256, 256, 128.0, 0), (200, 320, 333, 129, 170.0, 1), (96, 64, 70, 50, 30.0, 4)):
+            imgs = [rng.integers(0, 256, (hs, ws, cn), dtype=np.uint8) for _ in range(5)]
+            quats = [CS.c5_spec(f // 2, f % 2)[1][1] for f in range(5)]
+            dsts = [torch.zeros((ho, wo, cn), dtype=torch.uint8, device=dev) for _ in range(5)]
+            assert V.remap_tensors(base, [torch.from_numpy(i).to(dev) for i in imgs], dsts, radius=radius, interpolation=interp,
+                                   boarder_mode=border, rotations=quats) == ["ray"]
+            for f in range(5):
+                xm, ym = O.get_map(CS.c5_spec(f // 2, f % 2), radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+                want = O.remap(imgs[f], xm, ym, interp, border, 0)
+                got = dsts[f].cpu().numpy()
+                assert np.array_equal(got, want), ("rot", cn, (hs, ws), f, int((got != want).sum()))
     # a full-size pair of gray halves, box buffers too small for most tiles (V1C_CN_KB is a tuning-build switch; here: huge magnification)
     img = rng.integers(0, 256, (1024, 1024, 1), dtype=np.uint8)
     d = torch.empty((96, 96, 1), dtype=torch.uint8, device=dev)
     spec = [("equirect_enc", True), ("zoom", 0.08), CS.EQUI]
-    V.remap_tensors(CS.to_product(spec), [torch.from_numpy(img).to(dev)], [d], radius=512.0, interpolation=1)
+    V.remap_tensors(CS.to_product(spec), [torch.from_numpy(img).to(dev)], [d], radius=512.0, interpolation=interp)
     xm, ym = O.get_map(spec, radius=512.0, size_input=(1024, 1024), size_output=(96, 96))
-    assert np.array_equal(d.cpu().numpy(), O.remap(img, xm, ym, 1, 0, 0))
+    assert np.array_equal(d.cpu().numpy(), O.remap(img, xm, ym, interp, 0, 0))
 
 
 def test_seeded_random_cases_bit_exact(V, oracle_mod, dev):

@@ -186,7 +186,9 @@ def test_cn_kernel_waits_for_every_request_before_the_barrier(kernels_dis):
     LDS-DMA request is followed by a plain ``s_barrier`` without the wait in front of it."""
     for name, ins in pick(kernels_dis, "k_ray_lin_cn").items():
         analyse(ins)
-        assert sum(x.kind == "D" for x in ins) >= 2, name
+        # (template arguments VAR_W, ROT, CN, NN, K, BOXES: without plan-time boxes a workgroup serves ONE unit -- one request site)
+        one_unit = re.search(r"k_ray_lin_cnILi\dELi\dELi\dELi\dELi\dELi0EE", name) is not None
+        assert sum(x.kind == "D" for x in ins) >= (1 if one_unit else 2), name
         full_waits = [i for i, x in enumerate(ins) if x.kind == "W" and "vmcnt(0)" in x.args]
         assert full_waits, name
         for i, x in enumerate(ins):

@@ -852,9 +852,12 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
                                                 n == 1 ? p->mirror_rest1 : p->mirror_rest, n == 1 ? p->n_mirror_rest1 : p->n_mirror_rest,
                                                 p->mirror_raw_nwp, st, p->mirror_seq_kb));
         } else if (d.fast && p->ctx.g.cn != 3) {
-            // grayscale / BGRA: k_ray_lin_cn (plan-time boxes: the plan's own rotation only; one table entry per lane)
+            // grayscale / BGRA: k_ray_lin_cn (one table entry per lane; plan-time boxes for the plan's own rotation, boxes reduced in the
+            // kernel -- one unit per workgroup, a 12 KB buffer -- for units that override it)
             if (p->cn_kb > 0 && !d.any_rot && shared && aligned)
                 HIP_TRY(launch_ray_lin_cn(p->ctx, p->ctx_dev, lu, flags, p->ana.has_rot, p->tile_boxes, p->cn_kb, st));
+            else if (d.any_rot && shared && aligned && cn_kernel_supports(p->ctx.g))
+                HIP_TRY(launch_ray_lin_cn(p->ctx, p->ctx_dev, lu, flags, true, nullptr, 12, st));
             else
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, unit_args(u, n), n, st));
         } else if (d.fast) {
