@@ -101,6 +101,12 @@ WORKLOADS = {
     # batch shapes: `frames` SBS frames per GPU per step (BASELINE configs 3 and 5 shard 8 resp. 32 per GPU)
     "C3": dict(size=2880, poly=None, rot=None, interp=1, frames=8,
                desc="8 SBS frames 5760x2880 per GPU (of 64 over 8 GPUs), equidistant, bilinear"),
+    "C5G": dict(size=1920, poly=None, rot="calib", interp=1, frames=8, cn=1,
+                desc="8 GRAY SBS frames 3840x1920 per GPU, per-frame per-eye calibration rotation, bilinear (k_ray_lin_cn without plan-time boxes "
+                     "since r04; not a BASELINE config)"),
+    "C5A": dict(size=1920, poly=None, rot="calib", interp=1, frames=8, cn=4,
+                desc="8 BGRA SBS frames 3840x1920 per GPU, per-frame per-eye calibration rotation, bilinear (k_ray_lin_cn without plan-time boxes "
+                     "since r04; not a BASELINE config)"),
     "C5": dict(size=3840, poly=None, rot="calib", interp=1, frames=32,
                desc="32 SBS frames 7680x3840 per GPU (of 256 over 8 GPUs), per-frame per-eye calibration rotation, bilinear"),
 }
@@ -484,8 +490,8 @@ def main() -> None:
         if cfg["rot"] == "calib":
             rots = [m for f in mine for m in calib_rotations(f)]
         for k in range(nsets):
-            ins = [noise_disc_torch(size, 2 * size, f + 100003 * k, dev) for f in mine]
-            outs = [torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev) for _ in mine]
+            ins = [noise_disc_torch(size, 2 * size, f + 100003 * k, dev, cn) for f in mine]
+            outs = [torch.empty((size, 2 * size, cn), dtype=torch.uint8, device=dev) for _ in mine]
             sets.append(dict(srcs=[v for fr in ins for v in (fr[:, :size], fr[:, size:])],
                              dsts=[v for fr in outs for v in (fr[:, :size], fr[:, size:])], sbs=outs[0]))
 
