@@ -65,4 +65,4 @@ def test_tile_kernels_take_one_argument_block_at_offset_zero(product_kernels):
     assert len(sizes) == 1
     put = [k for k in product_kernels if "k_put_units" in k[".name"]]
     assert len(put) == 1
-    assert put[0][".args"][1][".value_kind"] == "by_value" and put[0][".args"][1][".offset"] == 8 and put[0][".args"][1][".size"] == 1792
+    assert put[0][".args"][1][".value_kind"] == "by_value" and put[0][".args"][1][".offset"] == 8 and put[0][".args"][1][".size"] == 32 * 112

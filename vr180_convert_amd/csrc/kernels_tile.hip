@@ -2824,8 +2824,14 @@ static bool units_dword_aligned(const LaunchUnits& lu)
 }
 
 // Units of a launch longer than the kernel-argument block holds: copied into a slot of the plan's device ring by launches of their
-// own (16 records each, carried in THEIR kernel arguments): stream-ordered, graph-capturable, no staging buffer to keep alive.
-__global__ __launch_bounds__(256) void k_put_units(DevUnit* dst, UnitArgs ua_, int n)
+// own (kPutUnits records each, carried in THEIR kernel arguments -- 3.6 KB of the 4 KB a launch may carry): stream-ordered,
+// graph-capturable, no staging buffer to keep alive.  A 64-unit launch (BASELINE config 5 per GPU) costs two of them, ~9 us in front
+// of a 2.3 ms launch.
+constexpr int kPutUnits = 32;
+struct PutArgs {
+    DevUnit u[kPutUnits];
+};
+__global__ __launch_bounds__(256) void k_put_units(DevUnit* dst, PutArgs ua_, int n)
 {
     typedef const V1C_CONST uint32_t* cu32;
     const cu32 src = (cu32)((const V1C_CONST uint8_t*)__builtin_amdgcn_kernarg_segment_ptr() + 8);  // (behind `dst`)
@@ -2836,10 +2842,11 @@ __global__ __launch_bounds__(256) void k_put_units(DevUnit* dst, UnitArgs ua_, i
 
 hipError_t launch_put_units(DevUnit* dst, const DevUnit* host, int n, hipStream_t stream)
 {
-    static_assert(sizeof(DevUnit) % 4 == 0 && alignof(UnitArgs) == 8, "k_put_units reads its records at byte 8 of the kernel arguments");
-    for (int base = 0; base < n; base += kMaxUnitsPerLaunch) {
-        const int m = std::min(kMaxUnitsPerLaunch, n - base);
-        UnitArgs ua;
+    static_assert(sizeof(DevUnit) % 4 == 0 && alignof(PutArgs) == 8 && sizeof(PutArgs) + 16 <= 4096,
+                  "k_put_units reads its records at byte 8 of the kernel arguments");
+    for (int base = 0; base < n; base += kPutUnits) {
+        const int m = std::min(kPutUnits, n - base);
+        PutArgs ua;
         std::memset(&ua, 0, sizeof(ua));
         std::memcpy(ua.u, host + base, sizeof(DevUnit) * (size_t)m);
         hipLaunchKernelGGL(k_put_units, dim3(1), dim3(256), 0, stream, dst + base, ua, m);
