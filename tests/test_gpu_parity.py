@@ -1277,6 +1277,50 @@ def test_one_plan_from_two_threads_and_streams(V, oracle_mod, dev):
     assert not errs, errs[:5]
 
 
+def test_unit_ring_from_two_threads_and_streams(V, oracle_mod, dev):
+    """One plan, two threads, a stream each, launches of 20 units with a rotation per unit: both go through the plan's unit ring
+    (4 slots: each thread's launches reuse slots the other thread's launches have just used -- the slot events order them across
+    streams), every output against the oracle."""
+    import threading
+
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.synth import noise_disc
+
+    O = oracle_mod
+    n, size = 20, 192
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    sets = []
+    for k in range(2):
+        imgs = [noise_disc(size, size, 900 + 50 * k + f) for f in range(n)]
+        quats = [CS.c5_spec(7 * k + f // 2, f % 2)[1][1] for f in range(n)]
+        want = [O.apply(CS.c5_spec(7 * k + f // 2, f % 2), [imgs[f]], size_output=(size, size), interpolation=1, radius=size / 2)[0] for f in range(n)]
+        sets.append((imgs, quats, want))
+    errs: list = []
+
+    def work(k: int) -> None:
+        try:
+            imgs, quats, want = sets[k]
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+                for it in range(12):
+                    dsts = [torch.zeros_like(x) for x in srcs]
+                    V.remap_tensors(base, srcs, dsts, radius=size / 2, interpolation=1, rotations=quats)
+                    s.synchronize()
+                    for f in range(n):
+                        if not np.array_equal(dsts[f].cpu().numpy(), want[f]):
+                            errs.append((k, it, f))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs[:5]
+
+
 def test_remap_sharded_on_the_devices_there_are(V, oracle_mod):
     """sharding.remap_sharded: the in-process multi-device dispatcher (worker thread + stream + staging ring
     per device).  One GPU on the test box: devices=[0] and devices=[0, 0] (two workers sharing the card)

@@ -5,8 +5,9 @@ lanes (the by-value KernelCtx + UnitArgs arguments pinned 98 of the 102 SGPRs). 
 through constant-address-space references (csrc/kernels.hpp); this test keeps it that way:
 
 * no kernel of the shipped library uses scratch or spills a register (the -DV1C_TUNING twin may: its general batch loop is an A/B form);
-* the tile kernels' one by-value argument sits at byte 0 of the kernel-argument segment and k_put_units' records at byte 8 -- the
-  kernels address them through ``__builtin_amdgcn_kernarg_segment_ptr()`` at exactly those offsets.
+* the tile kernels' one by-value argument sits at byte 0 of the kernel-argument segment (byte 48 behind the preloaded head of the mirror
+  kernels) and k_put_units' records at byte 8 -- the kernels address them through ``__builtin_amdgcn_kernarg_segment_ptr()`` at exactly
+  those offsets.
 """
 import shutil
 import subprocess
@@ -54,15 +55,24 @@ def test_no_kernel_of_the_product_uses_scratch_or_spills(product_kernels):
     assert not bad, bad
 
 
-def test_tile_kernels_take_one_argument_block_at_offset_zero(product_kernels):
+def test_tile_kernels_take_one_argument_block_at_a_known_offset(product_kernels):
     tile = [k for k in product_kernels if "8TileArgsE" in k[".name"]]
     assert len(tile) > 100
+    sizes = set()
+    n_head = 0
     for k in tile:
-        a0 = k[".args"][0]
-        assert a0[".value_kind"] == "by_value" and a0[".offset"] == 0, k[".name"]
-        assert all(a[".value_kind"].startswith("hidden_") for a in k[".args"][1:]), k[".name"]
-    sizes = {k[".args"][0][".size"] for k in tile}
-    assert len(sizes) == 1
+        explicit = [a for a in k[".args"] if not a[".value_kind"].startswith("hidden_")]
+        block = explicit[-1]
+        assert block[".value_kind"] == "by_value", k[".name"]
+        sizes.add(block[".size"])
+        if "pair_mirror_raw" in k[".name"] or "pair_mirror_seq" in k[".name"]:
+            # V1C_MIRROR_HEAD: eight scalar parameters (11 dwords, preloaded into SGPRs at wave start) in front of the block at byte 48
+            assert len(explicit) == 9 and block[".offset"] == 48, (k[".name"], block[".offset"])
+            assert [a[".offset"] for a in explicit[:8]] == [0, 8, 12, 16, 20, 24, 32, 40], k[".name"]
+            n_head += 1
+        else:
+            assert len(explicit) == 1 and block[".offset"] == 0, k[".name"]
+    assert len(sizes) == 1 and n_head >= 6
     put = [k for k in product_kernels if "k_put_units" in k[".name"]]
     assert len(put) == 1
     assert put[0][".args"][1][".value_kind"] == "by_value" and put[0][".args"][1][".offset"] == 8 and put[0][".args"][1][".size"] == 32 * 112

@@ -51,7 +51,8 @@ struct TileArgs {
     const KernelCtx* ctx;        // plan-resident copy (device memory)
     const DevUnit* units;        // null: the launch's units are `inl` below; else n_units records in device memory
     const TileBox* boxes;        // plan-time tile boxes (null: units that override the rotation reduce theirs in the kernel)
-    const TileBox* mboxes;       // ... of the bands that mirror the tiles (mirror launches)
+    const TileBox* mboxes;       // mirror launches: (tile box, box of the band that mirrors it) pairs, 64 bytes per tile
+                                 // (tuning build, register-staged k_ray_lin3_pair_mirror: the plain array of band boxes)
     const uint32_t* rest_list;   // tiles (ty << 16 | tx) a launch's fast path leaves to its general code / the tile list of a LIST launch
     uint32_t* tile_flags;        // one word per (unit slot, tile) for the fix-up pass behind this launch; null: proven unnecessary
     int n_units, upb;            // units of the launch, units per workgroup group

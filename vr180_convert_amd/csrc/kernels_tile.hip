@@ -54,9 +54,36 @@ typedef const V1C_CONST TileArgs& args_cref;
 typedef const V1C_CONST double* rot_cptr;  // 9 doubles, row-major
 
 // the kernel's own argument block (its one by-value parameter: offset 0 of the kernel-argument segment)
+template <int OFFSET = 0>
 __device__ __forceinline__ args_cref kernel_args()
 {
-    return *(const V1C_CONST TileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const V1C_CONST TileArgs*)((const V1C_CONST uint8_t*)__builtin_amdgcn_kernarg_segment_ptr() + OFFSET);
+}
+
+// ---- the preloaded head of the mirror launches ----
+// gfx950 can hand a kernel its first kernel-argument dwords in scalar registers at wave start (14 of them next to the kernel-argument
+// pointer; -mllvm -amdgpu-kernarg-preload-count=16: csrc/Makefile).  The mirror kernels -- the launches that ARE one chain of dependent
+// memory round trips (config 1: one round of workgroups) -- take what their first loads need that way, as eight scalar parameters in front
+// of the argument block: the (tile, band) box pairs, the tile-order constants, the destination size, the base of the plan's six row /
+// column tables (one buffer: plan.hip), the plan's context and the box buffer size / mirror row.  Box pair, row / column values, the
+// context's constants and the pair's unit records (in the block at a known offset) are then ALL requested at once: the fast path's scalar
+// chain is one round trip instead of three.  (A struct parameter cannot be preloaded, hence the packing: 11 dwords.)
+#define V1C_MIRROR_HEAD                                                                                                                  \
+    const TileBox *pairs, unsigned tiles_x_magic, unsigned gx_rest /* tiles_x | rest_rows << 16 */,                                      \
+        unsigned rows_strip /* rows of tile pairs | XCD strip rows (0 / 2) << 16 */, unsigned dst_wh /* dst_w | dst_h << 16 */,          \
+        const double *rowcol_tables, const KernelCtx *ctxp, unsigned kb_mh /* box buffer KB | mirror row << 16 */
+constexpr int kMirrorHeadBytes = 48;
+struct DstSize {
+    int dst_w, dst_h;
+};
+struct RowColTabs {
+    const double *col_s, *col_c, *col_h, *row_s, *row_c, *row_h;
+};
+// the six tables of a plan from the base of their buffer (plan.hip: col_s | col_c | col_h of wpad entries, row_s | row_c | row_h of dst_h)
+__device__ __forceinline__ RowColTabs rowcol_tables_at(const double* base, int dst_w, int dst_h)
+{
+    const int wpad = (dst_w + 3) & ~3;
+    return RowColTabs{base, base + wpad, base + 2 * wpad, base + 3 * wpad, base + 3 * wpad + dst_h, base + 3 * wpad + 2 * dst_h};
 }
 __device__ __forceinline__ ctx_cref args_ctx(args_cref a)
 {
@@ -213,6 +240,20 @@ __device__ __forceinline__ TileBox load_tile_box(const TileBox* boxes, int tile)
     TileBox b;
     b.x0 = b0.x, b.y0 = b0.y, b.cpr = b0.z, b.nrows = b0.w, b.idx0 = b1.x, b.nidx = b1.y, b.interior = b1.z, b.magic = b1.w;
     return b;
+}
+
+// the mirror launches' (tile box, band box) pair: one 64-byte entry, one scalar load
+struct TileBoxPair {
+    TileBox b, q;
+};
+__device__ __forceinline__ TileBoxPair load_tile_box_pair(const TileBox* pairs, int tile)
+{
+    typedef int __attribute__((ext_vector_type(16))) i32x16;
+    const i32x16 v = *(const V1C_CONST i32x16*)(pairs + 2 * __builtin_amdgcn_readfirstlane(tile));
+    TileBoxPair r;
+    r.b.x0 = v[0], r.b.y0 = v[1], r.b.cpr = v[2], r.b.nrows = v[3], r.b.idx0 = v[4], r.b.nidx = v[5], r.b.interior = v[6], r.b.magic = v[7];
+    r.q.x0 = v[8], r.q.y0 = v[9], r.q.cpr = v[10], r.q.nrows = v[11], r.q.idx0 = v[12], r.q.nidx = v[13], r.q.interior = v[14], r.q.magic = v[15];
+    return r;
 }
 
 // ceil(2^20 / cpr) for cpr = 1 .. kMaxCpr (a wave-uniform table read instead of an integer division,
@@ -1469,19 +1510,20 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
 // kernel is as slow as its slowest XCD.  `strip_magic` = floor(2^32 / strip_len) + 1.
 // `rows`, `row0`: the swizzled part of the grid is rows row0 .. row0 + rows - 1 of workgroups (0: all of gridDim.y); row0 *
 // gridDim.x must be a multiple of 8 (the XCD of a workgroup is its linear id modulo 8)
-__device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, unsigned strip_magic, int& tx, int& ty, unsigned rows = 0,
-                                         unsigned row0 = 0)
+// `gx`, `gy`: the grid (read from the launch's hidden kernel arguments by the wrapper below; the mirror kernels have them preloaded)
+__device__ __forceinline__ void xcd_tile_at(unsigned magic, unsigned strip_len, unsigned strip_magic, int& tx, int& ty, unsigned rows, unsigned row0,
+                                            const unsigned gx, const unsigned gy)
 {
     tx = blockIdx.x, ty = blockIdx.y - row0;
 #if V1C_XCD_SWIZZLE
-    const unsigned ntile = gridDim.x * (rows ? rows : gridDim.y), lin = (blockIdx.y - row0) * gridDim.x + blockIdx.x;
+    const unsigned ntile = gx * (rows ? rows : gy), lin = (blockIdx.y - row0) * gx + blockIdx.x;
     const unsigned per = ntile >> 3;  // tiles per XCD; the remainder keeps its natural order
     if (strip_len & 0x80000000u) {
-        // block mode (gridDim.x a multiple of 8): XCD x serves tile columns [x BW, (x + 1) BW), BW = gridDim.x / 8, in blocks of BH =
+        // block mode (gx a multiple of 8): XCD x serves tile columns [x BW, (x + 1) BW), BW = gx / 8, in blocks of BH =
         // strip_len & 0xffff tile rows, row-major inside a block -- the eight XCDs still work side by side in one band of BH tile rows,
         // but a block's halo (source rows / columns its neighbours fetch too) is its perimeter 2 (BW + BH) instead of the
-        // 2 (gridDim.x + 2) of a two-row strip
-        const unsigned BW = gridDim.x >> 3, BH = strip_len & 0xffffu, i = lin >> 3, x = lin & 7u;
+        // 2 (gx + 2) of a two-row strip
+        const unsigned BW = gx >> 3, BH = strip_len & 0xffffu, i = lin >> 3, x = lin & 7u;
         const unsigned blk = BW * BH, kb = i / blk, r = i - kb * blk, rr = r / BW;
         ty = (int)(kb * BH + rr);
         tx = (int)(x * BW + (r - rr * BW));
@@ -1496,10 +1538,16 @@ __device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, uns
             m = sidx < nfull ? (sidx * 8u + x) * strip_len + (i - sidx * strip_len)
                              : nfull * 8u * strip_len + x * (per - nfull * strip_len) + (i - nfull * strip_len);
         }
-        ty = gridDim.x == 1 ? (int)m : (int)__umulhi(m, magic);  // (2^32 / 1 + 1 does not fit the magic)
-        tx = (int)(m - (unsigned)ty * gridDim.x);
+        ty = gx == 1 ? (int)m : (int)__umulhi(m, magic);  // (2^32 / 1 + 1 does not fit the magic)
+        tx = (int)(m - (unsigned)ty * gx);
     }
 #endif
+}
+
+__device__ __forceinline__ void xcd_tile(unsigned magic, unsigned strip_len, unsigned strip_magic, int& tx, int& ty, unsigned rows = 0,
+                                         unsigned row0 = 0)
+{
+    xcd_tile_at(magic, strip_len, strip_magic, tx, ty, rows, row0, gridDim.x, gridDim.y);
 }
 
 // ---- one tile of ONE unit that overrides the rotation (per-frame calibration): box reduced in-kernel, table from global memory ----
@@ -1972,42 +2020,46 @@ __device__ __forceinline__ void store_pair_row(units_cptr U, const TileIds& t, i
 __device__ __forceinline__ void gather_one_raw(const TileBox& b, uint32_t raw, const int (&sx)[kPX], const int (&sy)[kPX], uint32_t (&pix)[kPX]);
 
 template <int VAR_W, int NE = 2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAVES, 8))) void k_ray_lin3_pair_mirror_raw(TileArgs a_)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAVES, 8))) void k_ray_lin3_pair_mirror_raw(V1C_MIRROR_HEAD, TileArgs a_)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 NE raw boxes (or the general code's cell buffers)
-    args_cref a = kernel_args();
-    touch_args(a);
+    args_cref a = kernel_args<kMirrorHeadBytes>();
     const int tid = threadIdx.x;
     // grid: first `rest_rows` rows of workgroups for the tiles this path leaves out (general pair code: they take longest, so
     // they are dispatched first -- dispatched last they were a tail: C1 0.0188 -> 0.0245 ms), then the rows of tile pairs
-    const unsigned rest_rows = a.rest_rows;
+    const unsigned tiles_x = gx_rest & 0xffffu, rest_rows = gx_rest >> 16;
     if (blockIdx.y < rest_rows) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned lin = blockIdx.y * tiles_x + blockIdx.x;
         if (lin >= (unsigned)a.n_rest)
             return;
         const uint32_t v = ((const V1C_CONST uint32_t*)a.rest_list)[lin];
-        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, NE, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box, a.half_dwords,
+        shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, NE, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)tiles_x, dyn_box, a.half_dwords,
                                                   tabw, (glb_u32_ptr) nullptr);
         return;
     }
-    ctx_cref c = args_ctx(a);
-    const units_cptr U = args_units(a);
-    geom_cref g = c.g;
-    ray_cref P = c.ray;
+    // from the preloaded head alone (V1C_MIRROR_HEAD): the tile, its row / column values (vector loads) and its pair of boxes (one scalar
+    // load) are requested before the argument block has been read at all
     int tx, ty;
-    xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
+    {
+        const unsigned slen = (rows_strip >> 16) * tiles_x;  // strips of 0 / 2 tile rows; floor(2^32 / (2 t)) == floor(floor(2^32 / t) / 2)
+        xcd_tile_at(tiles_x_magic, slen, ((tiles_x_magic - 1u) >> 1) + 1u, tx, ty, rows_strip & 0xffffu, rest_rows, tiles_x, 0u);
+    }
     // tile rows 0 .. TY / 2: row 0 of the image has no mirror image (its band row would be row H: not stored), row H / 2 is its
     // own (tile row TY / 2 and its band rewrite rows their neighbours write too -- with the same bytes)
-    const TileIds t = tile_ids(a, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
-    // the row / column table entries depend on nothing but the argument block: requested first, in flight during the second round of
-    // scalar loads (one clause: the two tile boxes, the plan's constants and table pointers, the unit(s))
+    const DstSize dsz{(int)(dst_wh & 0xffffu), (int)(dst_wh >> 16)};
+    const TileIds t = tile_ids(dsz, 0, tid, tx, ty, (int)tiles_x, NT / kLanesX);
     RowCol rc;
-    load_rowcol<0>(a, t.xc, t.jc, rc);
-    const TileBox b = load_tile_box(a.boxes, t.box_tile), q = load_tile_box(a.mboxes, t.box_tile);
+    load_rowcol<0>(rowcol_tables_at(rowcol_tables, dsz.dst_w, dsz.dst_h), t.xc, t.jc, rc);
+    const TileBoxPair bq = load_tile_box_pair(pairs, t.box_tile);
+    const TileBox &b = bq.b, &q = bq.q;
+    ctx_cref c = *(const V1C_CONST KernelCtx*)ctxp;
+    const units_cptr U = (units_cptr)a.inl;  // (one or two units: always the block's own records, at a known offset)
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
     touch_plan_and_units<0, NE>(c, U, 0, NE - 1);
-    const int nwp = a.kb;
+    const int nwp = (int)(kb_mh & 0xffffu);
     if (mirror_raw_fit(b, q, nwp, g.src_h, g.src_w) != 1)
         return;
     const bool mpoly = (b.interior & 2) != 0;
@@ -2029,9 +2081,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     }
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
     const uint32_t row_off = (uint32_t)t.x0 * 3u;
-    const int mirror_h = a.mirror_h;
+    const int mirror_h = (int)(kb_mh >> 16);
     const int jm = mirror_h - t.j;              // the band's row
-    const bool band_row = jm < g.dst_h;         // (false for row 0 of the image only)
+    const bool band_row = jm < dsz.dst_h;         // (false for row 0 of the image only)
     LaneCoords L;
     uint32_t p0[kPX], p1[kPX];
     const int nb = raw_box_dma(b, mb, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, raw_b);  // this wave's requests per box of the tile ...
@@ -2094,38 +2146,46 @@ __device__ __forceinline__ void gather_taps_raw(const uint32_t (&ta)[kPX], const
 // registers (74 against 68 VGPRs, 94 against 66 SGPRs) and LDS (its cell buffers) otherwise set the occupancy of a launch that never
 // runs it: 7 instead of 6 workgroups per CU
 template <int VAR_W, int REST = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_SEQ_WAVES : V1C_SEQ_WAVES + 1, 8))) void k_ray_lin3_pair_mirror_seq(TileArgs a_)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_SEQ_WAVES : V1C_SEQ_WAVES + 1, 8))) void k_ray_lin3_pair_mirror_seq(V1C_MIRROR_HEAD, TileArgs a_)
 {
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 raw boxes of a.kb KB (or the general code's cell buffers)
-    args_cref a = kernel_args();
-    touch_args(a);
+    args_cref a = kernel_args<kMirrorHeadBytes>();
     const int tid = threadIdx.x;
-    const unsigned rest_rows = REST ? a.rest_rows : 0u;
+    const unsigned tiles_x = gx_rest & 0xffffu, rest_rows = REST ? gx_rest >> 16 : 0u;
     if constexpr (REST) {
         if (blockIdx.y < rest_rows) {
-            const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned lin = blockIdx.y * tiles_x + blockIdx.x;
             if (lin >= (unsigned)a.n_rest)
                 return;
             const uint32_t v = ((const V1C_CONST uint32_t*)a.rest_list)[lin];
-            shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)gridDim.x, dyn_box,
+            shared_map_tile<VAR_W, 0, 2, 0, 1, NT, 0>(a, 2, 2, 0, (int)(v & 0xffffu), (int)(v >> 16), (int)tiles_x, dyn_box,
                                                       a.half_dwords, tabw, (glb_u32_ptr) nullptr);
             return;
         }
     }
-    ctx_cref c = args_ctx(a);
-    const units_cptr U = args_units(a);
+    // from the preloaded head alone (V1C_MIRROR_HEAD): the tile, its row / column values (vector loads) and its pair of boxes (one scalar
+    // load) are requested before the argument block has been read at all
+    int tx, ty;
+    {
+        const unsigned slen = (rows_strip >> 16) * tiles_x;  // strips of 0 / 2 tile rows; floor(2^32 / (2 t)) == floor(floor(2^32 / t) / 2)
+        xcd_tile_at(tiles_x_magic, slen, ((tiles_x_magic - 1u) >> 1) + 1u, tx, ty, rows_strip & 0xffffu, rest_rows, tiles_x, 0u);
+    }
+    // tile rows 0 .. TY / 2: row 0 of the image has no mirror image (its band row would be row H: not stored), row H / 2 is its
+    // own (tile row TY / 2 and its band rewrite rows their neighbours write too -- with the same bytes)
+    const DstSize dsz{(int)(dst_wh & 0xffffu), (int)(dst_wh >> 16)};
+    const TileIds t = tile_ids(dsz, 0, tid, tx, ty, (int)tiles_x, NT / kLanesX);
+    RowCol rc;
+    load_rowcol<0>(rowcol_tables_at(rowcol_tables, dsz.dst_w, dsz.dst_h), t.xc, t.jc, rc);
+    const TileBoxPair bq = load_tile_box_pair(pairs, t.box_tile);
+    const TileBox &b = bq.b, &q = bq.q;
+    ctx_cref c = *(const V1C_CONST KernelCtx*)ctxp;
+    const units_cptr U = (units_cptr)a.inl;  // (one or two units: always the block's own records, at a known offset)
     geom_cref g = c.g;
     ray_cref P = c.ray;
-    int tx, ty;
-    xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, tx, ty, gridDim.y - rest_rows, rest_rows);
-    const TileIds t = tile_ids(a, 0, tid, tx, ty, (int)gridDim.x, NT / kLanesX);
-    RowCol rc;
-    load_rowcol<0>(a, t.xc, t.jc, rc);
-    const TileBox b = load_tile_box(a.boxes, t.box_tile), q = load_tile_box(a.mboxes, t.box_tile);
     touch_plan_and_units<0, 2>(c, U, 0, 1);
-    const int cap_kb = a.kb;
+    const int cap_kb = (int)(kb_mh & 0xffffu);
     if (mirror_raw_fit(b, q, cap_kb, g.src_h, g.src_w) != 1)
         return;
     const bool mpoly = (b.interior & 2) != 0;
@@ -2164,8 +2224,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
         }
     }
     const uint32_t row_off = (uint32_t)t.x0 * 3u;
-    const int jm = a.mirror_h - t.j;
-    const bool band_row = jm < g.dst_h;
+    const int jm = (int)(kb_mh >> 16) - t.j;
+    const bool band_row = jm < dsz.dst_h;
     uint32_t pix[kPX];
     // ---- eye 0 ----
     wait_vm_barrier(nq);  // tile box
@@ -3071,7 +3131,7 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const KernelCtx* cdev
         return e ? (unsigned)std::atoi(e) : 0u;
     }();
     // the LDS-DMA kernels serve tile rows 0 .. TY / 2 (two more than the register-staged pairing of rows 1 .. TY / 2 - 1)
-    auto strips = [&](unsigned rows) {  // two tile rows per strip (tile_xcd_strips)
+    [[maybe_unused]] auto strips = [&](unsigned rows) {  // two tile rows per strip (tile_xcd_strips): the tuning build's A/B partners
         const unsigned per = (full.x * rows) >> 3;
         unsigned slen = strip_rows && strip_rows * full.x < per ? strip_rows * full.x : 0u;
         if (block_rows && full.x % 8 == 0 && raw_nwp > 0)
@@ -3081,42 +3141,48 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const KernelCtx* cdev
     };
     const unsigned raw_rows = full.y / 2 + 1;
     const unsigned rest_rows = ((((unsigned)n_rest + full.x - 1) / full.x) + 7u) & ~7u;  // whole rows, a multiple of 8: the pair rows keep their XCDs
+    // The LDS-DMA kernels take the head of their arguments as preloaded scalar parameters (V1C_MIRROR_HEAD): the (tile, band) box pairs
+    // (`mboxes`), tiles_x | rest_rows << 16, rows of tile pairs | XCD strip rows << 16 (two tile rows per strip, or one block per XCD), the
+    // destination size, the base of the plan's row / column tables (= col_s: one buffer), the context, box KB | mirror row << 16
+    const unsigned srows = strip_rows == 2u && 2u * full.x < ((full.x * raw_rows) >> 3) ? 2u : 0u;
+    const unsigned rows_strip = raw_rows | srows << 16, dst_wh = (unsigned)c.g.dst_w | (unsigned)c.g.dst_h << 16;
+#define V1C_MIRROR_LAUNCH(KERNEL, GRID, LDS, RESTROWS)                                                                                    \
+    hipLaunchKernelGGL(KERNEL, GRID, block, LDS, stream, a.mboxes, a.tiles_x_magic, full.x | (unsigned)(RESTROWS) << 16, rows_strip, dst_wh, \
+                       a.col_s, a.ctx, (unsigned)a.kb | (unsigned)a.mirror_h << 16, a)
     if (seq_kb > 0 && n_eyes == 2) {  // the eyes one after the other: two buffers of seq_kb KB (rest list made for that size)
         static const bool norest_off = [] {  // V1C_SEQ_NOREST=0 (A/B): the instantiation with the general pair code for every plan
             const char* e = tuning_env("V1C_SEQ_NOREST");
             return e && e[0] == '0';
         }();
-        strips(raw_rows);
         a.kb = seq_kb;
         if (n_rest == 0 && !norest_off) {  // nothing for the general pair code: the instantiation (and the LDS) without it
             const dim3 rgrid(full.x, raw_rows, 1);
             const size_t slds = (size_t)2 * 1024 * (size_t)seq_kb + 16;
             a.rest_rows = 0;
             if (c.ray.var_is_w)
-                hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<1, 0>), rgrid, block, slds, stream, a);
+                V1C_MIRROR_LAUNCH((k_ray_lin3_pair_mirror_seq<1, 0>), rgrid, slds, 0u);
             else
-                hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<0, 0>), rgrid, block, slds, stream, a);
+                V1C_MIRROR_LAUNCH((k_ray_lin3_pair_mirror_seq<0, 0>), rgrid, slds, 0u);
             return hipGetLastError();
         }
         const dim3 rgrid(full.x, raw_rows + rest_rows, 1);
         const size_t slds = std::max((size_t)half_dwords * 8 + 16, (size_t)2 * 1024 * (size_t)seq_kb);
         a.rest_rows = rest_rows;
         if (c.ray.var_is_w)
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<1>), rgrid, block, slds, stream, a);
+            V1C_MIRROR_LAUNCH((k_ray_lin3_pair_mirror_seq<1>), rgrid, slds, rest_rows);
         else
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_seq<0>), rgrid, block, slds, stream, a);
+            V1C_MIRROR_LAUNCH((k_ray_lin3_pair_mirror_seq<0>), rgrid, slds, rest_rows);
         return hipGetLastError();
     }
     if (raw_nwp > 0 && n_eyes == 1) {  // a single image: the LDS-DMA kernel's one-eye instantiation
         const dim3 rgrid(full.x, raw_rows + rest_rows, 1);
         // two boxes; the general pair code serves one unit from one cell buffer
         const size_t lds = std::max((size_t)half_dwords * 4 + 16, (size_t)2 * 1024 * (size_t)raw_nwp);
-        strips(raw_rows);
         a.kb = raw_nwp, a.rest_rows = rest_rows;
         if (c.ray.var_is_w)
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1, 1>), rgrid, block, lds, stream, a);
+            V1C_MIRROR_LAUNCH((k_ray_lin3_pair_mirror_raw<1, 1>), rgrid, lds, rest_rows);
         else
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0, 1>), rgrid, block, lds, stream, a);
+            V1C_MIRROR_LAUNCH((k_ray_lin3_pair_mirror_raw<0, 1>), rgrid, lds, rest_rows);
         return hipGetLastError();
     }
 #ifdef V1C_TUNING  // A/B partners of the seq kernel: the four-buffer LDS-DMA pair kernel (V1C_MIRROR_SEQ=0) and the register-staged one (V1C_MIRROR_RAW=0)
@@ -3136,10 +3202,11 @@ hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const KernelCtx* cdev
             a.n_rest = 0, a.rest_rows = 0, rgrid.y = raw_rows;
         if (skip == 2)
             rgrid.y = rest_rows;
+        const unsigned rr = skip == 1 ? 0u : rest_rows;
         if (c.ray.var_is_w)
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<1, 2>), rgrid, block, lds, stream, a);
+            V1C_MIRROR_LAUNCH((k_ray_lin3_pair_mirror_raw<1, 2>), rgrid, lds, rr);
         else
-            hipLaunchKernelGGL((k_ray_lin3_pair_mirror_raw<0, 2>), rgrid, block, lds, stream, a);
+            V1C_MIRROR_LAUNCH((k_ray_lin3_pair_mirror_raw<0, 2>), rgrid, lds, rr);
         return hipGetLastError();
     }
     const dim3 grid(full.x, full.y / 2 - 1, 2);

@@ -191,6 +191,7 @@ struct v1c_plan {
     // apply_lr pairs of unrotated chains: boxes of the bands that mirror the tiles about the equator and the tiles
     // the mirror launch leaves to the pair kernel (k_ray_lin3_pair_mirror); mirror_boxes == nullptr: not used
     void* mirror_boxes = nullptr;
+    const void* mirror_pairs = nullptr;  // (tile box, band box) interleaved, 64 bytes per tile: what the LDS-DMA mirror kernels read (one scalar load)
     const uint32_t* mirror_rest = nullptr;
     int n_mirror_rest = 0;
     int cn_kb = 0;                           // > 0: grayscale / BGRA bilinear through k_ray_lin_cn with box buffers of so many KB
@@ -383,12 +384,22 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             const RayAnalysis& a = p->ana;
             const RayHostTables ht = build_ray_host_tables(a, dst_w, dst_h);
             RayParams& r = p->ctx.ray;
-            if ((rc = upload(p, ht.col_s, &r.col_s)) || (rc = upload(p, ht.col_c, &r.col_c)) ||
-                (rc = upload(p, ht.col_h, &r.col_h)) || (rc = upload(p, ht.row_s, &r.row_s)) ||
-                (rc = upload(p, ht.row_c, &r.row_c)) || (rc = upload(p, ht.row_h, &r.row_h)) ||
-                (rc = upload(p, p->table.coef, &r.radial))) {
-                v1c_plan_destroy(p);
-                return rc;
+            // the six row / column tables in ONE buffer, in the order col_s | col_c | col_h (wpad entries each) | row_s | row_c | row_h
+            // (dst_h each): the mirror kernels get its base among their preloaded arguments and derive the others (kernels_tile.hip:
+            // rowcol_tables_at)
+            {
+                std::vector<double> all;
+                all.reserve(3 * ht.col_s.size() + 3 * ht.row_s.size());
+                for (const std::vector<double>* v : {&ht.col_s, &ht.col_c, &ht.col_h, &ht.row_s, &ht.row_c, &ht.row_h})
+                    all.insert(all.end(), v->begin(), v->end());
+                const double* base = nullptr;
+                if ((rc = upload(p, all, &base)) || (rc = upload(p, p->table.coef, &r.radial))) {
+                    v1c_plan_destroy(p);
+                    return rc;
+                }
+                const size_t wpad = ht.col_s.size(), hh = ht.row_s.size();
+                r.col_s = base, r.col_c = base + wpad, r.col_h = base + 2 * wpad;
+                r.row_s = base + 3 * wpad, r.row_c = base + 3 * wpad + hh, r.row_h = base + 3 * wpad + 2 * hh;
             }
             r.inv_step = p->table.inv_step;
             r.n_int = p->table.n_int;
@@ -591,6 +602,19 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                                 return rc;
                             }
                             p->mirror_boxes = mbx, p->n_mirror_rest = (int)mrest.size(), p->mirror_h = g.dst_h;
+                            {
+                                std::vector<char> pairs(2 * hb.size());
+                                for (size_t i = 0; i < hb.size() / 32; i++) {
+                                    std::memcpy(&pairs[64 * i], &hb[32 * i], 32);
+                                    std::memcpy(&pairs[64 * i + 32], &hm[32 * i], 32);
+                                }
+                                const char* dp = nullptr;
+                                if ((rc = upload(p, pairs, &dp))) {
+                                    v1c_plan_destroy(p);
+                                    return rc;
+                                }
+                                p->mirror_pairs = dp;
+                            }
                             std::vector<uint32_t> mrest1;
                             if (p->mirror_raw_nwp > 0 && tile_mirror_rest(hb.data(), hm.data(), g, p->half_dwords, g.dst_h, mrest1, p->mirror_raw_nwp, true, 1)) {
                                 if ((rc = upload(p, mrest1, &p->mirror_rest1))) {
@@ -848,7 +872,8 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         const bool mirror = d.fast && (n == 2 || (n == 1 && p->mirror_raw_nwp > 0 && p->n_mirror_rest1 >= 0)) && !d.any_rot &&
                             p->mirror_boxes != nullptr && shared && aligned;
         if (mirror) {
-            HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, p->ctx_dev, lu, flags, p->tile_boxes, p->mirror_boxes, p->half_dwords, p->mirror_h,
+            HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, p->ctx_dev, lu, flags, p->tile_boxes, p->mirror_raw_nwp > 0 ? p->mirror_pairs : p->mirror_boxes,
+                                                p->half_dwords, p->mirror_h,
                                                 n == 1 ? p->mirror_rest1 : p->mirror_rest, n == 1 ? p->n_mirror_rest1 : p->n_mirror_rest,
                                                 p->mirror_raw_nwp, st, p->mirror_seq_kb));
         } else if (d.fast && p->ctx.g.cn != 3) {
