@@ -66,14 +66,23 @@ def rotated(n, frames, steps):
     for i in range(steps):
         bad += int(not torch.equal(run(), ref))
     return bad
-def cn_batch(n, cn, units, steps):
-    """grayscale / BGRA units sharing the map: k_ray_lin_cn (double-buffered LDS-DMA boxes behind bare barriers)"""
+def cn_batch(n, cn, units, steps, interp=1, rot=False):
+    """grayscale / BGRA units sharing the map: k_ray_lin_cn (double-buffered LDS-DMA boxes behind bare barriers); `interp` 0 / 4: its
+    NEAREST / Lanczos4 forms; `rot`: a rotation per unit (boxes reduced in the kernel)"""
+    import numpy as np
+    from vr180_convert_amd.quat import as_rotation_matrix, from_rotation_vector
+    from vr180_convert_amd.transformer import Euclidean3DRotator
     t = EquirectangularEncoder() * PolynomialScaler([0, 1, -0.1]) * FisheyeDecoder("equidistant")
+    rots = None
+    if rot:
+        t = EquirectangularEncoder() * Euclidean3DRotator((1.0, 0.0, 0.0, 0.0)) * FisheyeDecoder("equidistant")
+        rng = np.random.default_rng(4)
+        rots = [as_rotation_matrix(from_rotation_vector(rng.normal(0, 0.02, 3))) for _ in range(units)]
     g = torch.Generator(device=dev).manual_seed(5)
     srcs = [torch.randint(0, 256, (n, n, cn), dtype=torch.uint8, device=dev, generator=g) for _ in range(units)]
     def run():
         dsts = [torch.empty((n, n, cn), dtype=torch.uint8, device=dev) for _ in range(units)]
-        V.remap_tensors(t, srcs, dsts, radius=n / 2, interpolation=1)
+        V.remap_tensors(t, srcs, dsts, radius=n / 2, interpolation=interp, rotations=rots)
         return torch.stack(dsts)
     ref = run().clone(); bad = 0
     for i in range(steps):
@@ -86,7 +95,12 @@ for rep in range(REPS):
     print("gray 2048 x 5 units:", cn_batch(2048, 1, 5, 1000), "bad of 1000", flush=True)
     print("BGRA 2048 x 2 units:", cn_batch(2048, 4, 2, 1000), "bad of 1000", flush=True)
     print("BGRA 1024 x 7 units:", cn_batch(1024, 4, 7, 1000), "bad of 1000", flush=True)
+    print("gray 1024 x 4 units NEAREST:", cn_batch(1024, 1, 4, 500, interp=0), "bad of 500", flush=True)
+    print("BGRA 1024 x 3 units Lanczos4:", cn_batch(1024, 4, 3, 300, interp=4), "bad of 300", flush=True)
+    print("BGRA 1024 x 6 units, a rotation each:", cn_batch(1024, 4, 6, 500, rot=True), "bad of 500", flush=True)
     print("single images 2048:", single(2048, 2000), "bad of 2000", flush=True)
+    print("rotated units 1440 x 16 frames (32 units: one launch through the unit ring):", rotated(1440, 16, 300), "bad of 300", flush=True)
+    print("batches 1024 x 12 frames (24 units through the ring):", batch(1024, 12, 500), "bad of 500", flush=True)
     print("C5-like rotated units 1920 x 8 frames:", rotated(1920, 8, 400), "bad of 400", flush=True)
     print("rotated units 1024 x 5 frames (odd unit count per launch group):", rotated(1024, 5, 800), "bad of 800", flush=True)
     print("C2-like pairs 4096:", pair(4096, [0, 1, -0.1], 1500), "bad of 1500", flush=True)
