@@ -68,7 +68,7 @@ def test_ray_path_full_size_sha(emul_lib, oracle_mod, golden_dir, name):
 
 @pytest.mark.parametrize("name,mode", [("C1", 1), ("C2", 1), ("C2", 0)])
 def test_rows_mirror_about_the_equator(emul_lib, oracle_mod, name, mode):
-    """The premise of k_ray_lin3_pair_mirror (kernels_tile.hip): for an unrotated equirectangular chain output rows j and
+    """The premise of k_ray_lin3_pair_mirror (kernels_mirror.hip): for an unrotated equirectangular chain output rows j and
     H - j differ only in the sign of sin(lat) -- the x coordinates are the SAME float32 bits and y mirrors about the source
     centre (y' - c_y == -(y - c_y) up to the rounding of one fma).  Checked on the product's per-pixel code compiled for
     the host, at the full BASELINE sizes, fused ray path (and the literal interpreter for C2)."""

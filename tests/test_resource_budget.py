@@ -38,7 +38,7 @@ def kernel_metadata(tmp: Path, obj: Path) -> list[dict]:
 @pytest.fixture(scope="module")
 def product_kernels(tmp_path_factory, product_lib):
     out = []
-    for name in ("kernels_tile.o", "kernels.o"):
+    for name in ("kernels_tile.o", "kernels_mirror.o", "kernels_cn.o", "kernels.o"):
         obj = CSRC / name
         assert obj.exists(), f"{name} is built by __graft_entry__.build() / make"
         out += kernel_metadata(tmp_path_factory.mktemp("meta"), obj)

@@ -1,4 +1,4 @@
-"""Build-time guard of the fence-less barrier protocol of the LDS-DMA kernels (csrc/kernels_tile.hip:
+"""Build-time guard of the fence-less barrier protocol of the LDS-DMA kernels (csrc/tile_device.hpp, kernels_tile.hip, kernels_mirror.hip, kernels_cn.hip:
 k_ray_lin3_pair_mirror_seq, k_ray_lin3_pair_mirror_raw, k_ray_lin3_batch_lean_raw, k_ray_lin3_rot_pair_raw, k_ray_lin_cn).
 
 Those kernels publish LDS-DMA data with a bare ``s_barrier`` behind a hand-counted ``s_waitcnt vmcnt(n)``: n is the
@@ -45,6 +45,18 @@ class Ins:
             self.kind = ""
 
 
+TILE_OBJECTS = ("kernels_tile", "kernels_mirror", "kernels_cn")  # the translation units of the tile kernels (csrc/Makefile)
+
+
+def _disassemble_all(tmp_path_factory, suffix):
+    out: dict[str, list[Ins]] = {}
+    for stem in TILE_OBJECTS:
+        one = _disassemble(tmp_path_factory, stem + suffix)
+        assert not (set(one) & set(out)), sorted(set(one) & set(out))[:4]
+        out.update(one)
+    return out
+
+
 def _disassemble(tmp_path_factory, objname):
     if not OBJDUMP.exists():
         pytest.skip("llvm-objdump not available")
@@ -73,13 +85,13 @@ def _disassemble(tmp_path_factory, objname):
 @pytest.fixture(scope="module")
 def kernels_dis(tmp_path_factory, product_lib):
     """the product's code object"""
-    return _disassemble(tmp_path_factory, "kernels_tile.o")
+    return _disassemble_all(tmp_path_factory, ".o")
 
 
 @pytest.fixture(scope="module")
 def tuning_dis(tmp_path_factory, product_lib):
     """the -DV1C_TUNING twin: the product's kernels plus the A/B partners (four-buffer pair kernel, register-staged forms)"""
-    return _disassemble(tmp_path_factory, "kernels_tile.tuning.o")
+    return _disassemble_all(tmp_path_factory, ".tuning.o")
 
 
 def analyse(ins):
@@ -199,7 +211,7 @@ def test_cn_kernel_waits_for_every_request_before_the_barrier(kernels_dis):
 
 def test_hand_written_memory_instructions_keep_their_wait_states(kernels_dis):
     """The two memory instructions issued from asm statements are invisible to the compiler's hazard recogniser, so their wait
-    states are part of the statements (csrc/kernels_tile.hip raw_box_dma, store4<1>) -- checked here in the code object:
+    states are part of the statements (csrc/tile_device.hpp raw_box_dma, store4<1>) -- checked here in the code object:
     * every SGPR-base LDS-DMA request of a box (``global_load_lds_dwordx4 v, s[..]`` behind an ``s_mov_b32 m0``) has ``s_nop 2``
       directly in front of it (M0 write -> use, VALU-written SGPR -> VMEM read) and puts M0 back directly behind it;
     * every system-scope streaming store (``sc0 sc1 nt``) is directly followed by ``s_nop 1`` (store data of more than 8 bytes ->

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Register / scratch / LDS budget of every kernel of a .hip source (hipcc -Rpass-analysis=kernel-resource-usage).
 
-    python3 tools/resource_usage.py [kernels_tile.hip] [-DV1C_TUNING ...] [--all] [--json out.json]
+    python3 tools/resource_usage.py [kernels_tile.hip kernels_mirror.hip ...] [-DV1C_TUNING ...] [--all] [--json out.json]
+
+(default: the three tile translation units kernels_tile.hip, kernels_mirror.hip, kernels_cn.hip)
 
 Prints the kernels that use scratch or spill SGPRs into vector lanes (`--all`: every kernel) and the totals the round's
 verdict asks for: number of kernels, kernels with scratch, largest SGPR spill.  tests/test_resource_budget.py runs it on the
@@ -18,7 +20,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "vr180_convert_amd" / "csrc"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-Wno-unused-function",
-         "-Wno-bitwise-instead-of-logical"]
+         "-Wno-bitwise-instead-of-logical", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+TILE_SRCS = ["kernels_tile.hip", "kernels_mirror.hip", "kernels_cn.hip"]
 
 
 def demangle(names: list[str]) -> list[str]:
@@ -54,7 +57,7 @@ def main(argv: list[str]) -> int:
     if "--json" in argv:
         out_json = argv[argv.index("--json") + 1]
     args = [a for a in argv if a not in ("--all", "--json", out_json)]
-    srcs = [a for a in args if a.endswith(".hip")] or ["kernels_tile.hip"]
+    srcs = [a for a in args if a.endswith(".hip")] or TILE_SRCS
     extra = [a for a in args if a.startswith("-")]
     total = []
     for s in srcs:

@@ -1,5 +1,5 @@
 // Checks the packed form of the bilinear blend weights (v_pk_mad_u16 with clamp + v_pk_mul_lo_u16,
-// kernels_tile.hip::blend_weights) against the scalar form for all 32 x 32 fractions.
+// tile_device.hpp::blend_weights) against the scalar form for all 32 x 32 fractions.
 // hipcc --offload-arch=gfx950 -O3 -o blend_weights_pk blend_weights_pk.hip && ./blend_weights_pk
 #include <hip/hip_runtime.h>
 #include <cstdio>

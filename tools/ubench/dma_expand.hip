@@ -1,5 +1,5 @@
 // Staging a BGR source box into LDS as BGRx (4 bytes per pixel), three ways:
-//   regs : global_load_dwordx3 (4 px per lane) + 3 v_perm + ds_write_b128     -- what kernels_tile.hip does
+//   regs : global_load_dwordx3 (4 px per lane) + 3 v_perm + ds_write_b128     -- what tile_device.hpp stage_load + stage_store do
 //   dma3 : global_load_lds_dword with per-lane UNALIGNED byte addresses 3 * px  -- LDS-DMA does the expansion:
 //          lane i of a wave-instruction fetches bytes [3 i, 3 i + 4) = B G R (B') into LDS dword i
 //   dma4 : the same instruction with aligned addresses 4 * px (how much the misalignment costs)

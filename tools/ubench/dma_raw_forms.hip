@@ -1,7 +1,7 @@
 // Building blocks of a "raw" pair kernel: the source box goes to LDS as it is in memory (packed BGR, 12 bytes per 4-pixel
 // chunk, lane-linear) by LDS-DMA -- no staging registers, so coordinates can be computed while the box is in flight -- and the
 // bilinear taps (6 bytes at byte offset 3 * px) are cut out of dword-aligned LDS reads.
-//   A. staging rate: global_load_dwordx3 + 3 v_perm + ds_write_b128 (kernels_tile.hip) vs global_load_lds_dwordx3 (12 B per
+//   A. staging rate: global_load_dwordx3 + 3 v_perm + ds_write_b128 (tile_device.hpp) vs global_load_lds_dwordx3 (12 B per
 //      lane, 768 B per wave-instruction) vs global_load_lds_dwordx4
 //   B. three dwords at a 4-byte-aligned LDS address: ds_read_b96 vs ds_read2_b32 + ds_read_b32; two dwords: ds_read_b64 at a
 //      4- (not 8-) byte-aligned address vs ds_read2_b32

@@ -1,7 +1,7 @@
 // How fast can a CU write the remap kernels' output pattern, and does the store FORM matter?
 // Every 256-thread workgroup writes one 64 x 16 pixel tile of a (H, W, 3) uint8 image (192 contiguous bytes per row,
 // 16 rows a row pitch apart), tiles in XCD-friendly row-major order, non-temporal.  Forms:
-//   x3   : global_store_dwordx3, 16 lanes per row (what kernels_tile.hip does: lane = 4 pixels = 12 bytes)
+//   x3   : global_store_dwordx3, 16 lanes per row (what the tile kernels do, tile_device.hpp: lane = 4 pixels = 12 bytes)
 //   x4   : global_store_dwordx4, 12 lanes per row (the same bytes, 48 of 64 lanes active)
 //   x4w  : global_store_dwordx4, all 64 lanes: a wave writes 5.33 rows (rows split at 16-byte granularity)
 //   x1   : 3 x global_store_dword per lane (what an unmerged packing would give)

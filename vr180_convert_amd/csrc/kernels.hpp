@@ -37,7 +37,7 @@ struct KernelCtx {
     int64_t map_pitch;        // bytes
 };
 
-// ---- argument block of the tile kernels (kernels_tile.hip): their ONE by-value kernel argument ----
+// ---- argument block of the tile kernels (kernels_tile.hip, kernels_mirror.hip, kernels_cn.hip): their ONE by-value kernel argument ----
 // Until round 3 every tile kernel took KernelCtx (330 bytes) and UnitArgs (16 units, 1.8 KB) by value.  Kernel-argument loads are
 // invariant and dereferenceable, so the compiler hoisted them to the kernel entry and kept them live: 98 of the 102 scalar
 // registers pinned, up to 28 of them spilled into vector lanes (two instantiations into scratch), and 16 units per launch at most.
@@ -78,7 +78,7 @@ hipError_t launch_remap(int mode, const KernelCtx& c, const UnitArgs& ua, int n_
 hipError_t launch_get_map(int mode, const KernelCtx& c, const UnitArgs& u, float* xmap, float* ymap, int64_t pitch,
                           hipStream_t stream);
 
-// ---- tile kernels (kernels_tile.hip).  Every launcher takes the plan's context twice -- `c`, the host copy its decisions read, and
+// ---- tile kernels (kernels_tile.hip, kernels_mirror.hip, kernels_cn.hip; building blocks in tile_device.hpp).  Every launcher takes the plan's context twice -- `c`, the host copy its decisions read, and
 // `cdev`, the device copy the kernels read --, the launch's units and `flags`: the plan's tile-flag words when a fix-up pass follows
 // the launch, null when the host has proven it unnecessary (the kernels then write none). ----
 // copy `n` unit records into device memory (a ring slot) with launches of their own: stream-ordered and graph-capturable

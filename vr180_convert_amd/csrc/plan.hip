@@ -385,7 +385,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             const RayHostTables ht = build_ray_host_tables(a, dst_w, dst_h);
             RayParams& r = p->ctx.ray;
             // the six row / column tables in ONE buffer, in the order col_s | col_c | col_h (wpad entries each) | row_s | row_c | row_h
-            // (dst_h each): the mirror kernels get its base among their preloaded arguments and derive the others (kernels_tile.hip:
+            // (dst_h each): the mirror kernels get its base among their preloaded arguments and derive the others (tile_device.hpp:
             // rowcol_tables_at)
             {
                 std::vector<double> all;
@@ -418,7 +418,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             p->plan_shared_entry = (p->ray_no_rot_safe && ray_entry_is_shared(p->table, ht.m_reach, p->ray_step)) ||
                                    (p->ray_plan_rot_safe && ray_entry_is_shared(p->table, rotated_reach(a.rot), p->ray_step));
             // polynomials in m on the same intervals: tiles whose intervals all qualify need no fp64
-            // square root (w-tables) and no fp64 index arithmetic (kernels_tile.hip, lane_coords<..., MPOLY>)
+            // square root (w-tables) and no fp64 index arithmetic (tile_device.hpp, lane_coords<..., MPOLY>)
             r.radial_m = nullptr, r.mp_first_ok = r.n_int, r.inv_step_f = (float)r.inv_step;
             if (p->plan_shared_entry && !p->disable_shared_entry && !p->disable_mpoly) {
                 const double reach = a.has_rot ? rotated_reach(a.rot) : ht.m_reach;
@@ -638,7 +638,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     int hist[12] = {0};
                     for (size_t i = 0; i < nt; i++) {
                         const int cpr = bi[i * 8 + 2], nrows = bi[i * 8 + 3];
-                        const int need = cpr > 0 ? nrows * (cpr * 4 + 4) : 0;  // = kernels_tile.hip LDS row pitch
+                        const int need = cpr > 0 ? nrows * (cpr * 4 + 4) : 0;  // = tile_device.hpp LDS row pitch
                         int k = 0;
                         while (k < 11 && need > (512 << k) / 2)
                             k++;

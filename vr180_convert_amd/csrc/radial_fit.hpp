@@ -226,7 +226,7 @@ inline void fit_parallel_for(int n, F&& body)
 // (fitting on the wide range keeps the noise of the high coefficients harmless there: nodes on
 // [-0.5, 0.5] leave ~1e-16 of long-double rounding in c7, which 1.5^7 would amplify past the
 // tolerance).  The level is stored in the two low mantissa bits of c7; the DOUBLE Horner the
-// kernels run is validated with those bits already in place.  kernels_tile.hip uses pixel 1's
+// kernels run is validated with those bits already in place.  tile_device.hpp uses pixel 1's
 // entry for all 4 pixels of a lane wherever the level allows.
 inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w, int n_int = kTableIntervals)
 {
@@ -490,7 +490,7 @@ inline double rotated_reach(const double* rot)
 }
 
 // true when one table entry may serve the 4 horizontally adjacent pixels of a lane
-// (kernels_tile.hip, OWN = 0): with pixel 1's entry centred at zc, |t_1 - zc| <= 0.5 and
+// (tile_device.hpp, OWN = 0): with pixel 1's entry centred at zc, |t_1 - zc| <= 0.5 and
 // |t_k - t_1| <= 2 * delta, so every pixel stays inside the validated range |z| <= 0.5 + level
 // when delta <= level / 2 -- provided every entry a pixel can select has that level.
 // delta = table units per output pixel: adjacent rays are at most `ray_step` radians apart

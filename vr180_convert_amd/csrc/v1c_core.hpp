@@ -314,7 +314,7 @@ V1C_HDF double fast_sqrt_half(double m)
 V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], double sl, double cl, double hl,
                       double slon, double clon, double hlon, double& ox, double& oy)
 {
-    // NOTE: kernels_tile.hip evaluates these very expressions (same operations, same order); the
+    // NOTE: tile_device.hpp (lane_coords) evaluates these very expressions (same operations, same order); the
     // fix-up pass relies on both agreeing bit for bit on which pixels are inside the table.
     double m, x32, y32;
     double sx_, sy_;  // the factors G multiplies: x32 = (G*kx)*sx_ + cx32, y32 = (G*ky)*sy_ + cy32
