@@ -174,6 +174,22 @@ int v1c_plan_path(const v1c_plan* plan);
  * per plan: each keeps its ring slot).  One plan may be run from several threads / streams.   */
 int v1c_plan_run(v1c_plan* plan, void* stream, const v1c_unit* units, int n_units);
 
+/* Which kernels the most recent launch group of v1c_plan_run on this plan used: one of the V1C_LAUNCH_* values, | V1C_LAUNCH_FIXUP
+ * when a fix-up pass followed; -1 before the first run.  The engine has several code paths for the same bytes (a generic per-pixel
+ * kernel for everything, LDS-tiled kernels for what the plan could prove about the chain and the units); tests use this to make
+ * sure a case meant for a tiled kernel was not served by the generic one.  For tests / bench.                                  */
+enum {
+    V1C_LAUNCH_GENERIC = 0, /* k_remap: fp64 interpreter or the ray path per pixel, samples from global memory */
+    V1C_LAUNCH_TILE = 1,    /* BGR, the general tile kernel: k_ray_lin3_tile (pairs, bicubic / Lanczos4, NEAREST, odd cases) */
+    V1C_LAUNCH_MIRROR = 2,  /* BGR pairs and single images of unrotated chains: k_ray_lin3_pair_mirror_seq / _raw */
+    V1C_LAUNCH_CN = 3,      /* grayscale / BGRA with plan-time boxes: k_ray_lin_cn */
+    V1C_LAUNCH_CN_ROT = 4,  /* grayscale / BGRA, units with a rotation of their own: k_ray_lin_cn without boxes */
+    V1C_LAUNCH_BATCH = 5,   /* BGR bilinear batches sharing a map: k_ray_lin3_batch_lean_raw (+ k_ray_lin3_tile for its rest tiles) */
+    V1C_LAUNCH_ROT_PAIR = 6, /* BGR bilinear units with a rotation of their own: k_ray_lin3_rot_pair_raw */
+    V1C_LAUNCH_FIXUP = 0x100
+};
+int v1c_plan_last_launch(const v1c_plan* plan);
+
 /* Evaluate only the coordinate chain on the output grid and store float32 maps (device
  * pointers, row pitch map_pitch bytes).  Replaces get_map(), remapper.py:23-59.  Used for
  * coordinate-parity tests and for callers that want the map itself.                         */

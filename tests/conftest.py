@@ -17,6 +17,35 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _log_launch_kinds(request):
+    """V1C_LOG_KINDS=<file>: append, per test, which kernel families its plan runs used (Plan.last_launch) -- the audit behind
+    profiles/*/test_kernel_coverage.log: a parity test only counts for a tiled kernel if the case reached it."""
+    path = os.environ.get("V1C_LOG_KINDS")
+    if not path or request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import collections
+
+    from vr180_convert_amd import remapper
+
+    seen: collections.Counter = collections.Counter()
+    orig = remapper.Plan.run
+
+    def run(self, *a, **k):
+        r = orig(self, *a, **k)
+        seen[(self.last_launch(), f"cn{self.cn}")] += 1
+        return r
+
+    remapper.Plan.run = run
+    try:
+        yield
+    finally:
+        remapper.Plan.run = orig
+        with open(path, "a") as f:
+            f.write(f"{request.node.nodeid}: " + ", ".join(f"{k[0]}/{k[1]} x{n}" for k, n in sorted(seen.items())) + "\n")
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -248,15 +248,23 @@ def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev, i
     odd output sizes, sources that are pitched views, a radius larger than the source (rays leaving it) -- every byte against the oracle."""
     from vr180_convert_amd.synth import noise_disc
 
+    from vr180_convert_amd import remapper
+
     O = oracle_mod
     rng = np.random.default_rng(777 + interp)
+    seen = set()
     specs = ([("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI],
              [("equirect_enc", True), ("rot", CS.ry(0.3)), ("poly", [0, 1, -0.1]), CS.EQUI])
     for cn in (1, 4):
         for si, spec in enumerate(specs):
             for border, bval in ((0, 77), (1, 0), (2, 0), (4, 0), (5, 0)):
                 hs, ws = 300 + 4 * si, 320
-                wo, ho = (333, 250) if border != 1 else (512, 384)
+                # outputs of >= 512 rows and columns reach k_ray_lin_cn (one table entry per lane needs rays that close together);
+                # the small one stays: the generic kernel serves it, as it does TRANSPARENT with anything but bilinear
+                # (the polynomial chains' w-table: from ~1000 px on)
+                big = 512 if si == 0 else 1024
+                wo, ho = ({0: (613, 587), 1: (601, 587), 2: (333, 250), 4: (589, 613), 5: (613, 587)} if si == 0 else
+                          {0: (1040, 1024), 1: (333, 250), 2: (512, 384), 4: (1027, 1040), 5: (333, 250)})[border]
                 n = 1 + (si + border) % 5
                 wide = [rng.integers(0, 256, (hs, ws + 8, cn), dtype=np.uint8) for _ in range(n)]
                 imgs = [np.ascontiguousarray(w[:, 4:4 + ws]) for w in wide]
@@ -267,11 +275,16 @@ def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev, i
                 radius = 140.0 if border != 4 else 190.0
                 modes = V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=radius, interpolation=interp, boarder_mode=border, boarder_value=bval)
                 assert modes == ["ray"], modes
+                kinds = remapper.last_launch_kinds()
+                if min(wo, ho) >= big and si < 2:  # (si = 2: the rotation takes rays into the back hemisphere -> fix-up pass -> generic)
+                    assert kinds == (["generic"] if border == 5 and interp != 1 else ["cn"]), (kinds, cn, si, border)
+                seen.update(kinds)
                 xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
                 for k in range(n):
                     want = O.remap(imgs[k], xm, ym, interp, border, bval, dst=fill.copy())
                     got = dsts[k].cpu().numpy()
                     assert np.array_equal(got, want), (cn, si, border, k, int((got != want).sum()))
+    assert {"cn", "generic"} <= seen, seen
     # seeded random geometries: odd / tiny / non-square sizes, radii beyond the source, negative radii, 1 - 6 units
     menus = [[("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0.02, 0.9, 0.05]), ("zoom", 1.1), CS.EQUI],
              [("equirect_enc", True), ("rot", CS.ry(-0.2)), CS.EQUI], [("equirect_enc", True), ("fisheye_dec", "stereographic")]]
@@ -299,12 +312,15 @@ def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev, i
 
     base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
     for cn in (1, 4):
-        for (hs, ws, wo, ho, radius, border) in ((256, 256, 256, 256, 128.0, 0), (200, 320, 333, 129, 170.0, 1), (96, 64, 70, 50, 30.0, 4)):
+        for (hs, ws, wo, ho, radius, border) in ((256, 256, 256, 256, 128.0, 0), (200, 320, 333, 129, 170.0, 1), (96, 64, 70, 50, 30.0, 4),
+                                                 (400, 400, 608, 608, 200.0, 0), (300, 360, 577, 577, 190.0, 2)):  # (square: rays stay in the front hemisphere)
             imgs = [rng.integers(0, 256, (hs, ws, cn), dtype=np.uint8) for _ in range(5)]
             quats = [CS.c5_spec(f // 2, f % 2)[1][1] for f in range(5)]
             dsts = [torch.zeros((ho, wo, cn), dtype=torch.uint8, device=dev) for _ in range(5)]
             assert V.remap_tensors(base, [torch.from_numpy(i).to(dev) for i in imgs], dsts, radius=radius, interpolation=interp,
                                    boarder_mode=border, rotations=quats) == ["ray"]
+            if min(wo, ho) >= 512:  # (the small ones: the generic kernel)
+                assert remapper.last_launch_kinds() == ["cn_rot"], (remapper.last_launch_kinds(), cn, wo, ho)
             for f in range(5):
                 xm, ym = O.get_map(CS.c5_spec(f // 2, f % 2), radius=radius, size_input=(hs, ws), size_output=(wo, ho))
                 want = O.remap(imgs[f], xm, ym, interp, border, 0)
@@ -355,6 +371,7 @@ def test_seeded_random_cases_bit_exact(V, oracle_mod, dev):
 
 def test_c2_full_size_apply_lr_vs_oracle(V, oracle_mod, dev):
     """BASELINE config C2 end to end: L+R 4096^2 -> 8192x4096 SBS, one launch."""
+    from vr180_convert_amd import remapper
     from vr180_convert_amd.synth import noise_disc
 
     spec, out, inp, radius = CS.FULL_CASES["C2"]
@@ -362,6 +379,7 @@ def test_c2_full_size_apply_lr_vs_oracle(V, oracle_mod, dev):
     want = oracle_mod.apply_lr(spec, left, right, size_output=out, interpolation=1, radius="max")
     sbs = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev),
                              size_output=out, interpolation=1, radius="max")
+    assert remapper.last_launch_kinds() == ["mirror"]
     got = sbs.cpu().numpy()
     assert got.shape == (4096, 8192, 3)
     assert np.array_equal(got, want)
@@ -1014,6 +1032,7 @@ def test_c4_full_size_eye_vs_oracle(V, oracle_mod, dev):
     EquirectangularEncoder * Euclidean3DRotator(from_euler_angles(0, pi/4, 0)) * PolynomialScaler([0,1,-0.1])
     * FisheyeDecoder("equidistant"), INTER_LANCZOS4 -- all 201 326 592 output bytes against the oracle
     (literal fp64 chain + restated cv2.remap, every host core of the GPU box)."""
+    from vr180_convert_amd import remapper
     from vr180_convert_amd.synth import noise_disc
 
     spec, out, inp, radius = CS.FULL_CASES["C4"]
@@ -1024,6 +1043,7 @@ def test_c4_full_size_eye_vs_oracle(V, oracle_mod, dev):
         want = O.apply(spec, [img], size_output=out, interpolation=4, radius="max")[0]
         dst = torch.empty((8192, 8192, 3), dtype=torch.uint8, device=dev)
         assert V.remap_tensors(CS.to_product(spec), [torch.from_numpy(img).to(dev)], [dst], radius=4096.0, interpolation=4) == ["ray"]
+        assert remapper.last_launch_kinds() == ["tile"]
         got = dst.cpu().numpy()
         assert got.shape == want.shape == (8192, 8192, 3)
         assert np.array_equal(got, want), int((got != want).sum())
@@ -1039,6 +1059,7 @@ def test_c5_full_size_units_vs_oracle(V, oracle_mod, dev):
     """BASELINE config 5 at its real size: FOUR 7680 x 3840 SBS frames (8 units of 3840^2 in one launch), every eye with
     its own calibration rotation (cli.py:308-319 pseudo-half quaternions), bilinear -- through the
     rotations= path that shares one plan -- against the oracle evaluating each unit's own chain."""
+    from vr180_convert_amd import remapper
     from vr180_convert_amd import transformer as T
     from vr180_convert_amd.synth import noise_disc
 
@@ -1055,6 +1076,7 @@ def test_c5_full_size_units_vs_oracle(V, oracle_mod, dev):
         srcs = [v for fr in frs for v in (fr[:, :n], fr[:, n:])]
         dsts = [v for o in outs for v in (o[:, :n], o[:, n:])]
         assert V.remap_tensors(base, srcs, dsts, radius=n / 2, interpolation=1, rotations=quats) == ["ray"]
+        assert remapper.last_launch_kinds() == ["rot_pair"]
         for k, f in enumerate(fids):
             got = outs[k].cpu().numpy()
             for eye in (0, 1):
@@ -1068,6 +1090,7 @@ def test_c3_full_size_frames_vs_oracle(V, oracle_mod, dev):
     """BASELINE config 3 at its real size: SBS frames of 5760 x 2880 split into halves (remapper.py:448-456),
     one shared equidistant map, bilinear, through the lean batch kernel (8 frames = 16 units in one launch: one rank's
     share of the 64 frames); ALL 16 units against the oracle."""
+    from vr180_convert_amd import remapper
     from vr180_convert_amd import transformer as T
     from vr180_convert_amd.synth import noise_disc
 
@@ -1082,6 +1105,7 @@ def test_c3_full_size_frames_vs_oracle(V, oracle_mod, dev):
         srcs = [v for fr in frames for v in (fr[:, :n], fr[:, n:])]
         dsts = [v for fr in outs for v in (fr[:, :n], fr[:, n:])]
         assert V.remap_tensors(t, srcs, dsts, radius=n / 2, interpolation=1) == ["ray"]
+        assert remapper.last_launch_kinds() == ["batch"]
         spec = [("equirect_enc", True), ("fisheye_dec", "equidistant")]
         xm, ym = O.get_map(spec, radius=n / 2, size_input=(n, n), size_output=(n, n))
         for f, eye in [(f, e) for f in range(8) for e in (0, 1)]:
@@ -1425,50 +1449,60 @@ def test_remap_sharded_border_transparent_is_deterministic(V, oracle_mod):
     assert np.array_equal(got[0], want[0])
 
 
-@pytest.mark.parametrize("src_hw,out_wh,radius", [
-    ((300, 300), (256, 96), 150.0),     # smallest mirror grid: 6 tile rows, 2 mirrored
-    ((512, 640), (320, 352), 250.0),    # non-square, source wider than high
-    ((1000, 1000), (1028, 512), 470.0), # width not a multiple of the tile (64): ragged last tile column -> rest list
-    ((700, 700), (512, 480), 350.0),    # 480 = 15 * 32: odd number of tile-row pairs
-    ((257, 263), (128, 100), 120.0),    # 100 rows: no mirror launch (not a multiple of 32), plain pair kernel
-    ((1800, 1800), (256, 256), 900.0),  # 7 x minification: boxes far beyond the DMA buffers / LDS -> rest list, global gathers
-    ((120, 120), (1024, 512), 60.0),    # 8 x magnification: boxes of a few rows
-    ((900, 1200), (640, 640), 450.0),   # 2 x minification in x: boxes around the buffer size, some tiles either side
-])
-def test_mirror_pair_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radius):
-    """apply_lr pairs of unrotated bilinear chains take k_ray_lin3_pair_mirror_raw (a tile and its mirror image about
-    the equator from one set of coordinates, boxes by LDS-DMA; tile rows 0, H/32 and the last one plus ineligible tiles
-    through the pair code in the same launch): every output byte against the oracle, m-table and w-table chains.
+# (source size, output size, radius, kernel family for the equidistant chain, for the polynomial chain): the mirror kernels need an
+# output whose rows pair up about the equator (H a multiple of 32), rays close enough for one table entry per lane (>= ~416 px for an
+# m-table, ~1000 for the w-table of the polynomial chain) and boxes the DMA buffers hold; everything else is the pair kernel's
+MIRROR_GEOMETRIES = [
+    ((300, 300), (448, 448), 150.0, "mirror", "tile"),      # smallest mirror grid: 28 tile rows
+    ((512, 640), (544, 576), 250.0, "mirror", "tile"),      # non-square both ways, source wider than high
+    ((1000, 1000), (1028, 1024), 470.0, "mirror", "mirror"),  # width not a multiple of the tile (64): ragged last tile column
+    ((1000, 1000), (1028, 1056), 470.0, "mirror", "mirror"),  # 1056 = 33 * 32: odd number of tile-row pairs
+    ((257, 263), (128, 100), 120.0, "tile", "tile"),        # 100 rows: no mirror launch, plain pair kernel
+    ((1800, 1800), (512, 512), 900.0, "tile", "tile"),      # 3.5 x minification: boxes beyond the DMA buffers, plain pair kernel
+    ((120, 120), (1024, 1024), 60.0, "mirror", "mirror"),   # 8.5 x magnification: boxes of a few rows
+    ((900, 1200), (640, 640), 450.0, "mirror", "tile"),     # 2 x minification in x: boxes around the buffer size, rest tiles
+    ((640, 640), (640, 640), 200.0, "mirror", "tile"),      # radius well inside the source: most rays leave the image circle
+]
+
+
+@pytest.mark.parametrize("src_hw,out_wh,radius,kind_m,kind_w", MIRROR_GEOMETRIES)
+def test_mirror_pair_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radius, kind_m, kind_w):
+    """apply_lr pairs of unrotated bilinear chains take k_ray_lin3_pair_mirror_seq (a tile and its mirror image about the equator
+    from one set of coordinates, boxes by LDS-DMA; ineligible tiles through the pair code in the same launch): every output byte
+    against the oracle, m-table and w-table chains -- and the launch IS the mirror launch where the table says so (round 4: the
+    geometries of round 3 turned out to be served by the pair kernel, v1c_plan_last_launch tells).
     (The register-staged k_ray_lin3_pair_mirror and other box-buffer sizes: test_kernel_variants_bit_exact.)"""
+    from vr180_convert_amd import remapper
     from vr180_convert_amd.synth import noise_disc
 
     O = oracle_mod
     left, right = noise_disc(*src_hw, 21), noise_disc(*src_hw, 22)
     left[::9, ::7] = 255
-    for spec in ([("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]):
+    for spec, kind in (([("equirect_enc", True), CS.EQUI], kind_m), ([("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI], kind_w)):
         want = O.apply_lr(spec, left, right, size_output=out_wh, interpolation=1, radius=radius, border_value=(5, 6, 7))
         got = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev),
                                  size_output=out_wh, interpolation=1, radius=radius, boarder_value=(5, 6, 7)).cpu().numpy()
+        assert remapper.last_launch_kinds() == [kind], (remapper.last_launch_kinds(), spec)
         assert np.array_equal(got, want), (spec, int((got != want).sum()))
 
 
-@pytest.mark.parametrize("src_hw,out_wh,radius", [((300, 300), (256, 96), 150.0), ((512, 640), (320, 352), 250.0),
-                                                  ((1000, 1000), (1028, 512), 470.0), ((700, 700), (512, 480), 350.0),
-                                                  ((1800, 1800), (256, 256), 900.0), ((120, 120), (1024, 512), 60.0)])
-def test_mirror_single_image_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radius):
+@pytest.mark.parametrize("src_hw,out_wh,radius,kind_m,kind_w", MIRROR_GEOMETRIES)
+def test_mirror_single_image_launch_geometries(V, oracle_mod, dev, src_hw, out_wh, radius, kind_m, kind_w):
     """apply() of ONE image of an unrotated bilinear chain (BASELINE config 1) takes the one-eye instantiation of
     k_ray_lin3_pair_mirror_raw (tile + mirror image from one set of coordinates, two boxes by LDS-DMA): every byte vs the
     oracle on the pair launch's geometries, m-table and w-table chains, a pitched source view."""
+    from vr180_convert_amd import remapper
     from vr180_convert_amd.synth import noise_disc
 
     O = oracle_mod
     wide = noise_disc(src_hw[0], src_hw[1] + 8, 23)
     img = wide[:, 4:4 + src_hw[1]]  # a column slice: pitch != 3 * width, rows dword-aligned (12-byte shift)
-    for spec in ([("equirect_enc", True), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]):
+    for spec, kind in (([("equirect_enc", True), CS.EQUI], kind_m), ([("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI], kind_w)):
         want = O.apply(spec, [np.ascontiguousarray(img)], size_output=out_wh, interpolation=1, radius=radius, border_value=(5, 6, 7))[0]
         src = torch.from_numpy(wide).to(dev)[:, 4:4 + src_hw[1]]
         dst = torch.empty((out_wh[1], out_wh[0], 3), dtype=torch.uint8, device=dev)
         V.remap_tensors(CS.to_product(spec), [src], [dst], radius=radius, interpolation=1, boarder_value=(5, 6, 7))
+        assert remapper.last_launch_kinds() == [kind], (remapper.last_launch_kinds(), spec)
         got = dst.cpu().numpy()
         assert np.array_equal(got, want), (spec, int((got != want).sum()))
 
@@ -1487,23 +1521,30 @@ def test_remap_sharded_splits_rows_when_devices_outnumber_eyes(V, oracle_mod):
         assert np.array_equal(got[0], want), ndev
 
 
+_DMA_KINDS: list = []  # (what, kernel family) of the pair / single-image launches of the test below
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_dma_kernels_random_geometries(V, oracle_mod, dev, seed):
     """The LDS-DMA kernels (k_ray_lin3_pair_mirror_raw for pairs, k_ray_lin3_batch_lean_raw for batches) on seeded random
     geometries: sources that are column halves of one SBS frame (pitched views whose rows end inside the frame / at its
     last byte -- the 16-byte units of a box row may read up to 12 bytes past the box, never past the allocation),
     magnification and minification, radius, polynomial.  Every output byte against the oracle."""
+    from vr180_convert_amd import remapper
     from vr180_convert_amd.synth import noise_disc
 
     O = oracle_mod
     rng = np.random.default_rng(900 + seed)
     h_in = int(rng.integers(6, 40)) * 16 + int(rng.integers(0, 16))
     w_in = int(rng.integers(6, 40)) * 16 + int(rng.integers(0, 4)) * 4  # (views of an SBS frame stay dword-aligned: w_in % 4 == 0)
-    out_w = int(rng.integers(2, 12)) * 64 + int(rng.choice([0, 0, 4, 60]))
-    out_h = int(rng.integers(3, 12)) * 32
-    radius = float(rng.uniform(0.35, 0.75)) * min(h_in, w_in)
+    # (outputs the mirror launch takes: rows pair up about the equator, at least ~416 px either way, not wider than high by more than
+    #  a tile -- rays beyond 90 degrees of longitude need the fix-up pass, which rules the mirror kernels out)
+    out_h = int(rng.integers(14, 23)) * 32
+    out_w = (out_h // 64 - int(rng.integers(0, 2))) * 64 + int(rng.choice([0, 0, 4, 60]))
+    radius = float(rng.uniform(0.35, 0.75 if seed % 4 == 2 else 0.55)) * min(h_in, w_in)  # (beyond 0.5: rays leave the source)
     spec = [("equirect_enc", True)]
-    if rng.random() < 0.6:
+    poly = seed % 4 == 3  # (a w-table: one entry per lane only from ~1000 px on -> the pair kernel here)
+    if poly:
         spec.append(("poly", [0, 1, float(rng.uniform(-0.2, 0.1))]))
     spec.append(CS.EQUI)
     frame = noise_disc(h_in, 2 * w_in, 40 + seed)
@@ -1514,6 +1555,9 @@ def test_dma_kernels_random_geometries(V, oracle_mod, dev, seed):
     fr = torch.from_numpy(frame).to(dev)
     got = V.apply_lr_tensors(CS.to_product(spec), fr[:, :w_in], fr[:, w_in:], size_output=(out_w, out_h), interpolation=1,
                              radius=radius, boarder_value=(9, 8, 7)).cpu().numpy()
+    kinds = remapper.last_launch_kinds()
+    assert kinds in (["mirror"], ["tile"]), (kinds, spec, out_w, out_h)  # (boxes beyond the DMA buffers: the pair kernel)
+    _DMA_KINDS.append(("pair", kinds[0]))
     assert np.array_equal(got, want), ("pair", h_in, w_in, out_w, out_h, int((got != want).sum()))
     # the same map over a batch of 5 views (3 + 2 units per workgroup): the batch kernel
     frames = [noise_disc(h_in, 2 * w_in, 60 + 5 * seed + f) for f in range(3)]
@@ -1522,12 +1566,14 @@ def test_dma_kernels_random_geometries(V, oracle_mod, dev, seed):
     srcs = [d[:, :w_in] for d in dev_frames] + [d[:, w_in:] for d in dev_frames[:2]]
     dsts = [torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=dev) for _ in srcs]
     V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=radius, interpolation=1)
+    assert remapper.last_launch_kinds() == ["batch"], remapper.last_launch_kinds()
     wants = O.apply(spec, srcs_np, size_output=(out_w, out_h), interpolation=1, radius=radius)
     for k in range(5):
         assert np.array_equal(dsts[k].cpu().numpy(), wants[k]), ("batch", k, h_in, w_in, out_w, out_h)
     # ONE image of the same map: the one-eye instantiation of the mirror kernel (its boxes have a pair's four buffers)
     dst = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=dev)
     V.remap_tensors(CS.to_product(spec), [fr[:, w_in:]], [dst], radius=radius, interpolation=1, boarder_value=(9, 8, 7))
+    _DMA_KINDS.append(("single", remapper.last_launch_kinds()[0]))
     want1 = O.apply(spec, [np.ascontiguousarray(right)], size_output=(out_w, out_h), interpolation=1, radius=radius, border_value=(9, 8, 7))[0]
     assert np.array_equal(dst.cpu().numpy(), want1), ("single", h_in, w_in, out_w, out_h)
     # the pair with INTER_NEAREST (bilinear tile kernels, coordinates 32 * cvRound(x)) and with bilinear BORDER_TRANSPARENT (store mask
@@ -1543,6 +1589,13 @@ def test_dma_kernels_random_geometries(V, oracle_mod, dev, seed):
     V.remap_tensors(CS.to_product(spec), [fr[:, :w_in], fr[:, w_in:]], dts, radius=radius, interpolation=1, boarder_mode=5)
     for e in range(2):
         assert np.array_equal(dts[e].cpu().numpy(), wt[e]), ("transparent", e, h_in, w_in, out_w, out_h)
+
+
+def test_dma_kernels_random_geometries_reached_the_mirror_kernels():
+    """at least four of the ten seeds above ran their pair AND their single image through the mirror kernels"""
+    if len(_DMA_KINDS) < 20:
+        pytest.skip("runs behind all ten seeds of test_dma_kernels_random_geometries")
+    assert sum(k == ("pair", "mirror") for k in _DMA_KINDS) >= 4 and sum(k == ("single", "mirror") for k in _DMA_KINDS) >= 4, _DMA_KINDS
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -232,3 +232,16 @@ def test_hand_written_memory_instructions_keep_their_wait_states(kernels_dis):
                 assert ins[i + 1].op == "s_nop" and ins[i + 1].args.strip() == "1", (name, hex(x.addr), ins[i + 1].op, ins[i + 1].args)
                 n_st += 1
     assert n_dma >= 20 and n_st >= 8, (n_dma, n_st)
+
+
+def test_no_kernel_contains_the_packed_shift_the_compiler_misreads(kernels_dis, tuning_dis, tmp_path_factory):
+    """v_ashr_pk_u8_i32 / v_ashr_pk_i8_i32 (new on gfx950) write 16 bits and leave the upper half of their destination as it was;
+    the compiler (ROCm 7.2) forms them from shift + clamp + pack of two bytes and then treats the result as zero-extended.  BGRA
+    bicubic / Lanczos4 came out with channels 2 and 3 OR-ed with a stale weight dword until the clamp got its own statement
+    (fixpt_u8, csrc/tile_device.hpp; found by tools/fuzz.py in round 4).  No object of the library may contain the instruction."""
+    generic = _disassemble(tmp_path_factory, "kernels.o")
+    n = 0
+    for name, ins in {**generic, **kernels_dis, **tuning_dis}.items():
+        n += len(ins)
+        assert not [x for x in ins if x.op.startswith("v_ashr_pk_")], name
+    assert n > 100000

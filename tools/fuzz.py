@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Differential fuzz on the GPU: random chains / sizes / flags through the product (C ABI, HIP kernels) against the CPU oracle,
+byte for byte, for a bounded time.  Wider than the seeded sweeps of tests/test_gpu_parity.py (those are the regression net; this
+is the search): chains drawn from a grammar over every lowered stage, sizes from 1 px to a few thousand (several tile rows, XCD
+strips, rest lists, the unit ring), cn 1 / 3 / 4, every interpolation and border mode incl. BORDER_TRANSPARENT, pitched source
+and destination views (dword-aligned or not), per-unit rotations, apply_lr pairs.
+
+    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--log gpurun_out/fuzz.log]
+
+Pixels at a pole of the projection are left out under the border modes that read source pixels there (REPLICATE, REFLECT, WRAP,
+REFLECT_101): where tan(theta) is taken at theta = 90 degrees one coordinate is ~1e17 - 1e19 and the other the ratio of two rounding
+residues of pi / 2 -- its value depends on the last bit of the platform's sin / cos (the product's per-pixel code compiled for the
+host equals the oracle there, tests/test_host_emul.py; the GPU's libm rounds differently).  With BORDER_CONSTANT -- the reference's
+default -- and BORDER_TRANSPARENT such a pixel is the border value / untouched either way and IS compared.  They are counted
+("singular") so that the exclusion stays visible.
+
+Every mismatch is printed as a self-contained case description (seed + case number reproduce it: `--seed S --only N`); exit code 1
+if there was one.  The oracle is test infrastructure: this tool is not part of the product.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import chainspecs as CS  # noqa: E402
+import vr180_convert_amd as V  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+MODELS = ["rectilinear", "stereographic", "equidistant", "equisolid", "orthographic"]
+
+
+def rand_rot(rng, big: bool):
+    from vr180_convert_amd.quat import as_rotation_matrix, from_rotation_vector
+
+    v = rng.normal(0, 1.0 if big else 0.03, 3)
+    return np.asarray(as_rotation_matrix(from_rotation_vector(v)), float)
+
+
+def rand_spec(rng):
+    """(spec, index of the chain's only rotate stage or None)"""
+    r = rng.random()
+    enc = ("equirect_enc", bool(rng.random() < 0.85)) if r < 0.7 else ("fisheye_enc", MODELS[int(rng.integers(5))])
+    mid = []
+    n_rot = 0
+    for _ in range(int(rng.choice([0, 0, 1, 1, 2, 3]))):
+        k = rng.random()
+        if k < 0.35:
+            mid.append(("rot", rand_rot(rng, rng.random() < 0.4).tolist()))
+            n_rot += 1
+        elif k < 0.45:
+            q = rng.normal(0, 1, 4)
+            q[0] = abs(q[0]) + 0.5  # non-unit on purpose (cli.py:308-319 builds such quaternions)
+            mid.append(("rot_quat", tuple(float(x) for x in q)))
+            n_rot += 1
+        elif k < 0.7:
+            n = int(rng.integers(2, 6))
+            co = [0.0, 1.0] + [float(x) for x in rng.normal(0, 0.08, n - 2)]
+            if rng.random() < 0.3:
+                co[0] = float(rng.normal(0, 0.02))
+            mid.append(("poly", co))
+        elif k < 0.9:
+            mid.append(("zoom", float(rng.uniform(0.4, 2.5))))
+        else:
+            mid.append(("inverse", ("zoom", float(rng.uniform(0.5, 2.0)))))
+    d = rng.random()
+    if d < 0.75:
+        dec = ("fisheye_dec", "equidistant")
+    elif d < 0.93:
+        dec = ("fisheye_dec", MODELS[int(rng.integers(5))])
+    else:
+        dec = ("rectilinear_dec", float(rng.uniform(8, 30)), float(rng.uniform(10, 40)))
+    spec = [enc] + mid + [dec]
+    rot_at = None
+    if n_rot == 1:
+        rot_at = [i for i, it in enumerate(spec) if it[0] in ("rot", "rot_quat")][0]
+    return spec, rot_at
+
+
+def rand_size(rng, big: float, lo: int = 1):
+    r = rng.random()
+    if r < big:
+        return int(rng.integers(1200, 2700))
+    if r < big + 0.35:
+        return int(rng.integers(300, 1200))
+    return int(rng.integers(lo, 300))
+
+
+def make_view(rng, arr: np.ndarray, dev, allow_unaligned: bool):
+    """the array as a device tensor: contiguous, or a column slice of a wider buffer (pitched; offset dword-aligned or not)"""
+    h, w, cn = arr.shape
+    if rng.random() < 0.5:
+        return torch.from_numpy(arr).to(dev)
+    pad_l = int(rng.integers(0, 9)) if allow_unaligned and rng.random() < 0.3 else 4 * int(rng.integers(0, 5))
+    pad_r = int(rng.integers(0, 9)) if allow_unaligned and rng.random() < 0.3 else 4 * int(rng.integers(0, 5))
+    wide = rng.integers(0, 256, (h, pad_l + w + pad_r, cn), dtype=np.uint8)
+    wide[:, pad_l:pad_l + w] = arr
+    return torch.from_numpy(wide).to(dev)[:, pad_l:pad_l + w]
+
+
+DUMP = [False]
+SINGULAR = [0]  # differing pixels at poles of the projection under source-reading border modes (module docstring)
+
+
+def dump_diff(k, got, want, maps, pmaps=None) -> None:
+    """where unit k differs: counts, bounding box, the first pixels with their map coordinates (the oracle's and the product's)"""
+    d = np.argwhere((got != want).any(axis=2))
+    print(f"  unit {k}: {len(d)} pixels differ, rows {d[:, 0].min()}..{d[:, 0].max()}, cols {d[:, 1].min()}..{d[:, 1].max()}; "
+          f"rows mod 16 {sorted(set((d[:, 0] % 16).tolist()))[:16]}, cols//4 mod 16 {sorted(set(((d[:, 1] // 4) % 16).tolist()))[:16]}")
+    for (j, i) in d[:12]:
+        pm = "" if pmaps is None else f" product map=({pmaps[0][j, i]!r}, {pmaps[1][j, i]!r})"
+        print(f"    (row {j}, col {i}) map=({maps[0][j, i]!r}, {maps[1][j, i]!r}){pm} got={got[j, i].tolist()} want={want[j, i].tolist()}")
+
+
+def one_case(rng, dev, big: float) -> tuple[str, int]:
+    """runs one random case; returns (description, number of differing bytes)"""
+    spec, rot_at = rand_spec(rng)
+    cn = int(rng.choice([3, 3, 3, 1, 4]))
+    interp = int(rng.choice([1, 1, 1, 0, 2, 4, 4]))
+    border = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 4, 5]))
+    bval = tuple(int(x) for x in rng.integers(0, 256, int(rng.integers(1, 5)))) if rng.random() < 0.7 else int(rng.integers(0, 256))
+    pair = rng.random() < 0.3
+    wo, ho = rand_size(rng, big), rand_size(rng, big)
+    if rng.random() < 0.3:
+        ho = wo
+    ws, hs = rand_size(rng, big, 3), rand_size(rng, big, 2)
+    if rng.random() < 0.4:
+        ws = hs = max(ws, 3)
+    if interp in (2, 4) and max(wo * ho, ws * hs) > 1500 * 1500:  # keep the oracle's K x K loops in seconds
+        wo, ho = min(wo, 1400), min(ho, 1400)
+    rsel = rng.random()
+    radius = min(ws, hs) / 2 if rsel < 0.5 else float(rng.uniform(0.2, 1.6) * min(ws, hs) / 2) if rsel < 0.92 else -float(rng.uniform(5, 100))
+    radius = float(max(radius, 1.0)) if radius > 0 else radius
+    if pair:
+        n = 2
+    else:
+        n = int(rng.choice([1, 1, 2, 3, 5, 8, 17, 33]))
+        if wo * ho * n > 6e6:
+            n = max(1, int(6e6 // (wo * ho)))
+    use_rot = (rot_at is not None) and (not pair) and rng.random() < 0.5
+    rots = [rand_rot(rng, False) for _ in range(n)] if use_rot else None
+    imgs = [rng.integers(0, 256, (hs, ws, cn), dtype=np.uint8) for _ in range(n)]
+    if rng.random() < 0.3:  # a fisheye disc with a black surround, like the real inputs
+        yy, xx = np.mgrid[:hs, :ws]
+        mask = ((xx - ws // 2) ** 2 + (yy - hs // 2) ** 2) > (min(ws, hs) / 2) ** 2
+        for im in imgs:
+            im[mask] = 0
+    fill = rng.integers(0, 256, (ho, wo, cn), dtype=np.uint8)
+    desc = f"spec={spec!r} cn={cn} interp={interp} border={border} bval={bval!r} out=({wo},{ho}) src=({ws},{hs}) radius={radius!r} n={n} pair={pair} rots={use_rot}"
+    t = CS.to_product(spec)
+    srcs = [make_view(rng, im, dev, allow_unaligned=True) for im in imgs]
+    if pair:
+        sbs = torch.from_numpy(np.concatenate([fill, fill], axis=1)).to(dev)
+        V.apply_lr_tensors(t, srcs[0], srcs[1], out=sbs, size_output=(wo, ho), interpolation=interp, boarder_mode=border, boarder_value=bval,
+                           radius=radius)
+        got = [sbs[:, :wo].cpu().numpy(), sbs[:, wo:].cpu().numpy()]
+    else:
+        dsts = [make_view(rng, fill.copy(), dev, allow_unaligned=True) for _ in range(n)]
+        kw = {}
+        if use_rot:
+            kw["rotations"] = rots
+        V.remap_tensors(t, srcs, dsts, radius=radius, interpolation=interp, boarder_mode=border, boarder_value=bval, **kw)
+        got = [d.cpu().numpy() for d in dsts]
+    bad = 0
+    maps = None
+    sing = None
+    for k in range(n):
+        if use_rot:
+            sp = list(spec)
+            sp[rot_at] = ("rot", rots[k].tolist())
+            maps = O.get_map(sp, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+        elif maps is None:
+            maps = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+        want = O.remap(imgs[k], maps[0], maps[1], interp, border, bval, dst=fill.copy())
+        if border in (1, 2, 3, 4) and (use_rot or sing is None):
+            sing = ~((np.abs(maps[0]) < 2.0 ** 25) & (np.abs(maps[1]) < 2.0 ** 25))  # (NaN counts as singular)
+        if sing is not None and sing.any():
+            diff = (got[k] != want).any(axis=2)
+            SINGULAR[0] += int((diff & sing).sum())
+            want = want.copy()
+            want[sing] = got[k][sing]
+        bad += int((got[k] != want).sum())
+        if DUMP[0] and (got[k] != want).any():
+            pm = None
+            try:
+                sp_k = spec if not use_rot else sp
+                pm = V.get_map(CS.to_product(sp_k), radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+            except Exception as e:  # noqa: BLE001
+                print("  (product map unavailable:", e, ")")
+            dump_diff(k, got[k], want, maps, pm)
+    return desc, bad
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", type=float, default=0.15, help="share of sizes drawn from 1200 - 2700")
+    ap.add_argument("--only", type=int, default=None, help="run only this case number (reproduce)")
+    ap.add_argument("--log", default=None)
+    ap.add_argument("--dump", action="store_true", help="print where a mismatching unit differs")
+    a = ap.parse_args()
+    DUMP[0] = a.dump
+    dev = torch.device("cuda", 0)
+    log = open(a.log, "a") if a.log else None
+
+    def say(s: str) -> None:
+        print(s, flush=True)
+        if log:
+            log.write(s + "\n")
+            log.flush()
+
+    t0 = time.time()
+    n_cases = n_bad = 0
+    last = t0
+    case = 0
+    while time.time() - t0 < a.seconds:
+        rng = np.random.default_rng([a.seed, case])  # every case reproducible by itself
+        if a.only is not None:
+            rng = np.random.default_rng([a.seed, a.only])
+        try:
+            desc, bad = one_case(rng, dev, a.big)
+        except Exception as e:  # noqa: BLE001 -- a refusal of the product (documented limits) is reported, not fatal
+            desc, bad = f"EXCEPTION {type(e).__name__}: {e}", -1
+        n_cases += 1
+        if bad != 0:
+            n_bad += 1
+            say(f"[case {a.only if a.only is not None else case}] {'MISMATCH ' + str(bad) + ' bytes' if bad > 0 else ''} {desc}")
+        if a.only is not None:
+            say(f"case {a.only}: {bad} differing bytes; {desc}")
+            break
+        case += 1
+        if time.time() - last > 30:
+            last = time.time()
+            say(f"... {n_cases} cases, {n_bad} reported, {time.time() - t0:.0f} s")
+    say(f"fuzz seed {a.seed}: {n_cases} cases in {time.time() - t0:.0f} s, {n_bad} reported; {SINGULAR[0]} differing pixels at projection poles left out")
+    return 1 if n_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

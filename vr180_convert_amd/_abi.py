@@ -13,6 +13,10 @@ OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4
 # cv2 enum values (reference cli.py:57-79 mirrors the same names)
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101, BORDER_TRANSPARENT = 0, 1, 2, 3, 4, 5
+# v1c_plan_last_launch (tests / bench): which kernels served the last launch group; | LAUNCH_FIXUP when a fix-up pass followed
+LAUNCH_GENERIC, LAUNCH_TILE, LAUNCH_MIRROR, LAUNCH_CN, LAUNCH_CN_ROT, LAUNCH_BATCH, LAUNCH_ROT_PAIR, LAUNCH_FIXUP = 0, 1, 2, 3, 4, 5, 6, 0x100
+LAUNCH_NAMES = {LAUNCH_GENERIC: "generic", LAUNCH_TILE: "tile", LAUNCH_MIRROR: "mirror", LAUNCH_CN: "cn", LAUNCH_CN_ROT: "cn_rot",
+                LAUNCH_BATCH: "batch", LAUNCH_ROT_PAIR: "rot_pair"}
 
 OP_NORMALIZE, OP_DENORMALIZE, OP_DENORMALIZE_INV, OP_ZOOM, OP_ZOOM_INV = 1, 2, 3, 4, 5
 OP_EQUIRECT_ENC, OP_EQUIRECT_DEC, OP_RADIAL, OP_ROTATE = 6, 7, 8, 9

@@ -113,7 +113,7 @@ int tile_half_dwords(const void* host_boxes, size_t n_tiles);
 // (radial_table_g_bound): k_ray_lin3_rot_pair_raw evaluates its speculative coordinates without the clamps of the cvRound trick
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,
                                 int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
-                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded = false);
+                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded = false, int* kind = nullptr);
 int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int lean_half);
 int tile_lean_half_dwords(int half_dwords);
 // `raw_nwp` > 0: batches through k_ray_lin3_batch_lean_raw (boxes by LDS-DMA, buffers of raw_nwp KB: tile_lean_raw_passes)

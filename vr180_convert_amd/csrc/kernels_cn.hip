@@ -115,7 +115,7 @@ __device__ __noinline__ uint32_t slow_pixel_table_cn(const uint8_t* src, int64_t
     uint32_t out = 0;
 #pragma unroll
     for (int ch = 0; ch < CN; ch++)
-        out |= (uint32_t)min(max(acc[ch] >> 15, 0), 255) << (8 * ch);
+        out |= fixpt_u8(acc[ch]) << (8 * ch);
     return out;
 }
 
@@ -170,7 +170,7 @@ __device__ __forceinline__ uint32_t blend_table_cn(uint32_t a, uint32_t pitch, g
     uint32_t out = 0;
 #pragma unroll
     for (int ch = 0; ch < CN; ch++)
-        out |= (uint32_t)min(max(acc[ch] >> 15, 0), 255) << (8 * ch);
+        out |= fixpt_u8(acc[ch]) << (8 * ch);
     return out;
 }
 

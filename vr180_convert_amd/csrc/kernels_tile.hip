@@ -629,7 +629,7 @@ hipError_t launch_tile_boxes(const KernelCtx& c, const KernelCtx* cdev, void* bo
 template <int K>
 static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const TileBox* bx,
                           int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
-                          int lean_raw_nwp, hipStream_t stream, bool coords_bounded)
+                          int lean_raw_nwp, hipStream_t stream, bool coords_bounded, int* kind)
 {
     const int n_units = lu.n;
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
@@ -722,6 +722,8 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
     }();
     if constexpr (K == 2) {
         if (!bx && shared_entry && !rot_pair_off && !nn) {
+            if (kind)
+                *kind = V1C_LAUNCH_ROT_PAIR;
             const dim3 pgrid(grid.x, grid.y, (unsigned)((n_units + 1) / 2));
             const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int);
             const bool mp = mpoly_all && c.ray.radial_m != nullptr;
@@ -761,6 +763,8 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
             if (lean) {                                                                                                               \
                 /* (running the remaining tiles on a side stream, forked and joined with events so that their */                      \
                 /* latency-bound kernel overlaps the lean one, measured 4 % slower on C3 than back to back) */                        \
+                if (kind)                                                                                                             \
+                    *kind = V1C_LAUNCH_BATCH;                                                                                         \
                 TileArgs la = a;                                                                                                      \
                 la.half_dwords = lean_half, la.kb = lean_raw_nwp;                                                                     \
                 la.rest_list = merged ? rest_list : (const uint32_t*)nullptr, la.n_rest = n_rest;                                     \
@@ -838,13 +842,15 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
 // `flags`: the plan's tile-flag words when a fix-up pass follows this launch, else null.
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,
                                 int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
-                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded)
+                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded, int* kind)
 {
     const TileBox* bx = (const TileBox*)boxes;
+    if (kind)
+        *kind = V1C_LAUNCH_TILE;  // (the general kernel, unless launch_tile_k picks the batch / rotation-pair kernel)
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
-    case 4: launch_tile_k<4>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
-    case 8: launch_tile_k<8>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded); break;
+    case 2: launch_tile_k<2>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind); break;
+    case 4: launch_tile_k<4>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind); break;
+    case 8: launch_tile_k<8>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

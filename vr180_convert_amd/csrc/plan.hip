@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -218,6 +219,7 @@ struct v1c_plan {
     hipEvent_t flags_ev = nullptr;
     hipStream_t flags_stream = nullptr;
     bool flags_pending = false;
+    std::atomic<int> last_launch{-1};   // V1C_LAUNCH_* of the most recent launch group of v1c_plan_run (tests: v1c_plan_last_launch)
     std::vector<void*> allocs;
 };
 
@@ -829,6 +831,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         if (p->mode != MODE_RAY) {
             const int n = std::min(kMaxUnitsPerLaunch, n_units - base);
             HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, unit_args(du + base, n), n, st));
+            p->last_launch.store(V1C_LAUNCH_GENERIC, std::memory_order_relaxed);
             base += n;
             continue;
         }
@@ -847,6 +850,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         // cases run the ray pass and, unless provably unnecessary, the fix-up pass
         if (d.any_rot && p->n_rot_stages > 1) {
             HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, unit_args(u, n), n, st));
+            p->last_launch.store(V1C_LAUNCH_GENERIC, std::memory_order_relaxed);
             continue;
         }
         std::unique_lock<std::mutex> flags_lk(p->flags_mu, std::defer_lock);
@@ -871,7 +875,9 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         // (a single image -- apply() of one image, BASELINE config 1 -- takes the LDS-DMA form's one-eye instantiation)
         const bool mirror = d.fast && (n == 2 || (n == 1 && p->mirror_raw_nwp > 0 && p->n_mirror_rest1 >= 0)) && !d.any_rot &&
                             p->mirror_boxes != nullptr && shared && aligned;
+        int kind = V1C_LAUNCH_GENERIC;
         if (mirror) {
+            kind = V1C_LAUNCH_MIRROR;
             HIP_TRY(launch_ray_lin3_pair_mirror(p->ctx, p->ctx_dev, lu, flags, p->tile_boxes, p->mirror_raw_nwp > 0 ? p->mirror_pairs : p->mirror_boxes,
                                                 p->half_dwords, p->mirror_h,
                                                 n == 1 ? p->mirror_rest1 : p->mirror_rest, n == 1 ? p->n_mirror_rest1 : p->n_mirror_rest,
@@ -879,17 +885,21 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         } else if (d.fast && p->ctx.g.cn != 3) {
             // grayscale / BGRA: k_ray_lin_cn (one table entry per lane; plan-time boxes for the plan's own rotation, boxes reduced in the
             // kernel -- one unit per workgroup, a 12 KB buffer -- for units that override it)
-            if (p->cn_kb > 0 && !d.any_rot && shared && aligned)
+            if (p->cn_kb > 0 && !d.any_rot && shared && aligned) {
+                kind = V1C_LAUNCH_CN;
                 HIP_TRY(launch_ray_lin_cn(p->ctx, p->ctx_dev, lu, flags, p->ana.has_rot, p->tile_boxes, p->cn_kb, st));
-            else if (d.any_rot && shared && aligned && cn_kernel_supports(p->ctx.g))
+            } else if (d.any_rot && shared && aligned && cn_kernel_supports(p->ctx.g)) {
+                kind = V1C_LAUNCH_CN_ROT;
                 HIP_TRY(launch_ray_lin_cn(p->ctx, p->ctx_dev, lu, flags, true, nullptr, 12, st));
-            else
+            } else {
                 HIP_TRY(launch_remap(MODE_RAY, p->ctx, unit_args(u, n), n, st));
+            }
         } else if (d.fast) {
             // precomputed tile boxes describe the plan's own rotation only
+            kind = V1C_LAUNCH_TILE;
             HIP_TRY(launch_ray_lin3_tile(p->ctx, p->ctx_dev, lu, flags, d.any_rot || p->ana.has_rot, d.any_rot ? nullptr : p->tile_boxes,
                                          p->half_dwords, shared, d.mpoly_all && !p->disable_mpoly, d.any_rot ? nullptr : p->rest_list, p->n_rest,
-                                         p->lean_half, p->strip_len, p->lean_raw_nwp, st, d.coords_bounded && !p->disable_coords_bounded));
+                                         p->lean_half, p->strip_len, p->lean_raw_nwp, st, d.coords_bounded && !p->disable_coords_bounded, &kind));
         } else {
             HIP_TRY(launch_remap(MODE_RAY, p->ctx, unit_args(u, n), n, st));
         }
@@ -898,6 +908,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             if (rc)
                 return rc;
         }
+        p->last_launch.store(kind | (d.need_fixup ? V1C_LAUNCH_FIXUP : 0), std::memory_order_relaxed);
         if (d.need_fixup) {
             HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, unit_args(u, n), n, st));
             HIP_TRY(hipEventRecord(p->flags_ev, st));
@@ -948,6 +959,13 @@ static constexpr size_t kFusedCacheSize = 32;
 static std::mutex g_cache_mu;
 static std::list<std::pair<PlanKey, std::shared_ptr<v1c_plan>>> g_cache_lru;  // front = most recently used
 static std::map<PlanKey, std::list<std::pair<PlanKey, std::shared_ptr<v1c_plan>>>::iterator> g_cache;
+
+extern "C" int v1c_plan_last_launch(const v1c_plan* p)
+{
+    if (!p)
+        return fail(V1C_E_INVALID, "plan is NULL");
+    return p->last_launch.load(std::memory_order_relaxed);
+}
 
 extern "C" int v1c_fused_cache_size(void)
 {

@@ -778,6 +778,18 @@ __device__ __forceinline__ uint32_t blend3(uint32_t alo, uint32_t ahi, uint32_t 
 // FixedPtCast: saturate((sum + 2^14) >> 15).  `lo` = dword index of the top-left tap.
 typedef short __attribute__((ext_vector_type(2))) short2v;
 
+// saturate_cast<uchar>(acc >> 15) of a FixedPtCast sum (acc already holds the + 2^14), for results that are packed into one dword
+// by shifts and ors.  The value passes through an empty asm statement: without it the compiler fuses shift + clamp + the packing of
+// two channels into v_ashr_pk_u8_i32 (new on gfx950) and treats its 16-bit result as zero-extended, while the instruction leaves the
+// upper half of its destination register as it was -- BGRA bicubic / Lanczos4 came out with channels 2 and 3 OR-ed with the bits of
+// a stale weight dword (found by tools/fuzz.py in round 4; tests/test_resource_budget.py keeps the instruction out of every object).
+__device__ __forceinline__ uint32_t fixpt_u8(int acc)
+{
+    int v = min(max(acc >> 15, 0), 255);
+    asm("" : "+v"(v));
+    return (uint32_t)v;
+}
+
 // (not inlined: four inlined copies make the scheduler hoist all 4 x K*K tap loads -> 256 VGPRs)
 // explicit address spaces: a generic pointer into a noinline function costs a flat-address null
 // check (3 VALU) per tap and defeats ds_read2 / global_load selection

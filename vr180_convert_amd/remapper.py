@@ -130,6 +130,14 @@ class Plan:
         """'ray' (fused separable tables + radial table) or 'literal' (fp64 interpreter)."""
         return "ray" if _native.lib().v1c_plan_path(self._h) == 1 else "literal"
 
+    def last_launch(self) -> str:
+        """Kernel family of this plan's most recent launch group (``v1c_plan_last_launch``): 'generic', 'tile', 'mirror', 'batch',
+        'rot_pair', 'cn' or 'cn_rot', with '+fixup' when a fix-up pass followed; '' before the first run.  For tests and the bench."""
+        k = _native.lib().v1c_plan_last_launch(self._h)
+        if k < 0:
+            return ""
+        return _abi.LAUNCH_NAMES.get(k & 0xFF, "?") + ("+fixup" if k & _abi.LAUNCH_FIXUP else "")
+
     def run(self, srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor], rots: Sequence[Any] | None = None) -> None:
         n = len(srcs)
         if n == 0 or len(dsts) != n or (rots is not None and len(rots) != n):
@@ -189,6 +197,16 @@ class Plan:
 _PLANS: "OrderedDict[tuple, Plan]" = OrderedDict()
 _PLAN_CACHE_SIZE = 32
 _PLANS_LOCK = threading.Lock()  # one worker thread per device (sharding.py) shares this cache
+
+
+_TLS = threading.local()  # .plans: the plans the calling thread's last remap_tensors ran (last_launch_kinds)
+
+
+def last_launch_kinds() -> list[str]:
+    """Kernel family per launch group of the calling thread's most recent ``remap_tensors`` / ``apply_lr_tensors`` call
+    (``Plan.last_launch``: 'generic', 'tile', 'mirror', 'batch', 'rot_pair', 'cn', 'cn_rot', '+fixup' appended when a fix-up pass followed).  The engine
+    serves the same bytes through several kernels; tests use this to make sure a case meant for a tiled kernel reached it."""
+    return [p.last_launch() for p in getattr(_TLS, "plans", [])]
 
 
 def clear_caches() -> None:
@@ -371,12 +389,14 @@ def remap_tensors(
             if memo_key is not None and last is not None and last[0] == memo_key:
                 plan = last[1]
                 plan.run(srcs, dsts, None)
+                _TLS.plans = [plan]
                 return [plan.path_cached]
     dev = srcs[0].device
     cn = int(srcs[0].shape[2])
     dst_wh = (int(dsts[0].shape[1]), int(dsts[0].shape[0]))
     groups, host_mapped = group_units(transformer, srcs, dsts, radius=radius, size_input=size_input)
     paths: list[str] = []
+    _TLS.plans = []
     for k, t, size_in_k in host_mapped:
         xm, ym = _host_map(t, radius=radius, size_input=size_in_k, size_output=dst_wh)
         xm_d, ym_d = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
@@ -394,6 +414,7 @@ def remap_tensors(
         plan = _plan_for(g.chain, src_hw=g.src_hw, dst_wh=dst_wh, cn=cn, interpolation=interpolation,
                          border_mode=boarder_mode, border_value=boarder_value, device=dev)
         plan.run(g.srcs, g.dsts, g.rots)
+        _TLS.plans.append(plan)
         paths.append(plan.path)
         if memo_key is not None and len(groups) == 1 and not host_mapped and g.rots is None and len(g.srcs) == n:
             plan.path_cached = paths[-1]
@@ -481,6 +502,7 @@ def _remap_with_rotations(transformer, srcs, dsts, rotations, *, radius, interpo
     plan = _plan_for(shared, src_hw=src_hw, dst_wh=dst_wh, cn=int(srcs[0].shape[2]), interpolation=interpolation,
                      border_mode=boarder_mode, border_value=boarder_value, device=dev)
     plan.run(srcs, dsts, [as_rotation_matrix(r) for r in rotations])
+    _TLS.plans = [plan]
     return [plan.path]
 
 
