@@ -7,12 +7,14 @@ and destination views (dword-aligned or not), per-unit rotations, apply_lr pairs
 
     python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--log gpurun_out/fuzz.log]
 
-Pixels at a pole of the projection are left out under the border modes that read source pixels there (REPLICATE, REFLECT, WRAP,
-REFLECT_101): where tan(theta) is taken at theta = 90 degrees one coordinate is ~1e17 - 1e19 and the other the ratio of two rounding
-residues of pi / 2 -- its value depends on the last bit of the platform's sin / cos (the product's per-pixel code compiled for the
-host equals the oracle there, tests/test_host_emul.py; the GPU's libm rounds differently).  With BORDER_CONSTANT -- the reference's
-default -- and BORDER_TRANSPARENT such a pixel is the border value / untouched either way and IS compared.  They are counted
-("singular") so that the exclusion stays visible.
+Pixels next to a pole of the projection are left out under the border modes that read source pixels there (REPLICATE, REFLECT, WRAP,
+REFLECT_101): where tan(theta) is taken at or next to theta = 90 degrees a coordinate is 1e6 ... 1e19 pixels and the fp64 rounding of
+pi / 2 and of the platform's sin / cos is amplified by the same factor -- at the pole itself the other coordinate is the ratio of two
+rounding residues and can change sign; a few 1e-5 rad beside it a coordinate of 2e6 px moved by one float32 ulp (seed 2, case 1423).
+The product's per-pixel code compiled for the host equals the oracle there (tests/test_host_emul.py); the GPU's libm rounds
+differently.  The mask: a map coordinate of magnitude >= 2^20 (cv2 itself saturates integer coordinates at 2^15).  With
+BORDER_CONSTANT -- the reference's default -- and BORDER_TRANSPARENT such a pixel is the border value / untouched either way and IS
+compared.  Masked pixels that differ are counted ("at projection poles") so that the exclusion stays visible.
 
 Every mismatch is printed as a self-contained case description (seed + case number reproduce it: `--seed S --only N`); exit code 1
 if there was one.  The oracle is test infrastructure: this tool is not part of the product.
@@ -181,7 +183,7 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
             maps = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
         want = O.remap(imgs[k], maps[0], maps[1], interp, border, bval, dst=fill.copy())
         if border in (1, 2, 3, 4) and (use_rot or sing is None):
-            sing = ~((np.abs(maps[0]) < 2.0 ** 25) & (np.abs(maps[1]) < 2.0 ** 25))  # (NaN counts as singular)
+            sing = ~((np.abs(maps[0]) < 2.0 ** 20) & (np.abs(maps[1]) < 2.0 ** 20))  # (NaN counts as singular)
         if sing is not None and sing.any():
             diff = (got[k] != want).any(axis=2)
             SINGULAR[0] += int((diff & sing).sum())
