@@ -640,6 +640,9 @@ def main() -> None:
                                              "run_band_job); every rank holds the whole source eye of its bands (upload not timed), "
                                              "no collective"}[args.split],
                        "split": args.split, "kernel_path": paths,
+                       # which kernel family served the launches of this workload (v1c_plan_last_launch): the measured launch is the
+                       # tiled kernel the workload is meant for, not the generic one
+                       "kernels": sorted({p.last_launch() for p in R._PLANS.values() if p.last_launch()}),
                        "buffer_sets": nsets},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,

@@ -107,6 +107,46 @@ def test_remap_lut_all_modes_vs_oracle(V, oracle_mod, dev, cn):
                 assert np.array_equal(out.cpu().numpy(), ref), (cn, interp, border, bv)
 
 
+@pytest.mark.parametrize("hw", [(101, 1), (1, 57), (1, 1), (2, 2), (3, 1)])
+def test_sources_one_pixel_wide_or_high(V, oracle_mod, dev, hw):
+    """Degenerate sources through the fused path and through cv2.remap alone: a source ONE pixel wide made the bilinear fast path's
+    unsigned bound wrap (reads far outside the image: a GPU memory fault, found by tools/fuzz.py in round 4; the host build of the
+    sampler runs under AddressSanitizer in tests/test_sampler_asan.py)."""
+    import ctypes as C
+
+    from vr180_convert_amd import _native
+    from vr180_convert_amd.remapper import border_scalar
+
+    O = oracle_mod
+    rng = np.random.default_rng(hw[0] * 1000 + hw[1])
+    hs, ws = hw
+    spec = [("equirect_enc", True), CS.EQUI]
+    for cn in (3, 1, 4):
+        src = rng.integers(0, 256, (hs, ws, cn), dtype=np.uint8)
+        s_d = torch.from_numpy(src).to(dev)
+        H, W = 40, 72
+        xm = rng.uniform(-6, ws + 6, (H, W)).astype(np.float32)
+        ym = rng.uniform(-6, hs + 6, (H, W)).astype(np.float32)
+        x_d, y_d = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
+        for interp in (0, 1, 2, 3, 4):
+            for border in range(6):
+                fill = rng.integers(0, 256, (H, W, cn), dtype=np.uint8)
+                want = O.remap(src, xm, ym, interp, border, (9, 8, 7, 6), dst=fill.copy())
+                out = torch.from_numpy(fill.copy()).to(dev)
+                rc = _native.lib().v1c_remap_lut(0, None, s_d.data_ptr(), hs, ws, s_d.stride(0), cn, out.data_ptr(), H, W, out.stride(0),
+                                                 x_d.data_ptr(), y_d.data_ptr(), W * 4, interp, border, border_scalar((9, 8, 7, 6)).ctypes.data)
+                assert rc == 0, _native.lib().v1c_last_error()
+                assert np.array_equal(out.cpu().numpy(), want), ("lut", hw, cn, interp, border)
+                if interp == 3:
+                    continue
+                dst = torch.from_numpy(fill.copy()).to(dev)
+                V.remap_tensors(CS.to_product(spec), [s_d], [dst], radius=max(hs, ws) / 2, interpolation=interp, boarder_mode=border,
+                                boarder_value=(9, 8, 7, 6))
+                xo, yo = O.get_map(spec, radius=max(hs, ws) / 2, size_input=(hs, ws), size_output=(W, H))
+                want = O.remap(src, xo, yo, interp, border, (9, 8, 7, 6), dst=fill.copy())
+                assert np.array_equal(dst.cpu().numpy(), want), ("chain", hw, cn, interp, border)
+
+
 # ---------------------------------------------------------------------------- fused path vs oracle
 CUTS = {
     # 1024^2 cuts of every BASELINE config (SURVEY.md 8d "Parity gate") + C1 in full

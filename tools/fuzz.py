@@ -3,9 +3,10 @@
 byte for byte, for a bounded time.  Wider than the seeded sweeps of tests/test_gpu_parity.py (those are the regression net; this
 is the search): chains drawn from a grammar over every lowered stage, sizes from 1 px to a few thousand (several tile rows, XCD
 strips, rest lists, the unit ring), cn 1 / 3 / 4, every interpolation and border mode incl. BORDER_TRANSPARENT, pitched source
-and destination views (dword-aligned or not), per-unit rotations, apply_lr pairs.
+and destination views (dword-aligned or not), per-unit rotations, apply_lr pairs; a share of the cases (--lut) runs cv2.remap alone
+(v1c_remap_lut) on random float32 maps sprinkled with NaN, infinities, 2^15 / 2^26 / 2^31-scale values and ties of the 1/32 grid.
 
-    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--log gpurun_out/fuzz.log]
+    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--lut 0.15] [--log gpurun_out/fuzz.log]
 
 Pixels next to a pole of the projection are left out under the border modes that read source pixels there (REPLICATE, REFLECT, WRAP,
 REFLECT_101): where tan(theta) is taken at or next to theta = 90 degrees a coordinate is 1e6 ... 1e19 pixels and the fp64 rounding of
@@ -133,9 +134,9 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
     wo, ho = rand_size(rng, big), rand_size(rng, big)
     if rng.random() < 0.3:
         ho = wo
-    ws, hs = rand_size(rng, big, 3), rand_size(rng, big, 2)
+    ws, hs = rand_size(rng, big, 1), rand_size(rng, big, 1)
     if rng.random() < 0.4:
-        ws = hs = max(ws, 3)
+        ws = hs = max(ws, 1)
     if interp in (2, 4) and max(wo * ho, ws * hs) > 1500 * 1500:  # keep the oracle's K x K loops in seconds
         wo, ho = min(wo, 1400), min(ho, 1400)
     rsel = rng.random()
@@ -201,13 +202,69 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
     return desc, bad
 
 
+def lut_case(rng, dev) -> tuple[str, int]:
+    """cv2.remap alone (v1c_remap_lut, what chains with user-defined stages use) on random float32 maps: smooth, noisy, and
+    sprinkled with the values the fixed-point conversion treats specially"""
+    import ctypes as C
+
+    from vr180_convert_amd import _native
+    from vr180_convert_amd.remapper import _stream_ptr, border_scalar
+
+    cn = int(rng.choice([1, 3, 4]))
+    interp = int(rng.choice([0, 1, 2, 3, 4]))
+    border = int(rng.integers(0, 6))
+    bval = tuple(int(x) for x in rng.integers(0, 256, int(rng.integers(1, 5))))
+    hs, ws = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+    ho, wo = int(rng.integers(1, 500)), int(rng.integers(1, 500))
+    src = rng.integers(0, 256, (hs, ws, cn), dtype=np.uint8)
+    jj, ii = np.mgrid[:ho, :wo].astype(np.float64)
+    kind = int(rng.integers(0, 3))
+    if kind == 0:  # affine + noise
+        a = rng.normal(0, 1, 6)
+        xm = a[0] * ii + a[1] * jj + rng.uniform(-ws, 2 * ws) + rng.normal(0, 0.3, (ho, wo))
+        ym = a[2] * ii + a[3] * jj + rng.uniform(-hs, 2 * hs) + rng.normal(0, 0.3, (ho, wo))
+    elif kind == 1:  # anywhere around the source
+        xm = rng.uniform(-40, ws + 40, (ho, wo))
+        ym = rng.uniform(-40, hs + 40, (ho, wo))
+    else:  # on the 1/32 grid and half-way between its points (ties of cvRound)
+        xm = rng.integers(-64, 32 * ws + 64, (ho, wo)) / 32.0 + rng.choice([0.0, 1 / 64, -1 / 64, 1e-7], (ho, wo))
+        ym = rng.integers(-64, 32 * hs + 64, (ho, wo)) / 32.0 + rng.choice([0.0, 1 / 64, -1 / 64, 1e-7], (ho, wo))
+    xm, ym = xm.astype(np.float32), ym.astype(np.float32)
+    special = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 3e9, -3e9, 2.0 ** 26, -(2.0 ** 26), 67108863.0, 32767.0, 32767.5, 32768.0, -32768.0,
+                        -32768.5, -32769.0, -0.5, -1.0, 0.0, -0.0, ws - 1.0, ws - 0.5, float(ws), hs - 1.0, float(hs), 1e-30, -1e-30], np.float32)
+    for m in (xm, ym):
+        k = int(rng.integers(0, max(2, m.size // 20)))
+        m.reshape(-1)[rng.integers(0, m.size, k)] = rng.choice(special, k)
+    pad = int(rng.integers(0, 3)) * 4
+    xw = np.zeros((ho, wo + pad), np.float32)
+    yw = np.zeros((ho, wo + pad), np.float32)
+    xw[:, :wo], yw[:, :wo] = xm, ym
+    fill = rng.integers(0, 256, (ho, wo, cn), dtype=np.uint8)
+    s_d = make_view(rng, src, dev, allow_unaligned=True)
+    d_d = make_view(rng, fill.copy(), dev, allow_unaligned=True)
+    x_d, y_d = torch.from_numpy(xw).to(dev), torch.from_numpy(yw).to(dev)
+    bv = border_scalar(bval)
+    rc = _native.lib().v1c_remap_lut(dev.index, _stream_ptr(dev), s_d.data_ptr(), hs, ws, s_d.stride(0), cn, d_d.data_ptr(), ho, wo, d_d.stride(0),
+                                     x_d.data_ptr(), y_d.data_ptr(), x_d.stride(0) * 4, interp, border, bv.ctypes.data)
+    _native.check(rc, "v1c_remap_lut")
+    got = d_d.cpu().numpy()
+    want = O.remap(src, xm, ym, interp, border, bval, dst=fill.copy())
+    bad = int((got != want).sum())
+    desc = f"LUT cn={cn} interp={interp} border={border} bval={bval!r} out=({wo},{ho}) src=({ws},{hs}) maps={kind} map_pad={pad}"
+    if bad and DUMP[0]:
+        dump_diff(0, got, want, (xm, ym))
+    return desc, bad
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", type=float, default=0.15, help="share of sizes drawn from 1200 - 2700")
+    ap.add_argument("--lut", type=float, default=0.15, help="share of cases that fuzz cv2.remap alone (v1c_remap_lut) on random maps")
     ap.add_argument("--only", type=int, default=None, help="run only this case number (reproduce)")
     ap.add_argument("--log", default=None)
+    ap.add_argument("--trace", default=None, help="file that always holds the number of the case being run")
     ap.add_argument("--dump", action="store_true", help="print where a mismatching unit differs")
     a = ap.parse_args()
     DUMP[0] = a.dump
@@ -228,8 +285,14 @@ def main() -> int:
         rng = np.random.default_rng([a.seed, case])  # every case reproducible by itself
         if a.only is not None:
             rng = np.random.default_rng([a.seed, a.only])
+        if a.trace:  # (a crash of the process -- a GPU memory fault aborts it -- leaves the case that was running on record)
+            with open(a.trace, "w") as tf:
+                tf.write(f"seed {a.seed} case {a.only if a.only is not None else case}\n")
         try:
-            desc, bad = one_case(rng, dev, a.big)
+            if rng.random() < a.lut:
+                desc, bad = lut_case(rng, dev)
+            else:
+                desc, bad = one_case(rng, dev, a.big)
         except Exception as e:  # noqa: BLE001 -- a refusal of the product (documented limits) is reported, not fatal
             desc, bad = f"EXCEPTION {type(e).__name__}: {e}", -1
         n_cases += 1

@@ -509,7 +509,7 @@ __device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowC
         // test); the bilinear path additionally wants 8 readable bytes per row for its global-memory
         // fallback, hence w - 2 there
         constexpr int off = K / 2 - 1;
-        const bool in = K == 2 ? okk & ((unsigned)ix < (unsigned)(g.src_w - 2)) & ((unsigned)iy < (unsigned)(g.src_h - 1))
+        const bool in = K == 2 ? okk & ((unsigned)ix < (unsigned)max(g.src_w - 2, 0)) & ((unsigned)iy < (unsigned)max(g.src_h - 1, 0))
                                : okk & ((unsigned)(ix - off) < (unsigned)max(g.src_w - (K - 1), 0)) &
                                      ((unsigned)(iy - off) < (unsigned)max(g.src_h - (K - 1), 0));
         L.inside |= in ? 1u << k : 0u;

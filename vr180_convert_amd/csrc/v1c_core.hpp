@@ -440,7 +440,9 @@ template <int CN>
 V1C_HD bool sample_linear_t(const Image& s, const Geom& g, const Taps t, uint8_t* out)
 {
     const int wx1 = t.fx, wx0 = 32 - t.fx, wy1 = t.fy, wy0 = 32 - t.fy;
-    if (CN == 3 && (unsigned)t.ix < (unsigned)(s.w - 2) && (unsigned)t.iy < (unsigned)(s.h - 1)) {
+    // (s.w - 2 clamped at 0: a source ONE pixel wide made the unsigned bound 2^32 - 1 and every pixel "inside" -- reads far outside
+    //  the image, a GPU memory fault; found by tools/fuzz.py in round 4)
+    if (CN == 3 && (unsigned)t.ix < (unsigned)(s.w > 2 ? s.w - 2 : 0) && (unsigned)t.iy < (unsigned)(s.h - 1)) {
         // whole 2x2 cell inside and 8 readable bytes per row: two unaligned 8-byte loads
         const uint8_t* p0 = s.p + (int64_t)t.iy * s.pitch + t.ix * 3;
         const u64pair a = load_u64_unaligned(p0);
