@@ -147,6 +147,53 @@ def test_sources_one_pixel_wide_or_high(V, oracle_mod, dev, hw):
                 assert np.array_equal(dst.cpu().numpy(), want), ("chain", hw, cn, interp, border)
 
 
+def test_views_of_buffers_beyond_4_gib_take_the_64_bit_kernels(V, oracle_mod, dev):
+    """The tile kernels address source and destination with 32-bit offsets; the host routes units whose rows end beyond 2^32 - 256 bytes
+    (or whose pitch is 2^24 or more) to the generic kernel with 64-bit offsets (decide_launch, csrc/plan.hip).  Sources and destinations
+    that are column slices of 4.6 GB / 5.1 GB buffers -- a pitch of 2.3 MB over 2 000 rows, a pitch of 17 MB over 300 -- against the
+    oracle, pairs and batches, and the same call on small buffers takes the tile kernels."""
+    from vr180_convert_amd import remapper
+
+    if torch.cuda.mem_get_info(0)[0] < 24 << 30:
+        pytest.skip("needs 24 GB of free device memory")
+    O = oracle_mod
+    rng = np.random.default_rng(99)
+    spec = [("equirect_enc", True), CS.EQUI]
+    t = CS.to_product(spec)
+    for (rows, pitch, ws, out) in ((2000, 2_300_000, 1504, 640), (300, 17_000_000, 400, 512)):
+        big_src = torch.empty((rows, pitch), dtype=torch.uint8, device=dev)
+        big_dst = torch.empty((out, 8_000_000 if pitch < (1 << 24) else pitch), dtype=torch.uint8, device=dev)
+        assert big_src.numel() > 1 << 32 and big_dst.numel() > 1 << 32
+        imgs = [rng.integers(0, 256, (rows, ws, 3), dtype=np.uint8) for _ in range(2)]
+        off = big_src.shape[1] - 2 * 3 * ws - 64  # the views sit at the END of the rows: byte offsets of the last rows exceed 2^32
+        srcs = []
+        for k, im in enumerate(imgs):
+            v = big_src[:, off + k * 3 * ws: off + (k + 1) * 3 * ws].unflatten(1, (ws, 3))
+            v.copy_(torch.from_numpy(im).to(dev))
+            srcs.append(v)
+        doff = big_dst.shape[1] - 2 * 3 * out - 128
+        dsts = [big_dst[:, doff + k * 3 * out: doff + (k + 1) * 3 * out].unflatten(1, (out, 3)) for k in range(2)]
+        assert srcs[1].data_ptr() + (rows - 1) * srcs[1].stride(0) - big_src.data_ptr() > 1 << 32
+        xm, ym = O.get_map(spec, radius=min(rows, ws) / 2, size_input=(rows, ws), size_output=(out, out))
+        for interp in (1, 4):
+            for d in dsts:
+                d.zero_()
+            assert V.remap_tensors(t, srcs, dsts, radius=min(rows, ws) / 2, interpolation=interp) == ["ray"]
+            assert remapper.last_launch_kinds() == ["generic"], remapper.last_launch_kinds()
+            for k in range(2):
+                want = O.remap(imgs[k], xm, ym, interp, 0, 0)
+                assert np.array_equal(dsts[k].cpu().numpy(), want), (rows, pitch, interp, k)
+        # the same units on buffers of their own: the tile kernels
+        small = [torch.from_numpy(im).to(dev) for im in imgs]
+        outs = [torch.empty((out, out, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        V.remap_tensors(t, small, outs, radius=min(rows, ws) / 2, interpolation=1)
+        assert remapper.last_launch_kinds()[0] in ("mirror", "tile"), remapper.last_launch_kinds()
+        for k in range(2):
+            assert np.array_equal(outs[k].cpu().numpy(), O.remap(imgs[k], xm, ym, 1, 0, 0)), k
+        del big_src, big_dst
+        torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------------------- fused path vs oracle
 CUTS = {
     # 1024^2 cuts of every BASELINE config (SURVEY.md 8d "Parity gate") + C1 in full
