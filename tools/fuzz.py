@@ -287,6 +287,34 @@ def lut_case(rng, dev) -> tuple[str, int]:
     return desc, bad
 
 
+def radius_case(rng, dev) -> tuple[str, int]:
+    """get_radius (transformer.py:108-140) as the device kernel against the oracle: random images with black margins, noise around the
+    threshold, every channel count, pitched views, images wider than high and the other way round, none / several rises and falls"""
+    from vr180_convert_amd.remapper import _get_radius_any
+
+    cn = int(rng.choice([1, 3, 4]))
+    h, w = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+    thr = int(rng.choice([10, 10, 1, 25, 200, 0, 255]))
+    img = rng.integers(0, 30 if rng.random() < 0.5 else 256, (h, w, cn), dtype=np.uint8)
+    if rng.random() < 0.8:  # black margins of random widths (possibly none, possibly everything)
+        a, b = sorted(int(v) for v in rng.integers(0, w + 1, 2))
+        c, d = sorted(int(v) for v in rng.integers(0, h + 1, 2))
+        img[:, :a] = 0
+        img[:, b:] = 0
+        img[:c] = 0
+        img[d:] = 0
+    t = make_view(rng, img, dev, allow_unaligned=True)
+    try:
+        want = ("value", O.get_radius(img, thr))
+    except IndexError:
+        want = ("IndexError", None)
+    try:
+        got = ("value", _get_radius_any(t, thr))
+    except IndexError:
+        got = ("IndexError", None)
+    return f"RADIUS cn={cn} size=({w},{h}) threshold={thr} want={want} got={got}", 0 if got == want else 1
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
@@ -320,8 +348,11 @@ def main() -> int:
             with open(a.trace, "w") as tf:
                 tf.write(f"seed {a.seed} case {a.only if a.only is not None else case}\n")
         try:
-            if rng.random() < a.lut:
+            r_kind = rng.random()
+            if r_kind < a.lut:
                 desc, bad = lut_case(rng, dev)
+            elif r_kind < a.lut + 0.05:
+                desc, bad = radius_case(rng, dev)
             else:
                 desc, bad = one_case(rng, dev, a.big)
         except Exception as e:  # noqa: BLE001 -- a refusal of the product (documented limits) is reported, not fatal
