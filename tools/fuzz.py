@@ -111,6 +111,7 @@ def make_view(rng, arr: np.ndarray, dev, allow_unaligned: bool):
 
 
 DUMP = [False]
+KINDS: dict = {}  # kernel family -> launch groups it served (remapper.last_launch_kinds): which kernels the run reached
 SINGULAR = [0]  # differing pixels among the ill-conditioned ones that are left out (module docstring)
 
 
@@ -197,6 +198,10 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
             kw["rotations"] = rots
         V.remap_tensors(t, srcs, dsts, radius=radius, interpolation=interp, boarder_mode=border, boarder_value=bval, **kw)
         got = [d.cpu().numpy() for d in dsts]
+    from vr180_convert_amd import remapper
+
+    for kind in remapper.last_launch_kinds():
+        KINDS[kind] = KINDS.get(kind, 0) + 1
     bad = 0
     maps = None
     sing = None
@@ -369,6 +374,7 @@ def main() -> int:
             last = time.time()
             say(f"... {n_cases} cases, {n_bad} reported, {time.time() - t0:.0f} s")
     say(f"fuzz seed {a.seed}: {n_cases} cases in {time.time() - t0:.0f} s, {n_bad} reported; {SINGULAR[0]} differing ill-conditioned pixels left out")
+    say("kernel families of the chain cases' launch groups: " + ", ".join(f"{k} x{v}" for k, v in sorted(KINDS.items())))
     return 1 if n_bad else 0
 
 
