@@ -6,7 +6,7 @@ strips, rest lists, the unit ring), cn 1 / 3 / 4, every interpolation and border
 and destination views (dword-aligned or not), per-unit rotations, apply_lr pairs; a share of the cases (--lut) runs cv2.remap alone
 (v1c_remap_lut) on random float32 maps sprinkled with NaN, infinities, 2^15 / 2^26 / 2^31-scale values and ties of the 1/32 grid.
 
-    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--lut 0.15] [--log gpurun_out/fuzz.log]
+    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--lut 0.15] [--hot 0.3] [--log gpurun_out/fuzz.log]
 
 Ill-conditioned pixels are left out and counted: where the chain amplifies a perturbation of the output position by 1e6 or more
 (measured on the oracle's fp64 map, `ill_conditioned`), the last bits of every intermediate -- they differ between glibc and the
@@ -111,6 +111,7 @@ def make_view(rng, arr: np.ndarray, dev, allow_unaligned: bool):
 
 
 DUMP = [False]
+HOT = [0.3]  # share of the chain cases drawn from the shapes the tuned kernels serve (--hot)
 KINDS: dict = {}  # kernel family -> launch groups it served (remapper.last_launch_kinds): which kernels the run reached
 SINGULAR = [0]  # differing pixels among the ill-conditioned ones that are left out (module docstring)
 
@@ -166,6 +167,42 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
         if wo * ho * n > 6e6:
             n = max(1, int(6e6 // (wo * ho)))
     use_rot = (rot_at is not None) and (not pair) and rng.random() < 0.5
+    unaligned_views = True
+    if rng.random() < HOT[0]:
+        # the shapes the tuned kernels are selected for (the free grammar above reaches them once in a hundred cases): an unrotated
+        # equirectangular -> equidistant chain (now and then with one polynomial, a zoom, or a rotate stage whose matrix the units
+        # override), rays that stay in the front hemisphere (output about square, rows pairing up about the equator), outputs of 416
+        # px and more (one table entry per lane), mostly bilinear + BORDER_CONSTANT, pairs / single images / batches / per-unit rotations
+        mid = []
+        rot_units = rng.random() < 0.3
+        if rot_units:
+            mid.append(("rot", np.eye(3).tolist()))
+        pk = rng.random()
+        if pk < 0.25:
+            mid.append(("poly", [0.0, 1.0, float(rng.uniform(-0.15, 0.08))]))
+        elif pk < 0.35:
+            mid.append(("zoom", float(rng.uniform(0.8, 1.3))))
+        spec = [("equirect_enc", True)] + mid + [("fisheye_dec", "equidistant")]
+        rot_at = 1 if rot_units else None
+        cn = int(rng.choice([3, 3, 3, 3, 1, 4]))
+        interp = int(rng.choice([1, 1, 1, 1, 1, 0, 2, 4]))
+        border = int(rng.choice([0, 0, 0, 0, 0, 1, 4, 5]))
+        ho = int(rng.integers(13, 66)) * 32 if rng.random() < 0.85 else int(rng.integers(416, 2100))
+        wo = max(1, ho + int(rng.choice([0, 0, 0, -64, -4, 4, 60, 64])) + (0 if rng.random() < 0.7 else int(rng.integers(-100, 30))))
+        if interp in (2, 4):
+            wo, ho = min(wo, 1100), min(ho, 1088)
+        hs = int(rng.integers(60, 2600))
+        ws = hs + (0 if rng.random() < 0.5 else int(rng.integers(-hs // 3, hs // 2)))
+        if rng.random() < 0.7:
+            ws = (ws + 3) & ~3  # (a width whose rows stay dword-aligned: the LDS-DMA kernels)
+        radius = float(rng.uniform(0.3, 0.62) * min(ws, hs))
+        shape = rng.random()
+        pair = (not rot_units) and shape < 0.4
+        n = 2 if pair else (1 if shape < 0.55 else int(rng.choice([2, 3, 4, 5, 8, 16, 17, 40])))
+        if not pair and wo * ho * n > 2.5e7:
+            n = max(1, int(2.5e7 // (wo * ho)))
+        use_rot = rot_units
+        unaligned_views = rng.random() < 0.15
     rots = [rand_rot(rng, False) for _ in range(n)] if use_rot else None
     # units of different source sizes behind one transformer: the map is for images[0] (remapper.py:385), every image is
     # sampled within its own bounds; a pair of per-eye transformers (remapper.py:460-473): every eye its own chain and geometry
@@ -184,7 +221,7 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
     desc = (f"spec={spec!r} cn={cn} interp={interp} border={border} bval={bval!r} out=({wo},{ho}) src=({ws},{hs}) radius={radius!r} n={n} pair={pair} "
             f"rots={use_rot}" + (f" sizes={sizes!r}" if sizes[1:] != sizes[:-1] else "") + (f" right_eye_spec={spec2!r}" if tuple_t else ""))
     t = CS.to_product(spec)
-    srcs = [make_view(rng, im, dev, allow_unaligned=True) for im in imgs]
+    srcs = [make_view(rng, im, dev, allow_unaligned=unaligned_views) for im in imgs]
     if pair:
         sbs = torch.from_numpy(np.concatenate([fill, fill], axis=1)).to(dev)
         tt = (t, CS.to_product(spec2)) if tuple_t else t
@@ -192,7 +229,7 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
                            radius=radius)
         got = [sbs[:, :wo].cpu().numpy(), sbs[:, wo:].cpu().numpy()]
     else:
-        dsts = [make_view(rng, fill.copy(), dev, allow_unaligned=True) for _ in range(n)]
+        dsts = [make_view(rng, fill.copy(), dev, allow_unaligned=unaligned_views) for _ in range(n)]
         kw = {}
         if use_rot:
             kw["rotations"] = rots
@@ -326,12 +363,14 @@ def main() -> int:
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", type=float, default=0.15, help="share of sizes drawn from 1200 - 2700")
     ap.add_argument("--lut", type=float, default=0.15, help="share of cases that fuzz cv2.remap alone (v1c_remap_lut) on random maps")
+    ap.add_argument("--hot", type=float, default=0.3, help="share of the chain cases drawn from the shapes the tuned kernels are selected for")
     ap.add_argument("--only", type=int, default=None, help="run only this case number (reproduce)")
     ap.add_argument("--log", default=None)
     ap.add_argument("--trace", default=None, help="file that always holds the number of the case being run")
     ap.add_argument("--dump", action="store_true", help="print where a mismatching unit differs")
     a = ap.parse_args()
     DUMP[0] = a.dump
+    HOT[0] = a.hot
     dev = torch.device("cuda", 0)
     log = open(a.log, "a") if a.log else None
 
