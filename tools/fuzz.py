@@ -329,6 +329,75 @@ def lut_case(rng, dev) -> tuple[str, int]:
     return desc, bad
 
 
+def api_case(rng, dev) -> tuple[str, int]:
+    """the reference's own entry points on host arrays: apply() (remapper.py:324-403: a list of images, 2-D grayscale among them,
+    radius 'auto' / 'max' / a number, the host pipeline behind it) and apply_lr() on arrays (merge=False)"""
+    spec, _ = rand_spec(rng)
+    t = CS.to_product(spec)
+    interp = int(rng.choice([1, 1, 0, 2, 4]))
+    border = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+    bval = int(rng.integers(0, 256)) if rng.random() < 0.5 else tuple(int(x) for x in rng.integers(0, 256, 3))
+    wo, ho = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+    hs, ws = int(rng.integers(8, 500)), int(rng.integers(8, 500))
+    gray2d = rng.random() < 0.2
+    cn = 1 if gray2d else int(rng.choice([3, 3, 1, 4]))
+    n = int(rng.choice([1, 2, 3, 7, 12]))
+    lr = rng.random() < 0.35
+
+    def disc():
+        im = rng.integers(40, 256, (hs, ws) if gray2d else (hs, ws, cn), dtype=np.uint8)
+        yy, xx = np.mgrid[:hs, :ws]
+        r = min(hs, ws) * float(rng.uniform(0.3, 0.49))
+        im[((xx - ws // 2) ** 2 + (yy - hs // 2) ** 2) > r * r] = 0  # black surround: radius='auto' finds an edge
+        return im
+
+    rsel = rng.random()
+    # (a 2-D image with radius='auto' raises IndexError in the reference -- get_radius indexes three axes, transformer.py:128-131 -- and here)
+    radius = "auto" if rsel < 0.35 and not gray2d else "max" if rsel < 0.7 else float(rng.uniform(0.3, 1.2) * min(hs, ws) / 2)
+
+    def masked_diff(g, w, r_used):
+        """differing bytes outside the ill-conditioned pixels (module docstring)"""
+        sing = ill_conditioned(spec, r_used, (hs, ws), (wo, ho))
+        if border in (1, 2, 3, 4):
+            xm, ym = O.get_map(spec, radius=r_used, size_input=(hs, ws), size_output=(wo, ho))
+            sing |= ~((np.abs(xm) < 2.0 ** 20) & (np.abs(ym) < 2.0 ** 20))
+        d = (g != w)
+        d = d.any(axis=2) if d.ndim == 3 else d
+        SINGULAR[0] += int((d & sing).sum())
+        return int((g != w)[~sing].sum())
+
+    desc = f"API {'apply_lr' if lr else 'apply'} spec={spec!r} cn={'2-D' if gray2d else cn} interp={interp} border={border} bval={bval!r} out=({wo},{ho}) src=({ws},{hs}) radius={radius!r} n={2 if lr else n}"
+    if lr and not gray2d and cn == 3:
+        import tempfile
+
+        from vr180_convert_amd import _io
+
+        left, right = disc(), disc()
+        with tempfile.TemporaryDirectory() as td:  # apply_lr saves (a PNG here: lossless) and returns nothing, like the reference
+            out_p = Path(td) / "sbs.png"
+            V.apply_lr(t, left_path=left, right_path=right, out_path=out_p, size_output=(wo, ho), interpolation=interp, boarder_mode=border,
+                       boarder_value=bval, radius=radius, device=dev)
+            got = _io.imread(out_p)
+        want = O.apply_lr(spec, left, right, size_output=(wo, ho), interpolation=interp, radius=radius, border_mode=border, border_value=bval)
+        got = np.asarray(got)
+        if got.shape != want.shape:
+            return desc, want.size
+        r_used = O.get_radius_smart(radius, [left, right])
+        return desc, masked_diff(got[:, :wo], want[:, :wo], r_used) + masked_diff(got[:, wo:], want[:, wo:], r_used)
+    imgs = [disc() for _ in range(n)]
+    got = V.apply(t, in_paths=imgs, size_output=(wo, ho), interpolation=interp, boarder_mode=border, boarder_value=bval, radius=radius, device=dev)
+    want = O.apply(spec, [im[..., None] if gray2d else im for im in imgs], size_output=(wo, ho), interpolation=interp, border_mode=border,
+                   border_value=bval, radius=radius)
+    bad = 0
+    r_used = O.get_radius_smart(radius, [im[..., None] if gray2d else im for im in imgs])
+    for g, w in zip(got, want):
+        g = np.asarray(g)
+        bad += masked_diff(g.reshape(w.shape), w, r_used) if g.size == w.size else w.size
+        if gray2d and g.ndim != 2:
+            bad += 1  # a 2-D image comes back 2-D (cv2.remap keeps the rank)
+    return desc, bad
+
+
 def radius_case(rng, dev) -> tuple[str, int]:
     """get_radius (transformer.py:108-140) as the device kernel against the oracle: random images with black margins, noise around the
     threshold, every channel count, pitched views, images wider than high and the other way round, none / several rises and falls"""
@@ -364,6 +433,7 @@ def main() -> int:
     ap.add_argument("--big", type=float, default=0.15, help="share of sizes drawn from 1200 - 2700")
     ap.add_argument("--lut", type=float, default=0.15, help="share of cases that fuzz cv2.remap alone (v1c_remap_lut) on random maps")
     ap.add_argument("--hot", type=float, default=0.3, help="share of the chain cases drawn from the shapes the tuned kernels are selected for")
+    ap.add_argument("--api", type=float, default=0.1, help="share of cases through apply() / apply_lr() on host arrays")
     ap.add_argument("--only", type=int, default=None, help="run only this case number (reproduce)")
     ap.add_argument("--log", default=None)
     ap.add_argument("--trace", default=None, help="file that always holds the number of the case being run")
@@ -397,6 +467,8 @@ def main() -> int:
                 desc, bad = lut_case(rng, dev)
             elif r_kind < a.lut + 0.05:
                 desc, bad = radius_case(rng, dev)
+            elif r_kind < a.lut + 0.05 + a.api:
+                desc, bad = api_case(rng, dev)
             else:
                 desc, bad = one_case(rng, dev, a.big)
         except Exception as e:  # noqa: BLE001 -- a refusal of the product (documented limits) is reported, not fatal
