@@ -238,3 +238,28 @@ def test_estimator_surface_of_the_transformers():
         return
     c = clone(T.ZoomTransformer(3.0))
     assert isinstance(c, T.ZoomTransformer) and c.scale == 3.0
+
+
+def test_the_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under vr180_convert_amd/ (Python or C++) names it, importing the package does not
+    load it, and bench.py reaches it only inside its cpu_baseline leg."""
+    import re
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    for f in list((root / "vr180_convert_amd").rglob("*.py")) + list((root / "vr180_convert_amd" / "csrc").glob("*.h*")) + \
+            list((root / "vr180_convert_amd" / "csrc").glob("*.hip")):
+        text = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle|libvr180oracle|orc_[a-z_]+\(", text, flags=re.M), f
+    code = "import sys; import vr180_convert_amd, vr180_convert_amd.remapper, vr180_convert_amd.sharding, vr180_convert_amd.cli; " \
+           "print(sorted(m for m in sys.modules if m.split('.')[0] == 'oracle'))"
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
+    assert out == "[]", out
+    bench = (root / "bench.py").read_text()
+    uses = [m.start() for m in re.finditer(r"from oracle|import oracle", bench)]
+    assert uses, "bench.py's cpu_baseline leg imports the oracle"
+    for u in uses:  # every import sits inside a function whose name says cpu_baseline / parity check
+        head = bench.rfind("\ndef ", 0, u)
+        assert re.match(r"\ndef (cpu_baseline|_cpu_baseline|parity|_parity)", bench[head:head + 40]), bench[head:head + 60]
