@@ -174,10 +174,73 @@ __device__ __forceinline__ uint32_t blend_table_cn(uint32_t a, uint32_t pitch, g
     return out;
 }
 
+// The same for TWO units that share the map (both eyes of a pair, consecutive frames of a batch): their taps sit at the same offset of
+// their box buffers and take the SAME weights, so the weight rows -- 32 / 128 B per pixel from L2, what the gray / BGRA K x K launches
+// were bound by (gray Lanczos4 pairs ran slower than BGR ones with a third of the multiplies) -- are fetched once for both.
+template <int CN, int K>
+__device__ __forceinline__ void blend_table_cn_pair(uint32_t a0, uint32_t a1, uint32_t pitch, glb_u32_ptr w, uint32_t& out0, uint32_t& out1)
+{
+    int acc0[CN], acc1[CN];
+#pragma unroll
+    for (int ch = 0; ch < CN; ch++)
+        acc0[ch] = acc1[ch] = 1 << 14;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const uint32_t ar0 = a0 + (uint32_t)r * pitch, ar1 = a1 + (uint32_t)r * pitch;
+        const lds_u32_ptr p0 = (lds_u32_ptr)(uintptr_t)(ar0 & ~3u), p1 = (lds_u32_ptr)(uintptr_t)(ar1 & ~3u);
+        uint32_t wr[K / 2];
+#pragma unroll
+        for (int q = 0; q < K / 2; q++)
+            wr[q] = w[r * (K / 2) + q];
+        if constexpr (CN == 4) {
+            uint32_t d0[K], d1[K];
+#pragma unroll
+            for (int q = 0; q < K; q++)
+                d0[q] = p0[q], d1[q] = p1[q];
+#pragma unroll
+            for (int q = 0; q < K / 2; q++) {
+                const short2v ww = __builtin_bit_cast(short2v, wr[q]);
+                acc0[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(d0[2 * q + 1], d0[2 * q], 0x0c040c00u)), ww, acc0[0], false);
+                acc0[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(d0[2 * q + 1], d0[2 * q], 0x0c050c01u)), ww, acc0[1], false);
+                acc0[2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(d0[2 * q + 1], d0[2 * q], 0x0c060c02u)), ww, acc0[2], false);
+                acc0[3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(d0[2 * q + 1], d0[2 * q], 0x0c070c03u)), ww, acc0[3], false);
+                acc1[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(d1[2 * q + 1], d1[2 * q], 0x0c040c00u)), ww, acc1[0], false);
+                acc1[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(d1[2 * q + 1], d1[2 * q], 0x0c050c01u)), ww, acc1[1], false);
+                acc1[2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(d1[2 * q + 1], d1[2 * q], 0x0c060c02u)), ww, acc1[2], false);
+                acc1[3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(d1[2 * q + 1], d1[2 * q], 0x0c070c03u)), ww, acc1[3], false);
+            }
+        } else {
+            uint32_t d0[K / 4 + 1], d1[K / 4 + 1], b0[K / 4], b1[K / 4];
+#pragma unroll
+            for (int q = 0; q < K / 4 + 1; q++)
+                d0[q] = p0[q], d1[q] = p1[q];
+#pragma unroll
+            for (int q = 0; q < K / 4; q++) {
+                b0[q] = __builtin_amdgcn_alignbyte(d0[q + 1], d0[q], ar0);  // bytes 4 q .. 4 q + 3 of the row
+                b1[q] = __builtin_amdgcn_alignbyte(d1[q + 1], d1[q], ar1);
+            }
+#pragma unroll
+            for (int q = 0; q < K / 2; q++) {
+                const short2v ww = __builtin_bit_cast(short2v, wr[q]);
+                const uint32_t sel = (q & 1) ? 0x0c030c02u : 0x0c010c00u;
+                acc0[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, b0[q / 2], sel)), ww, acc0[0], false);
+                acc1[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, b1[q / 2], sel)), ww, acc1[0], false);
+            }
+        }
+    }
+    out0 = out1 = 0;
+#pragma unroll
+    for (int ch = 0; ch < CN; ch++) {
+        out0 |= fixpt_u8(acc0[ch]) << (8 * ch);
+        out1 |= fixpt_u8(acc1[ch]) << (8 * ch);
+    }
+}
+
 // K = 2: bilinear, or nearest with NN = 1 (lane_coords<..., NN>: fixed point 32 * cvRound(x), fractions zero, for which the blend returns its
 // top-left tap exactly; every border mode but TRANSPARENT, whose skip rule differs from the bilinear one); K = 4 / 8: bicubic / Lanczos4
 // (blend_table_cn; every border mode but TRANSPARENT).
-// BOXES = 1: plan-time boxes, one workgroup per tile walking all units of the launch (they share the map).
+// BOXES = 1: plan-time boxes, one workgroup per tile walking all units of the launch (they share the map) -- one at a time with the
+// next unit's box in flight (K = 2), two at a time against one fetch of the weight rows (K = 4 / 8: blend_table_cn_pair).
 // BOXES = 0 (ROT = 1): units that override the rotation -- one unit per workgroup (blockIdx.z), coordinates with the unit's matrix,
 // the bounding box of its inside pixels reduced in the kernel (reduce_box), then the same requests, gather and patch path.
 template <int VAR_W, int ROT, int CN, int NN = 0, int K = 2, int BOXES = 1>
@@ -226,8 +289,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int upr = cn_units_per_row<CN>(b.cpr);
     const RawLanes m = raw_lanes_upr(max(upr, 1), lane);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_ptr)dyn_box, buf_bytes = (uint32_t)kb * 1024u;
-    if (fits)  // the first unit's box flies behind the coordinates
+    constexpr bool kPairs = K > 2 && BOXES;  // K x K taps: the units in pairs, both boxes resident (see the unit loop)
+    if (fits) {  // the first unit's box flies behind the coordinates (K x K: the first two units' boxes)
         raw_box_dma<CN>(b, m, U[u0].src, (uint32_t)U[u0].src_pitch, lane, wave, lds0);
+        if (kPairs && u0 + 1 < n_units)
+            raw_box_dma<CN>(b, m, U[u0 + 1].src, (uint32_t)U[u0 + 1].src_pitch, lane, wave, lds0 + buf_bytes);
+    }
     if (BOXES) {
         const bool tab_lds = (b.nidx > 0) & (b.nidx <= kTabSlice);
         const bool mpoly = (b.interior & 2) != 0;
@@ -254,6 +321,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             W[k] = blend_weights(L.sx[k], L.sy[k]);
         else
             we[k] = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
+    }
+    if constexpr (kPairs) {
+        // pixels the boxes did not serve (footprints leaving the source, a box beyond the buffers), then the store of unit u
+        // (a lambda of this block only: shared with the loop below it cost the bilinear instantiations 14 VGPRs and a wave per SIMD)
+        auto patch_and_store_cn = [&](int u, uint32_t (&pix)[kPX], unsigned done) {
+            const unsigned slow = L.ok & ~done;
+            unsigned skip = 0;  // BORDER_TRANSPARENT: the destination keeps its bytes
+            if (slow) {
+                const Image im{U[u].src, U[u].src_pitch, g.src_h, g.src_w};
+                const Geom gg = geom_copy(g);
+    #pragma unroll 1
+                for (int k = 0; k < kPX; k++) {
+                    if (slow & (1u << k)) {
+                        const int fsx = k == 0 ? L.sx[0] : k == 1 ? L.sx[1] : k == 2 ? L.sx[2] : L.sx[3];
+                        const int fsy = k == 0 ? L.sy[0] : k == 1 ? L.sy[1] : k == 2 ? L.sy[2] : L.sy[3];
+                        uint32_t r;
+                        if constexpr (K == 2) {
+                            uint8_t px[4] = {0, 0, 0, 0};
+                            const bool st = sample_linear_t<CN>(im, gg, taps_from_fixed(fsx, fsy), px);
+                            r = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
+                            skip |= (st ? 0u : 1u) << k;
+                        } else {
+                            r = slow_pixel_table_cn<CN, K>(im.p, im.pitch, im.h, im.w, gg.border,
+                                                           (uint32_t)gg.cval[0] | ((uint32_t)gg.cval[1] << 8) | ((uint32_t)gg.cval[2] << 16) | ((uint32_t)gg.cval[3] << 24),
+                                                           c.itab, fsx, fsy);
+                        }
+    #pragma unroll
+                        for (int q = 0; q < kPX; q++)
+                            pix[q] = q == k ? r : pix[q];
+                    }
+                }
+            }
+            if (t.active) {
+                uint8_t* drow = U[u].dst + (__umul24((uint32_t)t.j, (uint32_t)U[u].dst_pitch) + (uint32_t)t.x0 * (uint32_t)CN);
+                store_cn<CN>(drow, pix, L.ok & ~skip, dst_rows_dword_aligned(U, u));
+            }
+        };
+        // K x K taps: units u, u + 1 from the two buffers against ONE fetch of each pixel's weight rows.  Per pair: (everyone is done
+        // with the previous pair's buffers -> ) requests of both boxes -> all landed -> gather.  No box is in flight during a gather;
+        // the other workgroups of the CU cover that latency (64 / 16 taps per pixel keep a workgroup busy for long).
+        for (int u = u0; u < n_units; u += 2) {
+            const bool two = u + 1 < n_units;
+            if (incomplete)
+                if (uint32_t* flags = a.tile_flags) {
+                    flags[t.flag_tile + u * t.flag_stride] = 1;
+                    if (two)
+                        flags[t.flag_tile + (u + 1) * t.flag_stride] = 1;
+                }
+            uint32_t p0[kPX] = {0u, 0u, 0u, 0u}, p1[kPX] = {0u, 0u, 0u, 0u};
+            unsigned done = 0;
+            if (fits) {
+                if (u > u0) {
+                    wait_vm_barrier_imm<0>();  // every wave has its taps of the previous pair (their values went into its stores)
+                    raw_box_dma<CN>(b, m, U[u].src, (uint32_t)U[u].src_pitch, lane, wave, lds0);
+                    if (two)
+                        raw_box_dma<CN>(b, m, U[u + 1].src, (uint32_t)U[u + 1].src_pitch, lane, wave, lds0 + buf_bytes);
+                }
+                wait_vm_barrier_imm<0>();
+#pragma unroll 1
+                for (int k = 0; k < kPX; k++) {
+                    const uint32_t tk = k == 0 ? ta[0] : k == 1 ? ta[1] : k == 2 ? ta[2] : ta[3];
+                    const uint32_t ek = k == 0 ? we[0] : k == 1 ? we[1] : k == 2 ? we[2] : we[3];
+                    uint32_t r0, r1 = 0u;
+                    if (two)
+                        blend_table_cn_pair<CN, K>(tk + lds0, tk + lds0 + buf_bytes, lpitch, wtab + ek * (K * K / 2), r0, r1);
+                    else
+                        r0 = blend_table_cn<CN, K>(tk + lds0, lpitch, wtab + ek * (K * K / 2));
+#pragma unroll
+                    for (int q = 0; q < kPX; q++)
+                        p0[q] = q == k ? r0 : p0[q], p1[q] = q == k ? r1 : p1[q];
+                }
+                done = L.inside;
+            }
+            patch_and_store_cn(u, p0, done);
+            if (two)
+                patch_and_store_cn(u + 1, p1, done);
+        }
+        return;
     }
     for (int u = u0; u < n_units; u++) {
         if (incomplete)
