@@ -384,6 +384,22 @@ def api_case(rng, dev) -> tuple[str, int]:
             return desc, want.size
         r_used = O.get_radius_smart(radius, [left, right])
         return desc, masked_diff(got[:, :wo], want[:, :wo], r_used) + masked_diff(got[:, wo:], want[:, wo:], r_used)
+    if (not gray2d) and cn == 3 and rng.random() < 0.25:
+        # remap_sharded: apply_lr over a batch of frames by worker threads (one per listed device -- the one card several times)
+        frames = [(disc(), disc()) if rng.random() < 0.5 else np.concatenate([disc(), disc()], axis=1) for _ in range(n)]
+        ndev = int(rng.choice([1, 2, 3, 5]))
+        rad = radius if not isinstance(radius, str) or radius == "max" else float(min(hs, ws) * 0.45)
+        got = V.remap_sharded(t, frames, size_output=(wo, ho), interpolation=interp, boarder_mode=border, boarder_value=bval, radius=rad,
+                              devices=[dev.index] * ndev)
+        bad = 0
+        for f, g in zip(frames, got):
+            l_, r_ = (f if isinstance(f, tuple) else (f[:, :ws], f[:, ws:]))
+            r_used = O.get_radius_smart(rad, [l_, r_])
+            want = O.apply_lr(spec, np.ascontiguousarray(l_), np.ascontiguousarray(r_), size_output=(wo, ho), interpolation=interp, radius=rad,
+                              border_mode=border, border_value=bval)
+            g = np.asarray(g)
+            bad += (masked_diff(g[:, :wo], want[:, :wo], r_used) + masked_diff(g[:, wo:], want[:, wo:], r_used)) if g.shape == want.shape else want.size
+        return desc.replace("API apply", f"API remap_sharded x{ndev}"), bad
     imgs = [disc() for _ in range(n)]
     got = V.apply(t, in_paths=imgs, size_output=(wo, ho), interpolation=interp, boarder_mode=border, boarder_value=bval, radius=radius, device=dev)
     want = O.apply(spec, [im[..., None] if gray2d else im for im in imgs], size_output=(wo, ho), interpolation=interp, border_mode=border,
