@@ -97,6 +97,10 @@ for rep in range(REPS):
     print("BGRA 1024 x 7 units:", cn_batch(1024, 4, 7, 1000), "bad of 1000", flush=True)
     print("gray 1024 x 4 units NEAREST:", cn_batch(1024, 1, 4, 500, interp=0), "bad of 500", flush=True)
     print("BGRA 1024 x 3 units Lanczos4:", cn_batch(1024, 4, 3, 300, interp=4), "bad of 300", flush=True)
+    # (K x K taps take the units two at a time, both boxes resident, one fetch of the weight rows: pairs, an odd count, many)
+    print("gray 1024 x 2 units Lanczos4:", cn_batch(1024, 1, 2, 500, interp=4), "bad of 500", flush=True)
+    print("gray 1024 x 7 units bicubic:", cn_batch(1024, 1, 7, 300, interp=2), "bad of 300", flush=True)
+    print("BGRA 1024 x 16 units bicubic:", cn_batch(1024, 4, 16, 150, interp=2), "bad of 150", flush=True)
     print("BGRA 1024 x 6 units, a rotation each:", cn_batch(1024, 4, 6, 500, rot=True), "bad of 500", flush=True)
     print("single images 2048:", single(2048, 2000), "bad of 2000", flush=True)
     print("rotated units 1440 x 16 frames (32 units: one launch through the unit ring):", rotated(1440, 16, 300), "bad of 300", flush=True)
