@@ -250,11 +250,12 @@ def test_tile_kernels_other_border_modes(V, oracle_mod, dev, interp, border):
 
 
 def test_border_transparent_bilinear_through_the_tile_kernels(V, oracle_mod, dev):
-    """BORDER_TRANSPARENT with INTER_LINEAR runs the tile kernels since round 3: remapBilinear leaves every pixel whose 2 x 2
-    footprint is not fully inside the source untouched -- exactly the pixels the tile kernels' patch path handles one by one, now
-    with a per-pixel store mask.  Destinations start from a pattern (not zeros): skipped pixels must keep it.  Pairs, a batch,
-    per-unit rotations, zoomed-out chains with a wide skipped rim; NEAREST / Lanczos4 with the same border stay on the generic
-    kernel and must still agree."""
+    """BORDER_TRANSPARENT runs the tile kernels (INTER_LINEAR since round 3, bicubic / Lanczos4 since round 4): remapBilinear leaves
+    every pixel whose 2 x 2 footprint is not fully inside the source untouched, remapBicubic / remapLanczos4 every pixel whose centre
+    tap is outside (the others reflect their missing taps) -- exactly the pixels the tile kernels' patch path handles one by one, with
+    a per-pixel store mask.  Destinations start from a pattern (not zeros): skipped pixels must keep it.  Pairs, a batch, per-unit
+    rotations, zoomed-out chains with a wide skipped rim; NEAREST with the same border stays on the generic kernel and must still agree."""
+    from vr180_convert_amd import remapper
     from vr180_convert_amd import transformer as T
     from vr180_convert_amd.synth import noise_disc
 
@@ -267,13 +268,15 @@ def test_border_transparent_bilinear_through_the_tile_kernels(V, oracle_mod, dev
     fill = np.full((288, 352, 3), (11, 22, 33), np.uint8)
     for spec in ([("equirect_enc", True), ("zoom", 0.55), CS.EQUI], [("equirect_enc", True), ("poly", [0, 1, -0.1]), ("zoom", 0.7), CS.EQUI],
                  [("equirect_enc", True), ("rot", CS.ry(0.4)), ("zoom", 0.8), CS.EQUI]):
-        for interp in (1, 0, 4):
+        for interp in (1, 0, 4, 2):
             xm, ym = O.get_map(spec, radius=n / 2, size_input=(n, n), size_output=(352, 288))
             want = [O.remap(im, xm, ym, interp, 5, 0, dst=fill.copy()) for im in imgs]
             assert any((w == fill).all(axis=-1).any() for w in want) and any((w != fill).any() for w in want)
             for group in (srcs[:2], srcs):  # a pair, a batch
                 dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in group]
                 assert V.remap_tensors(CS.to_product(spec), group, dsts, radius=n / 2, interpolation=interp, boarder_mode=5) == ["ray"]
+                kind = remapper.last_launch_kinds()[0].split("+")[0]
+                assert kind == ("generic" if interp == 0 else kind) and (interp == 0 or kind in ("tile", "batch", "mirror")), (kind, interp)
                 for k, d in enumerate(dsts):
                     got = d.cpu().numpy()
                     assert np.array_equal(got, want[k]), (spec, interp, len(group), k, int((got != want[k]).sum()))
@@ -330,7 +333,7 @@ def test_nearest_through_the_tile_kernels(V, oracle_mod, dev):
 def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev, interp):
     """Grayscale and BGRA sources (cv2.remap takes whatever array the caller passes, remapper.py:388-398) run k_ray_lin_cn: INTER_LINEAR
     and (round 4) INTER_NEAREST, INTER_CUBIC, INTER_LANCZOS4: plain and rotated chains, every border mode (TRANSPARENT over a pre-filled
-    destination: bilinear in the tile kernel, the others in the generic one), batches of 1 - 5 units sharing the map, units with a
+    destination: NEAREST in the generic kernel, the others in the tile kernel), batches of 1 - 5 units sharing the map, units with a
     rotation of their own (boxes reduced in the kernel),
     odd output sizes, sources that are pitched views, a radius larger than the source (rays leaving it) -- every byte against the oracle."""
     from vr180_convert_amd.synth import noise_disc
@@ -364,7 +367,7 @@ def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev, i
                 assert modes == ["ray"], modes
                 kinds = remapper.last_launch_kinds()
                 if min(wo, ho) >= big and si < 2:  # (si = 2: the rotation takes rays into the back hemisphere -> fix-up pass -> generic)
-                    assert kinds == (["generic"] if border == 5 and interp != 1 else ["cn"]), (kinds, cn, si, border)
+                    assert kinds == (["generic"] if border == 5 and interp == 0 else ["cn"]), (kinds, cn, si, border)
                 seen.update(kinds)
                 xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
                 for k in range(n):

@@ -80,17 +80,24 @@ __device__ __forceinline__ void store_cn(uint8_t* drow, const uint32_t (&pix)[kP
     }
 }
 
-// slow_pixel_table3_t for CN = 1 / 4 channels: the rare pixel whose K x K footprint leaves the source (border rules; BORDER_TRANSPARENT
-// never comes here), loops rolled -- a small register footprint, no local arrays (sample_table<CN, K> of v1c_core.hpp keeps its tap
+// slow_pixel_table3_t for CN = 1 / 4 channels: the rare pixel whose K x K footprint leaves the source (border rules; BORDER_TRANSPARENT:
+// `skip` when the centre tap is outside), loops rolled -- a small register footprint, no local arrays (sample_table<CN, K> of v1c_core.hpp keeps its tap
 // columns in one: scratch)
 template <int CN, int K>
-__device__ __noinline__ uint32_t slow_pixel_table_cn(const uint8_t* src, int64_t pitch, int h, int w, int border, uint32_t cval, const short* itab,
+// Returns the pixel in the low dword; bit 32: leave the destination untouched.  (By value: a reference parameter of a non-inlined
+// function is a stack slot -- scratch memory for the whole kernel.)
+__device__ __noinline__ uint64_t slow_pixel_table_cn(const uint8_t* src, int64_t pitch, int h, int w, int border, uint32_t cval, const short* itab,
                                                      int fsx, int fsy)
 {
     const Taps t = taps_from_fixed(fsx, fsy);
     const short* __restrict__ wt = itab + (size_t)(t.fy * 32 + t.fx) * (K * K);
     constexpr int off = K / 2 - 1;
     const int sx = t.ix - off, sy = t.iy - off;
+    if (border == V1C_BORDER_TRANSPARENT) {  // centre tap outside the source: the destination keeps its bytes; else REFLECT_101
+        if ((unsigned)t.ix >= (unsigned)w || (unsigned)t.iy >= (unsigned)h)
+            return 1ull << 32;
+        border = V1C_BORDER_REFLECT_101;
+    }
     if (border == V1C_BORDER_CONSTANT && (sx >= w || sx + K <= 0 || sy >= h || sy + K <= 0))  // footprint entirely outside
         return CN == 1 ? (cval & 255u) : cval;
     int acc[CN];
@@ -343,9 +350,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                             r = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
                             skip |= (st ? 0u : 1u) << k;
                         } else {
-                            r = slow_pixel_table_cn<CN, K>(im.p, im.pitch, im.h, im.w, gg.border,
-                                                           (uint32_t)gg.cval[0] | ((uint32_t)gg.cval[1] << 8) | ((uint32_t)gg.cval[2] << 16) | ((uint32_t)gg.cval[3] << 24),
-                                                           c.itab, fsx, fsy);
+                            const uint64_t rr = slow_pixel_table_cn<CN, K>(im.p, im.pitch, im.h, im.w, gg.border,
+                                                                           (uint32_t)gg.cval[0] | ((uint32_t)gg.cval[1] << 8) | ((uint32_t)gg.cval[2] << 16) | ((uint32_t)gg.cval[3] << 24),
+                                                                           c.itab, fsx, fsy);
+                            r = (uint32_t)rr;
+                            skip |= (uint32_t)(rr >> 32) << k;
                         }
     #pragma unroll
                         for (int q = 0; q < kPX; q++)
@@ -448,9 +457,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         r = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
                         skip |= (st ? 0u : 1u) << k;
                     } else {
-                        r = slow_pixel_table_cn<CN, K>(im.p, im.pitch, im.h, im.w, gg.border,
-                                                       (uint32_t)gg.cval[0] | ((uint32_t)gg.cval[1] << 8) | ((uint32_t)gg.cval[2] << 16) | ((uint32_t)gg.cval[3] << 24),
-                                                       c.itab, fsx, fsy);
+                        const uint64_t rr = slow_pixel_table_cn<CN, K>(im.p, im.pitch, im.h, im.w, gg.border,
+                                                                       (uint32_t)gg.cval[0] | ((uint32_t)gg.cval[1] << 8) | ((uint32_t)gg.cval[2] << 16) | ((uint32_t)gg.cval[3] << 24),
+                                                                       c.itab, fsx, fsy);
+                        r = (uint32_t)rr;
+                        skip |= (uint32_t)(rr >> 32) << k;
                     }
 #pragma unroll
                     for (int q = 0; q < kPX; q++)
@@ -499,7 +510,9 @@ hipError_t launch_put_units(DevUnit* dst, const DevUnit* host, int n, hipStream_
 // k_ray_lin_cn: grayscale / BGRA; bilinear with every border mode, nearest / bicubic / Lanczos4 with every border mode but TRANSPARENT
 bool cn_kernel_supports(const Geom& g)
 {
-    return (g.cn == 1 || g.cn == 4) && taps_of(g.interp) != 0 && (g.interp == V1C_INTER_LINEAR || g.border != V1C_BORDER_TRANSPARENT) &&
+    // (INTER_NEAREST + BORDER_TRANSPARENT stays with the generic kernel: remapNearest skips by the pixel itself, the NN form here samples
+    //  through the bilinear footprint)
+    return (g.cn == 1 || g.cn == 4) && taps_of(g.interp) != 0 && (g.interp != V1C_INTER_NEAREST || g.border != V1C_BORDER_TRANSPARENT) &&
            g.src_w >= 3 && g.src_h >= 2;
 }
 

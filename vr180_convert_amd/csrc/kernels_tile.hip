@@ -419,10 +419,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
 
 bool tile_kernel_supports(const Geom& g)
 {
-    // every border mode (the border only matters to pixels whose footprint leaves the source, and those take the generic
-    // samplers) -- BORDER_TRANSPARENT for INTER_LINEAR only: its skipped pixels (remapBilinear: the 2 x 2 footprint not fully inside)
-    // are what the bilinear patch path leaves unstored; the NEAREST / bicubic / Lanczos4 skip rules differ and stay generic
-    return g.cn == 3 && (g.border != V1C_BORDER_TRANSPARENT || g.interp == V1C_INTER_LINEAR) && taps_of(g.interp) != 0 && g.src_w >= 3 &&
+    // every border mode (the border only matters to pixels whose footprint leaves the source, and those take the per-pixel samplers
+    // of the patch path) -- BORDER_TRANSPARENT with the skip rule of the interpolation: remapBilinear leaves a pixel untouched when its
+    // 2 x 2 footprint is not fully inside, remapBicubic / remapLanczos4 when its centre tap is outside (the patch path's store mask);
+    // remapNearest skips by the pixel itself, which the NEAREST form here (the bilinear footprint with zero fractions) does not express:
+    // that one combination stays with the generic kernel
+    return g.cn == 3 && (g.border != V1C_BORDER_TRANSPARENT || g.interp != V1C_INTER_NEAREST) && taps_of(g.interp) != 0 && g.src_w >= 3 &&
            g.src_h >= 2;
 }
 

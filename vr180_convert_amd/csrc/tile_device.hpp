@@ -881,6 +881,13 @@ __device__ __noinline__ uint32_t slow_pixel_table3_t(const uint8_t* src, int64_t
     const short* __restrict__ wt = itab + (size_t)(t.fy * 32 + t.fx) * (K * K);
     constexpr int off = K / 2 - 1;
     const int sx = t.ix - off, sy = t.iy - off;
+    if (border == V1C_BORDER_TRANSPARENT) {
+        // remapBicubic / remapLanczos4: a pixel whose centre tap lies outside the source keeps the destination's bytes (bit 24 of the
+        // result, as slow_pixel_linear3_t reports it); the others take their missing taps by BORDER_REFLECT_101
+        if ((unsigned)t.ix >= (unsigned)w || (unsigned)t.iy >= (unsigned)h)
+            return 1u << 24;
+        border = V1C_BORDER_REFLECT_101;
+    }
     if (border == V1C_BORDER_CONSTANT && (sx >= w || sx + K <= 0 || sy >= h || sy + K <= 0))  // footprint entirely outside
         return cval_bgr & 0xffffffu;
     int a0 = 1 << 14, a1 = 1 << 14, a2 = 1 << 14;
@@ -1021,7 +1028,7 @@ __device__ __forceinline__ void patch_and_store(ctx_cref c, units_cptr U, int z,
 {
     geom_cref g = c.g;
     const unsigned slow = L.ok & ~done;
-    unsigned skip = 0;  // BORDER_TRANSPARENT (bilinear): pixels whose 2 x 2 footprint leaves the source keep the destination's bytes
+    unsigned skip = 0;  // BORDER_TRANSPARENT: pixels the sampler leaves untouched (bilinear: 2 x 2 footprint not inside; K x K: centre tap outside)
     if (slow) {
         if (K == 2) {
             // one inlined copy in a rolled loop (a call would pin every live value above the 40
@@ -1044,9 +1051,13 @@ __device__ __forceinline__ void patch_and_store(ctx_cref c, units_cptr U, int z,
                 if (slow & (1u << k))
                     // (float)sx / 32 re-quantises to sx while |sx| < 2^24; beyond that the footprint is
                     // outside the source either way (saturated short coordinates)
-                    pix[k] = slow_pixel_table3_t<K>(src, U[z].src_pitch, g.src_h, g.src_w, g.border,
-                                                    (uint32_t)g.cval[0] | ((uint32_t)g.cval[1] << 8) | ((uint32_t)g.cval[2] << 16), c.itab,
-                                                    (float)L.sx[k] * 0.03125f, (float)L.sy[k] * 0.03125f);
+                {
+                    const uint32_t r = slow_pixel_table3_t<K>(src, U[z].src_pitch, g.src_h, g.src_w, g.border,
+                                                              (uint32_t)g.cval[0] | ((uint32_t)g.cval[1] << 8) | ((uint32_t)g.cval[2] << 16), c.itab,
+                                                              (float)L.sx[k] * 0.03125f, (float)L.sy[k] * 0.03125f);
+                    skip |= (r >> 24) << k;  // (BORDER_TRANSPARENT: centre tap outside the source)
+                    pix[k] = r & 0xffffffu;
+                }
         }
     }
     if (!t.active)
