@@ -324,6 +324,64 @@ static int plan_common(v1c_plan* p, int device, int src_h, int src_w, int dst_h,
     return V1C_OK;
 }
 
+// The fitted radial tables depend on the chain's radial stages and the interval count only -- not on radius, image sizes, rotation or
+// pixel format -- and fitting them (long double evaluation + validation of up to 1 024 intervals, twice for a w-table chain, plus the
+// m-polynomial fit) is most of a plan's creation time.  A caller whose radius changes from image to image (radius="auto", the
+// reference's default, remapper.py:62-90) creates a plan per image: the fits are kept, the 16 most recently used.
+namespace {
+struct FitKey {
+    std::string ops;  // the radial stages, byte for byte
+    int n_int;
+    bool operator==(const FitKey& o) const { return n_int == o.n_int && ops == o.ops; }
+};
+struct FitEntry {
+    FitKey key;
+    std::shared_ptr<const RadialTable> table;
+    std::shared_ptr<const MPolyTable> mpoly;  // (fitted on demand)
+};
+std::mutex g_fit_mu;
+std::list<FitEntry> g_fits;  // front = most recently used
+
+FitKey fit_key(const std::vector<v1c_op>& radial, int n_int)
+{
+    FitKey k;
+    k.n_int = n_int;
+    if (!radial.empty())
+        k.ops.assign((const char*)radial.data(), radial.size() * sizeof(v1c_op));
+    return k;
+}
+
+// the entry of `key`, moved to the front (created by `make` when missing); g_fit_mu held by the caller
+template <typename Make>
+FitEntry& fit_entry(const FitKey& key, Make make)
+{
+    for (auto it = g_fits.begin(); it != g_fits.end(); ++it)
+        if (it->key == key) {
+            g_fits.splice(g_fits.begin(), g_fits, it);
+            return g_fits.front();
+        }
+    g_fits.push_front(FitEntry{key, make(), nullptr});
+    while (g_fits.size() > 16)
+        g_fits.pop_back();
+    return g_fits.front();
+}
+}  // namespace
+
+static RadialTable cached_radial_table(const std::vector<v1c_op>& radial, int n_int)
+{
+    std::lock_guard<std::mutex> lk(g_fit_mu);
+    return *fit_entry(fit_key(radial, n_int), [&] { return std::make_shared<const RadialTable>(build_radial_table(radial, n_int)); }).table;
+}
+
+static MPolyTable cached_mpoly_table(const std::vector<v1c_op>& radial, const RadialTable& table)
+{
+    std::lock_guard<std::mutex> lk(g_fit_mu);
+    FitEntry& e = fit_entry(fit_key(radial, table.n_int), [&] { return std::make_shared<const RadialTable>(table); });
+    if (!e.mpoly)
+        e.mpoly = std::make_shared<const MPolyTable>(fit_mpoly_table(radial, table));
+    return *e.mpoly;
+}
+
 extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chain, int src_h, int src_w, int dst_h,
                                int dst_w, int cn, int interp, int border_mode, const uint8_t border_val[4])
 {
@@ -380,7 +438,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
     if (p->ana.ok) {
         // NormalizeTransformer + lon = x * pi/2: adjacent output pixels' rays are <= pi / s apart
         p->ray_step = 3.14159265358979323846 / p->ana.norm_s;
-        p->table = build_radial_table(p->ana.radial, table_intervals_for(p->ray_step));
+        p->table = cached_radial_table(p->ana.radial, table_intervals_for(p->ray_step));
         if (ray_table_usable(p->table)) {
             p->mode = MODE_RAY;
             const RayAnalysis& a = p->ana;
@@ -425,7 +483,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             if (p->plan_shared_entry && !p->disable_shared_entry && !p->disable_mpoly) {
                 const double reach = a.has_rot ? rotated_reach(a.rot) : ht.m_reach;
                 const int lv = shared_entry_level(p->table, p->ray_step);
-                const MPolyTable mp = fit_mpoly_table(p->ana.radial, p->table);
+                const MPolyTable mp = cached_mpoly_table(p->ana.radial, p->table);
                 const int first = lv > 0 ? mpoly_first_ok(mp, p->table, reach, lv) : r.n_int;
                 if (first < r.n_int / 2) {  // worth a second table: most of the image qualifies
                     if ((rc = upload(p, mp.coef, &r.radial_m))) {
