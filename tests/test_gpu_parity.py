@@ -254,7 +254,7 @@ def test_border_transparent_bilinear_through_the_tile_kernels(V, oracle_mod, dev
     every pixel whose 2 x 2 footprint is not fully inside the source untouched, remapBicubic / remapLanczos4 every pixel whose centre
     tap is outside (the others reflect their missing taps) -- exactly the pixels the tile kernels' patch path handles one by one, with
     a per-pixel store mask.  Destinations start from a pattern (not zeros): skipped pixels must keep it.  Pairs, a batch, per-unit
-    rotations, zoomed-out chains with a wide skipped rim; NEAREST with the same border stays on the generic kernel and must still agree."""
+    rotations, zoomed-out chains with a wide skipped rim; NEAREST (remapNearest: the pixel itself outside) through the NN form's patch path."""
     from vr180_convert_amd import remapper
     from vr180_convert_amd import transformer as T
     from vr180_convert_amd.synth import noise_disc
@@ -276,7 +276,7 @@ def test_border_transparent_bilinear_through_the_tile_kernels(V, oracle_mod, dev
                 dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in group]
                 assert V.remap_tensors(CS.to_product(spec), group, dsts, radius=n / 2, interpolation=interp, boarder_mode=5) == ["ray"]
                 kind = remapper.last_launch_kinds()[0].split("+")[0]
-                assert kind == ("generic" if interp == 0 else kind) and (interp == 0 or kind in ("tile", "batch", "mirror")), (kind, interp)
+                assert kind in ("tile", "batch", "mirror"), (kind, interp)
                 for k, d in enumerate(dsts):
                     got = d.cpu().numpy()
                     assert np.array_equal(got, want[k]), (spec, interp, len(group), k, int((got != want[k]).sum()))
@@ -333,7 +333,7 @@ def test_nearest_through_the_tile_kernels(V, oracle_mod, dev):
 def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev, interp):
     """Grayscale and BGRA sources (cv2.remap takes whatever array the caller passes, remapper.py:388-398) run k_ray_lin_cn: INTER_LINEAR
     and (round 4) INTER_NEAREST, INTER_CUBIC, INTER_LANCZOS4: plain and rotated chains, every border mode (TRANSPARENT over a pre-filled
-    destination: NEAREST in the generic kernel, the others in the tile kernel), batches of 1 - 5 units sharing the map, units with a
+    destination, each interpolation's own skip rule), batches of 1 - 5 units sharing the map, units with a
     rotation of their own (boxes reduced in the kernel),
     odd output sizes, sources that are pitched views, a radius larger than the source (rays leaving it) -- every byte against the oracle."""
     from vr180_convert_amd.synth import noise_disc
@@ -367,7 +367,7 @@ def test_gray_and_bgra_bilinear_through_the_cn_tile_kernel(V, oracle_mod, dev, i
                 assert modes == ["ray"], modes
                 kinds = remapper.last_launch_kinds()
                 if min(wo, ho) >= big and si < 2:  # (si = 2: the rotation takes rays into the back hemisphere -> fix-up pass -> generic)
-                    assert kinds == (["generic"] if border == 5 and interp == 0 else ["cn"]), (kinds, cn, si, border)
+                    assert kinds == ["cn"], (kinds, cn, si, border)
                 seen.update(kinds)
                 xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
                 for k in range(n):

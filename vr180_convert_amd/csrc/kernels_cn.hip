@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     uint32_t r;
                     if constexpr (K == 2) {
                         uint8_t px[4] = {0, 0, 0, 0};
-                        const bool st = sample_linear_t<CN>(im, gg, taps_from_fixed(fsx, fsy), px);
+                        // (NN: remapNearest's border rules -- TRANSPARENT skips by the pixel itself, not by the bilinear footprint)
+                        const bool st = NN ? sample_nearest<CN>(im, gg, (float)(fsx >> 5), (float)(fsy >> 5), px)
+                                           : sample_linear_t<CN>(im, gg, taps_from_fixed(fsx, fsy), px);
                         r = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
                         skip |= (st ? 0u : 1u) << k;
                     } else {
@@ -510,9 +512,7 @@ hipError_t launch_put_units(DevUnit* dst, const DevUnit* host, int n, hipStream_
 // k_ray_lin_cn: grayscale / BGRA; bilinear with every border mode, nearest / bicubic / Lanczos4 with every border mode but TRANSPARENT
 bool cn_kernel_supports(const Geom& g)
 {
-    // (INTER_NEAREST + BORDER_TRANSPARENT stays with the generic kernel: remapNearest skips by the pixel itself, the NN form here samples
-    //  through the bilinear footprint)
-    return (g.cn == 1 || g.cn == 4) && taps_of(g.interp) != 0 && (g.interp != V1C_INTER_NEAREST || g.border != V1C_BORDER_TRANSPARENT) &&
+    return (g.cn == 1 || g.cn == 4) && taps_of(g.interp) != 0 &&
            g.src_w >= 3 && g.src_h >= 2;
 }
 

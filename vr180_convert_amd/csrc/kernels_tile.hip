@@ -421,11 +421,9 @@ bool tile_kernel_supports(const Geom& g)
 {
     // every border mode (the border only matters to pixels whose footprint leaves the source, and those take the per-pixel samplers
     // of the patch path) -- BORDER_TRANSPARENT with the skip rule of the interpolation: remapBilinear leaves a pixel untouched when its
-    // 2 x 2 footprint is not fully inside, remapBicubic / remapLanczos4 when its centre tap is outside (the patch path's store mask);
-    // remapNearest skips by the pixel itself, which the NEAREST form here (the bilinear footprint with zero fractions) does not express:
-    // that one combination stays with the generic kernel
-    return g.cn == 3 && (g.border != V1C_BORDER_TRANSPARENT || g.interp != V1C_INTER_NEAREST) && taps_of(g.interp) != 0 && g.src_w >= 3 &&
-           g.src_h >= 2;
+    // 2 x 2 footprint is not fully inside, remapBicubic / remapLanczos4 when its centre tap is outside, remapNearest when the pixel
+    // itself is (the NN = 1 kernels gather through the bilinear footprint, their patch path samples by remapNearest's rules)
+    return g.cn == 3 && taps_of(g.interp) != 0 && g.src_w >= 3 && g.src_h >= 2;
 }
 
 size_t tile_box_bytes(const Geom& g)

@@ -220,6 +220,18 @@ __device__ __forceinline__ uint32_t slow_pixel_linear3_t(const uint8_t* src, int
     return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | (st ? 0u : 1u << 24);
 }
 
+// the same for INTER_NEAREST (the NN = 1 kernels: fixed point 32 * saturate_cast<short>(cvRound(x)), so sx >> 5 is remapNearest's pixel):
+// remapNearest's border rules -- BORDER_TRANSPARENT leaves a pixel untouched when the pixel ITSELF lies outside, not when its bilinear
+// footprint does
+__device__ __forceinline__ uint32_t slow_pixel_nearest3_t(const uint8_t* src, int64_t pitch, int h, int w, geom_cref gc, int sx, int sy)
+{
+    const Geom g = geom_copy(gc);
+    uint8_t px[3] = {0, 0, 0};
+    const Image im{src, pitch, h, w};
+    const bool st = sample_nearest<3>(im, g, (float)(sx >> 5), (float)(sy >> 5), px);  // (|sx >> 5| <= 2^15: exact in fp32)
+    return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | (st ? 0u : 1u << 24);
+}
+
 struct u128 {
     uint32_t x, y, z, w;
 };
@@ -1022,7 +1034,7 @@ __device__ __forceinline__ void store_interior(units_cptr U, int z, const TileId
 }
 
 // ---- slow-path patch (pixels with valid coordinates the tiled path did not produce) and store ----
-template <int K>
+template <int K, int NN = 0>
 __device__ __forceinline__ void patch_and_store(ctx_cref c, units_cptr U, int z, const TileIds& t, const LaneCoords& L,
                                                 uint32_t (&pix)[kPX], unsigned done, const uint8_t* __restrict__ src)
 {
@@ -1038,7 +1050,11 @@ __device__ __forceinline__ void patch_and_store(ctx_cref c, units_cptr U, int z,
                 if (slow & (1u << k)) {
                     const int fsx = k == 0 ? L.sx[0] : k == 1 ? L.sx[1] : k == 2 ? L.sx[2] : L.sx[3];
                     const int fsy = k == 0 ? L.sy[0] : k == 1 ? L.sy[1] : k == 2 ? L.sy[2] : L.sy[3];
-                    const uint32_t r = slow_pixel_linear3_t(src, U[z].src_pitch, g.src_h, g.src_w, g, fsx, fsy);
+                    uint32_t r;
+                    if constexpr (NN)
+                        r = slow_pixel_nearest3_t(src, U[z].src_pitch, g.src_h, g.src_w, g, fsx, fsy);
+                    else
+                        r = slow_pixel_linear3_t(src, U[z].src_pitch, g.src_h, g.src_w, g, fsx, fsy);
                     skip |= (r >> 24) << k;
 #pragma unroll
                     for (int q = 0; q < kPX; q++)
@@ -1067,7 +1083,7 @@ __device__ __forceinline__ void patch_and_store(ctx_cref c, units_cptr U, int z,
 
 // ---- taps, blend, slow-path patch and store: shared tail of the kernels ----
 // `wtab` = OpenCV's int16 weight table for K = 4 / 8 (global memory, or LDS in the persistent kernel)
-template <int K, typename WPtr>
+template <int K, int NN = 0, typename WPtr>
 __device__ __forceinline__ void sample_and_store(ctx_cref c, units_cptr U, int z, const TileIds& t, const LaneCoords& L,
                                                  const TileBox& b, bool use_lds, const uint32_t* boxw, WPtr wtab,
                                                  const uint8_t* __restrict__ src, uint32_t spitch, bool all_in = false)
@@ -1112,7 +1128,7 @@ __device__ __forceinline__ void sample_and_store(ctx_cref c, units_cptr U, int z
         done = L.inside;
     }
 
-    patch_and_store<K>(c, U, z, t, L, pix, done, src);
+    patch_and_store<K, NN>(c, U, z, t, L, pix, done, src);
 }
 
 // ---- one tile for up to `upb` units that share the map (plan-time boxes) ----
@@ -1362,9 +1378,9 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
                 }
             }
             blend_taps(T0, L, pix);
-            patch_and_store<K>(c, U, z0, t, L, pix, L.inside, U[z0].src);
+            patch_and_store<K, NN>(c, U, z0, t, L, pix, L.inside, U[z0].src);
             blend_taps(T1, L, pix);
-            patch_and_store<K>(c, U, z0 + 1, t, L, pix, L.inside, U[z0 + 1].src);
+            patch_and_store<K, NN>(c, U, z0 + 1, t, L, pix, L.inside, U[z0 + 1].src);
             return;
         }
         if constexpr (K != 2) {
@@ -1432,14 +1448,14 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
                     pa[k] = (uint32_t)pp, pb[k] = (uint32_t)(pp >> 32);
                 }
             }
-            patch_and_store<K>(c, U, z0, t, L, pa, L.inside, U[z0].src);
-            patch_and_store<K>(c, U, z0 + 1, t, L, pb, L.inside, U[z0 + 1].src);
+            patch_and_store<K, NN>(c, U, z0, t, L, pa, L.inside, U[z0].src);
+            patch_and_store<K, NN>(c, U, z0 + 1, t, L, pb, L.inside, U[z0 + 1].src);
             return;
         }
         }
-        sample_and_store<K>(c, U, z0, t, L, b, fit0, boxw, wtab, U[z0].src, (uint32_t)U[z0].src_pitch);
+        sample_and_store<K, NN>(c, U, z0, t, L, b, fit0, boxw, wtab, U[z0].src, (uint32_t)U[z0].src_pitch);
         if (nu == 2)
-            sample_and_store<K>(c, U, z0 + 1, t, L, b, fit1, boxw + half_dwords, wtab, U[z0 + 1].src, (uint32_t)U[z0 + 1].src_pitch);
+            sample_and_store<K, NN>(c, U, z0 + 1, t, L, b, fit1, boxw + half_dwords, wtab, U[z0 + 1].src, (uint32_t)U[z0 + 1].src_pitch);
         return;
     }
     bool fit_cur = fit0, fit_nxt = fit1, fit_s = false;
@@ -1457,7 +1473,7 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
         }
         if (u + 2 < nu)
             fit_s = issue(z + 2, S0);
-        sample_and_store<K>(c, U, z, t, L, b, fit_cur, boxw + (u & 1) * half_dwords, wtab, U[z].src, (uint32_t)U[z].src_pitch,
+        sample_and_store<K, NN>(c, U, z, t, L, b, fit_cur, boxw + (u & 1) * half_dwords, wtab, U[z].src, (uint32_t)U[z].src_pitch,
                             interior);
         fit_cur = fit_nxt;
         V1C_STAMP(4 + (u & 1));  // taps + blend + store of one unit
@@ -1577,7 +1593,7 @@ __device__ __forceinline__ void rot_unit_tile(args_cref a, int z, int btx, int b
                 blend_taps(T, L, pix);
                 store_interior(U, z, t, pix);
             } else {  // box too large for LDS (strong minification): gather from global memory
-                sample_and_store<K>(c, U, z, t, L, fb, false, boxw, wtab, src, spitch);
+                sample_and_store<K, NN>(c, U, z, t, L, fb, false, boxw, wtab, src, spitch);
             }
             return;
         }
@@ -1597,7 +1613,7 @@ __device__ __forceinline__ void rot_unit_tile(args_cref a, int z, int btx, int b
     if (L.ok != (1u << t.npx) - 1)
         if (uint32_t* flags = a.tile_flags)
             flags[t.flag_tile] = 1;
-    sample_and_store<K>(c, U, z, t, L, b, use_lds, boxw, wtab, src, spitch);
+    sample_and_store<K, NN>(c, U, z, t, L, b, use_lds, boxw, wtab, src, spitch);
 }
 
 // ---- a pair (apply_lr) of an unrotated chain: a tile AND its mirror image about the equator per workgroup ----
