@@ -61,7 +61,34 @@ def main() -> int:
                                            bad=int((ref != out).sum())))
                     return 1
                 n += 1
-    print(f"sampler fuzz: {n} remaps, all equal to the oracle, no sanitizer report")
+    # the coordinate code under the sanitizer too: random chains through the interpreter and, where the plan takes it, the ray path
+    # with its fitted tables (radial_fit.hpp: table slices, m-polynomial tables, row / column tables) -- reads outside any of them abort
+    models = ["rectilinear", "stereographic", "equidistant", "equisolid", "orthographic"]
+    t1 = time.time()
+    m = 0
+    while time.time() - t1 < budget / 2:
+        spec = [("equirect_enc", bool(rng.random() < 0.8))] if rng.random() < 0.7 else [("fisheye_enc", models[int(rng.integers(5))])]
+        for _ in range(int(rng.integers(0, 3))):
+            k = rng.random()
+            if k < 0.4:
+                a = rng.normal(0, 0.5, 3)
+                th = float(np.linalg.norm(a)) or 1.0
+                K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]]) / th
+                spec.append(("rot", (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).tolist()))
+            elif k < 0.7:
+                spec.append(("poly", [0.0, 1.0] + [float(v) for v in rng.normal(0, 0.08, int(rng.integers(0, 3)))]))
+            else:
+                spec.append(("zoom", float(rng.uniform(0.4, 2.5))))
+        spec.append(("fisheye_dec", models[int(rng.integers(5))]) if rng.random() < 0.85 else ("rectilinear_dec", 12.0, 17.0))
+        wo, ho = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+        hs, ws = int(rng.integers(2, 3000)), int(rng.integers(3, 3000))
+        ch = O.chain_from_spec(spec, radius=float(rng.uniform(0.2, 1.5) * min(hs, ws) / 2), size_input=(hs, ws), size_output=(wo, ho))
+        xm, ym = np.empty((ho, wo), np.float32), np.empty((ho, wo), np.float32)
+        st = (C.c_longlong * 5)()
+        for mode in (0, 1):
+            E.emul_get_map(C.byref(ch), C.c_void_p(None), wo, ho, mode, C.c_void_p(xm.ctypes.data), C.c_void_p(ym.ctypes.data), st)
+        m += 1
+    print(f"sampler fuzz: {n} remaps, all equal to the oracle; {m} random chains through the coordinate code; no sanitizer report")
     return 0
 
 

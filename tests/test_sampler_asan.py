@@ -1,6 +1,6 @@
-"""The product's per-pixel sampler (v1c_core.hpp), compiled for the host with AddressSanitizer, on degenerate and random small sources
-(1 x 1, one pixel wide, one row high, pitched) and maps full of special values, against the oracle -- in a subprocess with the
-sanitizer runtime preloaded.  GPU AddressSanitizer is not available on the pool; the sampler is __host__ __device__ code, so the host
+"""The product's per-pixel code (v1c_core.hpp, radial_fit.hpp), compiled for the host with AddressSanitizer: the sampler on degenerate
+and random small sources (1 x 1, one pixel wide, one row high, pitched) and maps full of special values, against the oracle, then
+random chains through the interpreter and the ray path with its fitted tables -- in a subprocess with the sanitizer runtime preloaded.  GPU AddressSanitizer is not available on the pool; the sampler is __host__ __device__ code, so the host
 build finds what a GPU run would answer with a memory fault (round 4: a source one pixel wide, found by tools/fuzz.py)."""
 import os
 import subprocess
