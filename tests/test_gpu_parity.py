@@ -1206,6 +1206,41 @@ def test_c3_full_size_frames_vs_oracle(V, oracle_mod, dev):
         O.set_threads(min(8, __import__("os").cpu_count() or 1))
 
 
+def test_sizes_beyond_the_baseline_configs(V, oracle_mod, dev):
+    """Four times BASELINE's largest output: 16 384 x 16 384 per eye (a 32 768 x 16 384 side-by-side buffer of 1.6 GB: 32-bit offsets at
+    their far end, 65 536 tiles per eye) through the mirror launch, and the widest output the ABI takes, 32 767 columns -- every byte
+    against the oracle."""
+    from vr180_convert_amd import remapper
+    from vr180_convert_amd.synth import noise_disc
+
+    if torch.cuda.mem_get_info(0)[0] < 12 << 30:
+        pytest.skip("needs 12 GB of free device memory")
+    O = oracle_mod
+    _all_cores(O)
+    try:
+        spec = CS.FULL_CASES["C2"][0]
+        n_in, n = 6000, 16384
+        left, right = noise_disc(n_in, n_in, 1), noise_disc(n_in, n_in, 2)
+        sbs = V.apply_lr_tensors(CS.to_product(spec), torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev), size_output=(n, n),
+                                 interpolation=1, radius="max")
+        assert remapper.last_launch_kinds() == ["mirror"]
+        got = sbs.cpu().numpy()
+        del sbs
+        xm, ym = O.get_map(spec, radius=n_in / 2, size_input=(n_in, n_in), size_output=(n, n))
+        for e, im in enumerate((left, right)):
+            want = O.remap(im, xm, ym, 1, 0, 0)
+            assert np.array_equal(got[:, e * n:(e + 1) * n], want), e
+        del got, want, xm, ym
+        w2, h2 = 32767, 2048
+        d = torch.empty((h2, w2, 3), dtype=torch.uint8, device=dev)
+        V.remap_tensors(CS.to_product(spec), [torch.from_numpy(left).to(dev)], [d], radius=n_in / 2, interpolation=1)
+        xm, ym = O.get_map(spec, radius=n_in / 2, size_input=(n_in, n_in), size_output=(w2, h2))
+        assert np.array_equal(d.cpu().numpy(), O.remap(left, xm, ym, 1, 0, 0))
+    finally:
+        O.set_threads(min(8, __import__("os").cpu_count() or 1))
+        torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------------------- live third-party hooks
 @pytest.mark.parametrize("interp", [0, 1, 2, 4])
 def test_device_remap_equals_live_cv2_when_present(V, oracle_mod, dev, interp):
