@@ -1083,6 +1083,37 @@ def test_launches_of_more_than_16_units_go_through_the_unit_ring(V, oracle_mod, 
             assert np.array_equal(dsts[k].cpu().numpy(), want[k]), k
 
 
+def test_more_units_than_a_ring_slot_holds(V, oracle_mod, dev):
+    """v1c_plan_run takes any number of units: a ring slot holds 256, longer arrays go out 256 at a time (csrc/plan.hip).  300 frames
+    sharing one map (the batch kernel) and 270 units with a rotation each (the rotation-pair kernel): every unit against the oracle."""
+    from vr180_convert_amd import remapper
+    from vr180_convert_amd import transformer as T
+
+    O = oracle_mod
+    rng = np.random.default_rng(4242)
+    hs = ws = 160
+    wo = ho = 448
+    spec = [("equirect_enc", True), CS.EQUI]
+    imgs = [rng.integers(0, 256, (hs, ws, 3), dtype=np.uint8) for _ in range(300)]
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    dsts = [torch.empty((ho, wo, 3), dtype=torch.uint8, device=dev) for _ in imgs]
+    assert V.remap_tensors(CS.to_product(spec), srcs, dsts, radius=hs / 2, interpolation=1) == ["ray"]
+    assert remapper.last_launch_kinds() == ["batch"], remapper.last_launch_kinds()
+    xm, ym = O.get_map(spec, radius=hs / 2, size_input=(hs, ws), size_output=(wo, ho))
+    for k in range(300):
+        assert np.array_equal(dsts[k].cpu().numpy(), O.remap(imgs[k], xm, ym, 1, 0, 0)), k
+    base = T.EquirectangularEncoder() * T.Euclidean3DRotator((1, 0, 0, 0)) * T.FisheyeDecoder("equidistant")
+    n = 270
+    quats = [CS.c5_spec(f // 2, f % 2)[1][1] for f in range(n)]
+    for d in dsts[:n]:
+        d.zero_()
+    assert V.remap_tensors(base, srcs[:n], dsts[:n], radius=hs / 2, interpolation=1, rotations=quats) == ["ray"]
+    assert remapper.last_launch_kinds() == ["rot_pair"], remapper.last_launch_kinds()
+    for f in range(n):
+        xm, ym = O.get_map(CS.c5_spec(f // 2, f % 2), radius=hs / 2, size_input=(hs, ws), size_output=(wo, ho))
+        assert np.array_equal(dsts[f].cpu().numpy(), O.remap(imgs[f], xm, ym, 1, 0, 0)), f
+
+
 @pytest.mark.parametrize("env", [{"V1C_DISABLE_SHARED_ENTRY": "1"}, {"V1C_DISABLE_MPOLY": "1"}, {"V1C_UPB": "1"}, {"V1C_UPB": "3"},
                                  {"V1C_DISABLE_FAST": "1"}, {"V1C_DISABLE_COORDS_BOUNDED": "1"}, {"V1C_DISABLE_LEAN": "1"}, {"V1C_DISABLE_MERGE": "1"}, {"V1C_XCD_STRIPS": "2"},
                                  {"V1C_DISABLE_MIRROR": "1"}, {"V1C_MIRROR_RAW": "0"}, {"V1C_MIRROR_RAW": "4"}, {"V1C_MIRROR_RAW": "7"},
