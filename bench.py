@@ -94,6 +94,11 @@ WORKLOADS = {
                 desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_CUBIC (the K x K tile kernel with 4 x 4 taps; not a BASELINE config)"),
     "C2L": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=4,
                 desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_LANCZOS4 (the reference's default interpolation at C2's size; not a BASELINE config)"),
+    "C1L": dict(size=2048, poly=None, rot=None, interp=4,
+                desc="L+R 2048x2048 -> 4096x2048 SBS, equidistant, INTER_LANCZOS4: the reference's call with every default (cli.py:230-231 "
+                     "transformer, remapper.py:412-413 size and interpolation); not a BASELINE config"),
+    "C1L995": dict(size=2048, poly=None, rot=None, interp=4, rscale=0.995,
+                   desc="C1L with the image circle 0.5 % inside the frame: no K x K footprint crosses the border of the source (A/B only)"),
     "C2T": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, border=5,
                 desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, bilinear, BORDER_TRANSPARENT (tile kernels since r03; not a BASELINE config)"),
     "C2N": dict(size=4080, poly=[0, 1, -0.1], rot=None, interp=1,
@@ -513,7 +518,7 @@ def main() -> None:
         def step(i: int):
             b = sets[i % nsets]
             V.apply_lr_tensors(transformer, b["left"], b["right"], out=b["sbs"], size_output=(size, size),
-                               interpolation=cfg["interp"], radius="max", boarder_mode=border)
+                               interpolation=cfg["interp"], radius=("max" if "rscale" not in cfg else cfg["rscale"] * size / 2), boarder_mode=border)
 
     def barrier():
         if world > 1:

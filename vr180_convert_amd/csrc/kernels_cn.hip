@@ -104,19 +104,39 @@ __device__ __noinline__ uint64_t slow_pixel_table_cn(const uint8_t* src, int64_t
 #pragma unroll
     for (int ch = 0; ch < CN; ch++)
         acc[ch] = 1 << 14;
+    // (column indices first, then a row's K taps requested together: one memory round trip per row instead of one per tap --
+    //  slow_pixel_table3_t, tile_device.hpp)
+    typedef const __attribute__((address_space(1))) uint8_t* g8;
+    typedef const __attribute__((address_space(1))) short* g16;
+    int xo[K];  // byte offset of tap j in a row; -1: outside under BORDER_CONSTANT
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const int xj = border_index(sx + j, w, border);
+        xo[j] = xj < 0 ? -1 : xj * CN;
+    }
+    const g16 wg = (g16)wt;
 #pragma unroll 1
     for (int i = 0; i < K; i++) {
         const int yi = border_index(sy + i, h, border);  // -1: outside under BORDER_CONSTANT
-        const uint8_t* S = src + (int64_t)(yi < 0 ? 0 : yi) * pitch;
-#pragma unroll 1
+        const g8 S = (g8)src + (int64_t)(yi < 0 ? 0 : yi) * pitch;
+        uint32_t d[K];  // a tap's CN bytes (BGRA: one dword load, at whatever alignment the source has)
+        short wv[K];
+        typedef uint32_t __attribute__((aligned(1), may_alias)) u32_u;
+#pragma unroll
         for (int j = 0; j < K; j++) {
-            const int xj = border_index(sx + j, w, border);
-            const bool in = (yi >= 0) & (xj >= 0);
-            const int wv = wt[i * K + j];
-            const uint8_t* p = S + (in ? xj : 0) * CN;
+            const g8 p = S + (xo[j] < 0 ? 0 : xo[j]);
+            if constexpr (CN == 4)
+                d[j] = *(const __attribute__((address_space(1))) u32_u*)p;
+            else
+                d[j] = p[0];
+            wv[j] = wg[i * K + j];
+        }
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const uint32_t v = ((yi >= 0) & (xo[j] >= 0)) ? d[j] : cval;
 #pragma unroll
             for (int ch = 0; ch < CN; ch++)
-                acc[ch] += (in ? (int)p[ch] : (int)((cval >> (8 * ch)) & 255u)) * wv;
+                acc[ch] += (int)((v >> (8 * ch)) & 255u) * (int)wv[j];
         }
     }
     uint32_t out = 0;

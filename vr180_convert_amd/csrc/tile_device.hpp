@@ -902,20 +902,40 @@ __device__ __noinline__ uint32_t slow_pixel_table3_t(const uint8_t* src, int64_t
     }
     if (border == V1C_BORDER_CONSTANT && (sx >= w || sx + K <= 0 || sy >= h || sy + K <= 0))  // footprint entirely outside
         return cval_bgr & 0xffffffu;
+    // The column indices first (borderInterpolate's loops and switches), then row by row K taps' loads with no control flow between
+    // them: one memory round trip per ROW.  With index and load of every tap in one rolled loop each tap waited for its own load -- 64
+    // round trips per pixel, 512 per wave of a tile whose every footprint crosses the border: where the image circle touches the frame
+    // (radius = "max", what "auto" finds for a full-frame circle: the reference's defaults) a handful of such waves next to the poles ran
+    // 170 us after the rest of the launch had finished, and the 2 048² Lanczos4 pair took 0.285 ms instead of 0.087
+    // (profiles/r04d_final/kxk_border_tiles.log).
+    typedef const __attribute__((address_space(1))) uint8_t* g8;
+    typedef const __attribute__((address_space(1))) short* g16;
+    int xo[K];  // byte offset of tap j in a row; -1: outside under BORDER_CONSTANT
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const int xj = border_index(sx + j, w, border);
+        xo[j] = xj < 0 ? -1 : xj * 3;
+    }
+    const g16 wg = (g16)wt;
     int a0 = 1 << 14, a1 = 1 << 14, a2 = 1 << 14;
 #pragma unroll 1
     for (int i = 0; i < K; i++) {
         const int yi = border_index(sy + i, h, border);  // -1: outside under BORDER_CONSTANT
-        const uint8_t* S = src + (int64_t)(yi < 0 ? 0 : yi) * pitch;
-#pragma unroll 1
+        const g8 S = (g8)src + (int64_t)(yi < 0 ? 0 : yi) * pitch;
+        uint8_t b0[K], b1[K], b2[K];
+        short wv[K];
+#pragma unroll
         for (int j = 0; j < K; j++) {
-            const int xj = border_index(sx + j, w, border);
-            const bool in = (yi >= 0) & (xj >= 0);
-            const int wv = wt[i * K + j];
-            const uint8_t* p = S + (in ? xj : 0) * 3;
-            a0 += (in ? (int)p[0] : cv0) * wv;
-            a1 += (in ? (int)p[1] : cv1) * wv;
-            a2 += (in ? (int)p[2] : cv2) * wv;
+            const g8 p = S + (xo[j] < 0 ? 0 : xo[j]);
+            b0[j] = p[0], b1[j] = p[1], b2[j] = p[2];
+            wv[j] = wg[i * K + j];
+        }
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const bool in = (yi >= 0) & (xo[j] >= 0);
+            a0 += (in ? (int)b0[j] : cv0) * (int)wv[j];
+            a1 += (in ? (int)b1[j] : cv1) * (int)wv[j];
+            a2 += (in ? (int)b2[j] : cv2) * (int)wv[j];
         }
     }
     const int o0 = min(max(a0 >> 15, 0), 255), o1 = min(max(a1 >> 15, 0), 255), o2 = min(max(a2 >> 15, 0), 255);
