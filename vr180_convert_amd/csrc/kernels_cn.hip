@@ -80,9 +80,9 @@ __device__ __forceinline__ void store_cn(uint8_t* drow, const uint32_t (&pix)[kP
     }
 }
 
-// slow_pixel_table3_t for CN = 1 / 4 channels: the rare pixel whose K x K footprint leaves the source (border rules; BORDER_TRANSPARENT:
-// `skip` when the centre tap is outside), loops rolled -- a small register footprint, no local arrays (sample_table<CN, K> of v1c_core.hpp keeps its tap
-// columns in one: scratch)
+// slow_pixel_table3_t for CN = 1 / 4 channels: the pixels whose K x K footprint leaves the source (border rules; BORDER_TRANSPARENT:
+// bit 32 of the result when the centre tap is outside); the row loop rolled, a row's taps in registers (sample_table<CN, K> of v1c_core.hpp
+// keeps its tap columns in a local array: scratch)
 template <int CN, int K>
 // Returns the pixel in the low dword; bit 32: leave the destination untouched.  (By value: a reference parameter of a non-inlined
 // function is a stack slot -- scratch memory for the whole kernel.)

@@ -879,9 +879,9 @@ __device__ __noinline__ uint64_t blend_table_pair(lds_cell_ptr cells, uint32_t l
     return (uint64_t)pa | ((uint64_t)pb << 32);
 }
 
-// Border-aware K x K sampler for the rare pixel whose footprint leaves the source (same
-// arithmetic as sample_table<3, K> in v1c_core.hpp, loops kept rolled: a small register
-// footprint matters more than speed here because the callee's VGPRs count against the kernel).
+// Border-aware K x K sampler for the pixels whose footprint leaves the source (same arithmetic as
+// sample_table<3, K> in v1c_core.hpp; the row loop rolled, a row's taps together: see inside.  The
+// callee's VGPRs count against the kernel -- 117 for K = 8, four waves per SIMD).
 template <int K>
 // (border mode and the packed BGR border value as plain scalars: a Geom passed by value to a
 // non-inlined function had its byte members mis-read -- cval[2] came back as 63)
