@@ -76,3 +76,25 @@ def test_tile_kernels_take_one_argument_block_at_a_known_offset(product_kernels)
     put = [k for k in product_kernels if "k_put_units" in k[".name"]]
     assert len(put) == 1
     assert put[0][".args"][1][".value_kind"] == "by_value" and put[0][".args"][1][".offset"] == 8 and put[0][".args"][1][".size"] == 32 * 112
+
+
+def test_hot_kernels_keep_their_occupancy(product_kernels):
+    """Waves per SIMD of the kernels the BASELINE configurations run are set by their VGPR count (512 / count, in steps of 8 registers).
+    An innocent-looking edit moves it: sharing one lambda between the two unit loops of k_ray_lin_cn cost its bilinear forms 14 VGPRs and
+    a wave per SIMD (+6 % on gray pairs, round 4).  Ceilings = the counts the round's measurements were made with."""
+    import re
+
+    ceilings = {
+        r"k_ray_lin3_pair_mirror_seqILi[01]ELi0EE": 72,     # C1 / C2 pairs: 7 waves per SIMD
+        r"k_ray_lin3_pair_mirror_rawILi0ELi1EE": 72,        # C1S single image
+        r"k_ray_lin3_batch_lean_rawILi0ELi0ELi0EE": 80,     # C3 batches: 6
+        r"k_ray_lin3_rot_pair_rawILi0ELi1ELi1EE": 96,       # C5 per-unit rotations: 5
+        r"k_ray_lin3_tileILi1ELi1ELi1ELi8ELi0ELi1ELi0ELi0EE": 128,  # C4 Lanczos4 pair: 4
+        r"k_ray_lin_cnILi1ELi0ELi[14]ELi0ELi2ELi1EE": 64,   # gray / BGRA bilinear pairs (w-table): 8
+        r"k_ray_lin_cnILi0ELi0ELi[14]ELi0ELi2ELi1EE": 72,   # (m-table): 7
+    }
+    for pat, ceil in ceilings.items():
+        hits = [k for k in product_kernels if re.search(pat, k[".name"])]
+        assert hits, pat
+        for k in hits:
+            assert k[".vgpr_count"] <= ceil, (k[".name"], k[".vgpr_count"], ceil)
