@@ -114,7 +114,32 @@ WORKLOADS = {
                      "since r04; not a BASELINE config)"),
     "C5": dict(size=3840, poly=None, rot="calib", interp=1, frames=32,
                desc="32 SBS frames 7680x3840 per GPU (of 256 over 8 GPUs), per-frame per-eye calibration rotation, bilinear"),
+    # The reference's own test calls (tests/test_remapper.py:42-109): 256 x 256 outputs, the default Lanczos4, radius "max"
+    "C0": dict(size=256, poly=None, rot=None, interp=4,
+               desc="L+R 256x256 -> 512x256 SBS, equidistant, INTER_LANCZOS4: the size of the reference's own test calls "
+                    "(tests/test_remapper.py:73,90,108); not a BASELINE config"),
+    "C0B": dict(size=256, poly=None, rot=None, interp=1,
+                desc="L+R 256x256 -> 512x256 SBS, equidistant, bilinear (the reference's test size; not a BASELINE config)"),
 }
+# Chains that do not start with EquirectangularEncoder(is_latitude_y=True) -- 7 of the reference's 10 test chains
+# (tests/test_remapper.py:42-91: fisheye -> fisheye re-projection, SURVEY.md 8a "planar mode"), each as a 2048 x 2048 pair,
+# bilinear and Lanczos4.  `spec`: the neutral chain description of oracle/oracle.py (chain_from_spec).
+_RY45 = [[math.cos(math.pi / 4), 0.0, math.sin(math.pi / 4)], [0.0, 1.0, 0.0], [-math.sin(math.pi / 4), 0.0, math.cos(math.pi / 4)]]
+_SPEC_CHAINS = {
+    "P1": ("FisheyeEncoder('rectilinear') * FisheyeDecoder('equidistant')",
+           [("fisheye_enc", "rectilinear"), ("fisheye_dec", "equidistant")]),
+    "P2": ("FisheyeEncoder('equidistant') * Euclidean3DRotator(Ry pi/4) * FisheyeDecoder('equidistant')",
+           [("fisheye_enc", "equidistant"), ("rot", _RY45), ("fisheye_dec", "equidistant")]),
+    "P3": ("EquirectangularEncoder(is_latitude_y=False) * FisheyeDecoder('equidistant')",
+           [("equirect_enc", False), ("fisheye_dec", "equidistant")]),
+    "P4": ("FisheyeEncoder('equidistant') * PolynomialScaler([0, 1, -0.1]) * FisheyeDecoder('equidistant')",
+           [("fisheye_enc", "equidistant"), ("poly", [0, 1, -0.1]), ("fisheye_dec", "equidistant")]),
+}
+for _n, (_d, _sp) in _SPEC_CHAINS.items():
+    WORKLOADS[_n] = dict(size=2048, poly=None, rot=None, interp=1, spec=_sp,
+                         desc=f"L+R 2048x2048 -> 4096x2048 SBS, {_d}, bilinear (a chain of the reference's tests; not a BASELINE config)")
+    WORKLOADS[_n + "L"] = dict(size=2048, poly=None, rot=None, interp=4, spec=_sp,
+                               desc=f"L+R 2048x2048 -> 4096x2048 SBS, {_d}, INTER_LANCZOS4 (a chain of the reference's tests; not a BASELINE config)")
 
 
 def allreduce_max(value: float, device: torch.device) -> float:
@@ -148,6 +173,8 @@ def build_transformer(cfg):
     from vr180_convert_amd.transformer import (EquirectangularEncoder, Euclidean3DRotator, FisheyeDecoder,
                                                PolynomialScaler)
 
+    if cfg.get("spec") is not None:
+        return spec_to_product(cfg["spec"])
     t = EquirectangularEncoder()
     if cfg["rot"] == "ry45":
         t = t * Euclidean3DRotator(from_euler_angles(0.0, math.pi / 4, 0.0))
@@ -156,6 +183,30 @@ def build_transformer(cfg):
     if cfg["poly"] is not None:
         t = t * PolynomialScaler(cfg["poly"])
     return t * FisheyeDecoder("equidistant")
+
+
+def spec_to_product(spec):
+    """Neutral chain description (oracle/oracle.py: chain_from_spec) -> the product's transformer objects."""
+    import vr180_convert_amd.transformer as T
+
+    def one(item):
+        kind, *a = item
+        if kind == "equirect_enc":
+            return T.EquirectangularEncoder(*a[:1])
+        if kind == "fisheye_enc":
+            return T.FisheyeEncoder(a[0])
+        if kind == "fisheye_dec":
+            return T.FisheyeDecoder(a[0])
+        if kind == "poly":
+            return T.PolynomialScaler(a[0])
+        if kind == "rot":
+            return T.Euclidean3DRotator(np.asarray(a[0], float))
+        raise ValueError(item)
+
+    out = one(spec[0])
+    for it in spec[1:]:
+        out = out * one(it)
+    return out
 
 
 def calib_rotations(frame: int):
@@ -175,6 +226,8 @@ def calib_rotations(frame: int):
 def oracle_spec(cfg):
     import math
 
+    if cfg.get("spec") is not None:
+        return list(cfg["spec"])
     spec = [("equirect_enc", True)]
     if cfg["rot"] == "ry45":
         c, s = math.cos(math.pi / 4), math.sin(math.pi / 4)
@@ -280,17 +333,20 @@ def spawn_ranks(args, argv: list[str]) -> int:
 PMC_CHILD_ARGS: list[str] = []  # main(): what besides --workload selects the launch (--split)
 
 
-def _pmc_pass(counter: str, workload: str, timeout_s: float):
-    """One `rocprofv3 --pmc <counter>` child pass of this bench (short, nothing else profiled): mean
-    counter value of the dominant remap kernel, or None.  The child is a fresh process; this one only waits."""
+def _pmc_pass(counter: str, workload: str, timeout_s: float, want_all: bool = False):
+    """One `rocprofv3 --pmc <counters>` child pass of this bench (short, nothing else profiled): mean
+    counter value of the dominant remap kernel, or None.  The child is a fresh process; this one only waits.
+    `counter` may name several counters of one pass (space separated); with `want_all` the result is
+    (kernel, {counter: sum over the dominant kernel's dispatches}, dispatches) instead of (kernel, per-step value)."""
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
+    names = counter.split()
     tmp = tempfile.mkdtemp(prefix="v1c_pmc_")
     env = dict(os.environ, V1C_BENCH_CHILD="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
+    cmd = [exe, "--pmc", *names, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
            str(Path(__file__).resolve()), "--workload", workload, "--steps", str(PMC_STEPS), "--warmup", str(PMC_WARMUP), "--no-cpu-baseline",
            "--traffic", "none", "--no-cold-extra", "--no-condition", "--no-sustained", *PMC_CHILD_ARGS]
     try:
@@ -303,20 +359,31 @@ def _pmc_pass(counter: str, workload: str, timeout_s: float):
             return None
         rows = []
         for f in Path(tmp).rglob("*counter_collection.csv"):
-            rows += [r for r in csv.DictReader(open(f)) if r.get("Counter_Name") == counter and
+            rows += [r for r in csv.DictReader(open(f)) if r.get("Counter_Name") in names and
                      ("k_ray" in r.get("Kernel_Name", "") or "k_remap" in r.get("Kernel_Name", ""))]
         if not rows:
             return None
-        by_kernel: dict[str, list[float]] = {}
+        by_kernel: dict[str, dict[str, list[float]]] = {}
         for r in rows:
-            by_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-        # the dominant kernel = the one with the largest counter total; per STEP = total / steps of the child
-        kern = max(by_kernel, key=lambda k: sum(by_kernel[k]))
-        return kern, sum(sum(v) for v in by_kernel.values()) / (1 + PMC_WARMUP + PMC_STEPS)  # + the cold first step
+            by_kernel.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        # the dominant kernel = the one with the largest total of the first counter; per STEP = total / steps of the child
+        kern = max(by_kernel, key=lambda k: sum(by_kernel[k].get(names[0], [0.0])))
+        if want_all:
+            return kern, {c: sum(v) for c, v in by_kernel[kern].items()}, len(by_kernel[kern].get(names[0], []))
+        return kern, sum(sum(v.get(names[0], [])) for v in by_kernel.values()) / (1 + PMC_WARMUP + PMC_STEPS)  # + the cold first step
     except Exception:  # noqa: BLE001 - traffic must never break the bench line
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_valu_per_wave(workload: str):
+    """VALU instructions per wave of the dominant kernel, from one `--pmc SQ_INSTS_VALU SQ_WAVES` child pass of this run."""
+    r = _pmc_pass("SQ_INSTS_VALU SQ_WAVES", workload, 240.0, want_all=True)
+    if r is None or not r[1].get("SQ_WAVES"):
+        return None
+    return {"kernel": r[0].split("(")[0], "valu_instr_per_wave": r[1]["SQ_INSTS_VALU"] / r[1]["SQ_WAVES"],
+            "waves_per_launch": r[1]["SQ_WAVES"] / max(r[2], 1)}
 
 
 def measure_traffic(workload: str):
@@ -649,6 +716,10 @@ def main() -> None:
                        # tiled kernel the workload is meant for, not the generic one
                        "kernels": sorted({p.last_launch() for p in R._PLANS.values() if p.last_launch()}),
                        "buffer_sets": nsets},
+            # what the process group reported (a SCALE record then shows by itself that RCCL saw N ranks)
+            "backend": (dist.get_backend() if world > 1 and dist.is_initialized() else "none (single process)"),
+            "world_size_seen": (dist.get_world_size() if world > 1 and dist.is_initialized() else 1),
+            "per_rank_kernel_ms": [round(ms, 4) for ms in per_rank_ms],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
                          "kernel_ms": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": alg_bytes,
@@ -657,22 +728,29 @@ def main() -> None:
         }
         if sustained is not None:
             line["sustained"] = sustained
-        if cfg["interp"] == 4 and not frames and not single:
-            # INTER_LANCZOS4 is not HBM-bound: 64 taps x 3 channels x 2 eyes = 384 exact integer multiply-accumulates per output
-            # position, one v_perm_b32 + one v_dot2_i32_i16 per two of them (OpenCV's int16 weights admit no cheaper exact form:
-            # DESIGN.md 4.5).  Ceiling = the VALU issue time of the kernel's instruction stream: waves x VALU instructions per wave
-            # (PMC, SQ_INSTS_VALU / SQ_WAVES: profiles/r02f_final/pmc_C4.log) x 4 cycles per wave-instruction on 1024 SIMDs at the
-            # ~2.1 GHz the part sustains.  `frac` stays the HBM fraction (the metric); `valu_int` says how close the launch is to
-            # what actually bounds it.
-            waves = size * size / 256.0  # a wave = 64 lanes x 4 px, both eyes
-            instr, cyc, clk = 2073.0, 4.0, 2.1e9
-            floor_ms = waves * instr * cyc / (1024 * clk) * 1e3
-            line["roofline"]["bound"] = "valu-int"
-            line["roofline"]["valu_int"] = {"floor_ms": round(floor_ms, 4), "frac_of_ceiling": round(floor_ms / kernel_ms_max / max(world, 1) if strong else floor_ms / kernel_ms_max, 4),
-                                            "valu_instr_per_wave": instr, "cycles_per_wave_instr": cyc, "clock_hz": clk,
-                                            "note": "exact int16 tap arithmetic on VALU bounds this launch, not HBM; achieved / peak / frac "
-                                                    "are still the HBM figures of the metric"}
         child = os.environ.get("V1C_BENCH_CHILD") == "1" or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if cfg["interp"] in (2, 4) and not frames and not single:
+            # INTER_CUBIC / INTER_LANCZOS4 are not HBM-bound: K x K taps x 3 channels x 2 eyes exact integer multiply-accumulates per
+            # output position, one v_perm_b32 + one v_dot2_i32_i16 per two of them (OpenCV's int16 weights admit no cheaper exact form:
+            # DESIGN.md 4.5).  Ceiling = the VALU issue time of the kernel's instruction stream: waves x VALU instructions per wave x 4
+            # cycles per wave-instruction on 1024 SIMDs at the ~2.1 GHz the part sustains.  The instruction count is MEASURED by this
+            # run (a `--pmc SQ_INSTS_VALU SQ_WAVES` child pass of the same workload: "source": "live"); without rocprofv3 the object
+            # says so and carries no ceiling.  `frac` stays the HBM fraction (the metric); `valu_int` says how close the launch is to
+            # what actually bounds it.
+            line["roofline"]["bound"] = "valu-int"
+            cyc, clk = 4.0, 2.1e9
+            vi = None
+            if world == 1 and not child and args.traffic == "live":
+                vi = measure_valu_per_wave(args.workload)
+            if vi is not None:
+                floor_ms = vi["waves_per_launch"] * vi["valu_instr_per_wave"] * cyc / (1024 * clk) * 1e3
+                line["roofline"]["valu_int"] = {"source": "live", "floor_ms": round(floor_ms, 4), "frac_of_ceiling": round(floor_ms / kernel_ms_max, 4),
+                                                "valu_instr_per_wave": round(vi["valu_instr_per_wave"], 1), "waves_per_launch": round(vi["waves_per_launch"], 1),
+                                                "kernel": vi["kernel"], "cycles_per_wave_instr": cyc, "clock_hz": clk,
+                                                "note": "exact int16 tap arithmetic on VALU bounds this launch, not HBM; achieved / peak / frac "
+                                                        "are still the HBM figures of the metric"}
+            else:
+                line["roofline"]["valu_int"] = {"source": "unmeasured (no rocprofv3 --pmc pass in this run)", "floor_ms": None, "frac_of_ceiling": None}
         if world == 1 and not child:
             if not frames:
                 torch.cuda.synchronize(dev)

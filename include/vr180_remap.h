@@ -174,6 +174,13 @@ int v1c_plan_path(const v1c_plan* plan);
  * per plan: each keeps its ring slot).  One plan may be run from several threads / streams.   */
 int v1c_plan_run(v1c_plan* plan, void* stream, const v1c_unit* units, int n_units);
 
+/* Hand the plan's capture-owned unit buffers out again (see v1c_plan_run: a recorded launch of more
+ * than 16 units keeps one of 4 for the graph that replays it).  Call it once every graph that
+ * recorded such a launch of this plan has been destroyed -- a process that re-captures over and
+ * over (a resolution that changes back and forth) would otherwise get V1C_E_UNSUPPORTED from the
+ * 5th such capture on.  Nothing in the reference corresponds to it (no graphs there).             */
+int v1c_plan_release_captures(v1c_plan* plan);
+
 /* Which kernels the most recent launch group of v1c_plan_run on this plan used: one of the V1C_LAUNCH_* values, | V1C_LAUNCH_FIXUP
  * when a fix-up pass followed; -1 before the first run.  The engine has several code paths for the same bytes (a generic per-pixel
  * kernel for everything, LDS-tiled kernels for what the plan could prove about the chain and the units); tests use this to make

@@ -166,8 +166,8 @@ class _FakeCv2:
 
 
 def test_automatch_front_ends_report_a_missing_opencv(tmp_path, monkeypatch):
-    """Without cv2 (the GPU image): --automatch fm / gui say which package is missing; --savematch without fm is a usage error
-    instead of an option that silently does nothing."""
+    """Without cv2 (the GPU image): --automatch fm / gui say which package is missing; --savematch without fm is ignored like in the
+    reference (cli.py:365), with a warning -- never a usage error: scripts that always pass the flag keep working."""
     import builtins
 
     from vr180_convert_amd.synth import pattern
@@ -180,8 +180,14 @@ def test_automatch_front_ends_report_a_missing_opencv(tmp_path, monkeypatch):
     for opt in ("fm0.5", "gui"):
         r = runner.invoke(cli.app, ["lr", str(img), str(img), "--radius", "max", "--size", "32x32", "--automatch", opt])
         assert r.exit_code != 0 and "OpenCV" in (r.stdout + str(r.exception) + getattr(r, "stderr", "")), (opt, r.stdout, r.exception)
+    seen = []
+    monkeypatch.setattr(cli.LOG, "warning", lambda msg, *a, **k: seen.append(str(msg)))
+    from vr180_convert_amd import remapper
+
+    monkeypatch.setattr(remapper, "apply_lr", lambda *a, **k: seen.append("apply_lr ran"))
     r = runner.invoke(cli.app, ["lr", str(img), str(img), "--radius", "max", "--size", "32x32", "--savematch"])
-    assert r.exit_code != 0 and "savematch" in (r.stdout + str(r.exception) + getattr(r, "stderr", ""))
+    assert r.exit_code == 0, (r.stdout, r.exception)
+    assert any("--savematch ignored" in m for m in seen) and "apply_lr ran" in seen
 
 
 def test_automatch_fm_gui_and_savematch_glue_with_a_stand_in_cv2(tmp_path, monkeypatch):

@@ -23,7 +23,7 @@ LLVM = Path("/opt/rocm/lib/llvm/bin")
 
 def kernel_metadata(tmp: Path, obj: Path) -> list[dict]:
     if not (LLVM / "llvm-readelf").exists():
-        pytest.skip("llvm-readelf not available")
+        pytest.fail("llvm-readelf not available: the image ships it under /opt/rocm/lib/llvm/bin -- the check must run, here and on the GPU box")
     shutil.copy(obj, tmp / "o.o")
     subprocess.run([str(LLVM / "llvm-objdump"), "--offloading", "o.o"], cwd=tmp, check=True, capture_output=True, timeout=300)
     code = [p for p in tmp.iterdir() if "gfx950" in p.name]

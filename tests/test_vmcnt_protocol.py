@@ -59,7 +59,7 @@ def _disassemble_all(tmp_path_factory, suffix):
 
 def _disassemble(tmp_path_factory, objname):
     if not OBJDUMP.exists():
-        pytest.skip("llvm-objdump not available")
+        pytest.fail("llvm-objdump not available: the image ships it under /opt/rocm/lib/llvm/bin -- the check must run, here and on the GPU box")
     obj = CSRC / objname
     assert obj.exists(), f"{objname} is built by __graft_entry__.build() / make"
     d = tmp_path_factory.mktemp("dis")

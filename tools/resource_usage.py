@@ -19,8 +19,17 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "vr180_convert_amd" / "csrc"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-Wno-unused-function",
-         "-Wno-bitwise-instead-of-logical", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+
+
+def makefile_flags() -> list[str]:
+    """CXXFLAGS of csrc/Makefile (the one place the product's compiler flags are written down), with ARCH expanded."""
+    text = (CSRC / "Makefile").read_text().replace("\\\n", " ")
+    arch = re.search(r"^ARCH\s*\?=\s*(\S+)", text, re.M).group(1)
+    flags = re.search(r"^CXXFLAGS\s*=\s*(.*)$", text, re.M).group(1)
+    return flags.replace("$(ARCH)", arch).split()
+
+
+FLAGS = makefile_flags()
 TILE_SRCS = ["kernels_tile.hip", "kernels_mirror.hip", "kernels_cn.hip"]
 
 

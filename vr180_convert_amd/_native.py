@@ -20,6 +20,7 @@ SYMBOLS = [
     "v1c_abi_version", "v1c_device_count", "v1c_last_error", "v1c_plan_create", "v1c_plan_destroy",
     "v1c_plan_path", "v1c_plan_run", "v1c_plan_get_map", "v1c_remap_fused", "v1c_remap_lut",
     "v1c_get_radius", "v1c_get_radius_async", "v1c_build_itab", "v1c_anaglyph", "v1c_fused_cache_size", "v1c_plan_last_launch",
+    "v1c_plan_release_captures",
 ]
 
 
@@ -56,6 +57,10 @@ def lib() -> C.CDLL:
     L.v1c_plan_path.argtypes = [vp]
     L.v1c_plan_last_launch.argtypes = [vp]
     L.v1c_plan_last_launch.restype = i32
+    try:
+        L.v1c_plan_release_captures.argtypes = [vp]
+    except AttributeError:  # (an older build behind V1C_LIB: A/B runs of tools/ab.sh only)
+        pass
     L.v1c_plan_run.argtypes = [vp, vp, C.POINTER(_abi.Unit), i32]
     L.v1c_plan_get_map.argtypes = [vp, vp, vp, vp, i64, vp]
     L.v1c_remap_fused.argtypes = [i32, vp, vp, i32, i32, i64, i32, vp, i32, i32, i64, C.POINTER(_abi.Chain), i32, i32, vp]

@@ -218,7 +218,8 @@ def lr(
                         r_earlier_l, swap) if name_unique else ""
     out = output_path(out_path, left_path, right_path, tag)
     if savematch and not automatch.startswith("fm"):
-        raise typer.BadParameter("--savematch draws the feature matches of --automatch fm: there is nothing to save without it")
+        # (the reference ignores the flag silently, cli.py:365: scripts that always pass it keep working)
+        LOG.warning("--savematch ignored: it draws the feature matches of --automatch fm, and there are none without it")
     if automatch != "":
         match_image = out.with_suffix(f".match{out.suffix}") if savematch else None  # cli.py:362-365
         chain = calibrated_pair(chain, automatch, left_path, right_path, radius_, match_image)

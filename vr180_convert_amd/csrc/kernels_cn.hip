@@ -264,8 +264,9 @@ __device__ __forceinline__ void blend_table_cn_pair(uint32_t a0, uint32_t a1, ui
 }
 
 // K = 2: bilinear, or nearest with NN = 1 (lane_coords<..., NN>: fixed point 32 * cvRound(x), fractions zero, for which the blend returns its
-// top-left tap exactly; every border mode but TRANSPARENT, whose skip rule differs from the bilinear one); K = 4 / 8: bicubic / Lanczos4
-// (blend_table_cn; every border mode but TRANSPARENT).
+// top-left tap exactly); K = 4 / 8: bicubic / Lanczos4 (blend_table_cn).  Every border mode, BORDER_TRANSPARENT included: the pixels a
+// box cannot serve take the border-aware per-pixel samplers (slow_pixel_table_cn, sample_linear_t / sample_nearest), which apply the
+// skip rule of the interpolation and report it to the store mask (skip bits).
 // BOXES = 1: plan-time boxes, one workgroup per tile walking all units of the launch (they share the map) -- one at a time with the
 // next unit's box in flight (K = 2), two at a time against one fetch of the weight rows (K = 4 / 8: blend_table_cn_pair).
 // BOXES = 0 (ROT = 1): units that override the rotation -- one unit per workgroup (blockIdx.z), coordinates with the unit's matrix,
@@ -506,10 +507,16 @@ constexpr int kPutUnits = 32;
 struct PutArgs {
     DevUnit u[kPutUnits];
 };
+// the kernel-argument segment of k_put_units as the ABI lays it out (natural alignment, declaration order): where the records start
+struct PutKernargs {
+    DevUnit* dst;
+    PutArgs ua;
+    int n;
+};
 __global__ __launch_bounds__(256) void k_put_units(DevUnit* dst, PutArgs ua_, int n)
 {
     typedef const V1C_CONST uint32_t* cu32;
-    const cu32 src = (cu32)((const V1C_CONST uint8_t*)__builtin_amdgcn_kernarg_segment_ptr() + 8);  // (behind `dst`)
+    const cu32 src = (cu32)((const V1C_CONST uint8_t*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PutKernargs, ua));  // (behind `dst`)
     const int words = n * (int)(sizeof(DevUnit) / 4);
     for (int i = threadIdx.x; i < words; i += 256)
         ((uint32_t*)dst)[i] = src[i];
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256) void k_put_units(DevUnit* dst, PutArgs ua_, in
 
 hipError_t launch_put_units(DevUnit* dst, const DevUnit* host, int n, hipStream_t stream)
 {
-    static_assert(sizeof(DevUnit) % 4 == 0 && alignof(PutArgs) == 8 && sizeof(PutArgs) + 16 <= 4096,
+    static_assert(sizeof(DevUnit) % 4 == 0 && alignof(PutArgs) == 8 && sizeof(PutArgs) + 16 <= 4096 && offsetof(PutKernargs, ua) == 8,
                   "k_put_units reads its records at byte 8 of the kernel arguments");
     for (int base = 0; base < n; base += kPutUnits) {
         const int m = std::min(kPutUnits, n - base);
@@ -529,7 +536,8 @@ hipError_t launch_put_units(DevUnit* dst, const DevUnit* host, int n, hipStream_
     return hipGetLastError();
 }
 
-// k_ray_lin_cn: grayscale / BGRA; bilinear with every border mode, nearest / bicubic / Lanczos4 with every border mode but TRANSPARENT
+// k_ray_lin_cn: grayscale / BGRA; every interpolation with every border mode (no border test here on purpose: BORDER_TRANSPARENT's skip
+// rules live in the kernel's patch path)
 bool cn_kernel_supports(const Geom& g)
 {
     return (g.cn == 1 || g.cn == 4) && taps_of(g.interp) != 0 &&

@@ -28,8 +28,11 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(TileArgs a_)  // a.boxes: wri
     const TileIds t = tile_ids(c.g, 0, tid, blockIdx.x, blockIdx.y, gridDim.x, NT / kLanesX);
     RowCol rc;
     load_rowcol<ROT>(c.ray, t.xc, mirror_h > 0 ? min(max(mirror_h - t.j, 0), c.g.dst_h - 1) : t.jc, rc);
+    // bicubic / Lanczos4 boxes of BGR plans with BORDER_CONSTANT cover the footprints that cross the edge of the source too (the tile kernel
+    // stages the border colour around the image: stage_load_ext); the cn kernels' raw LDS-DMA boxes cannot, their plans keep the strict boxes
+    const int ext = (K != 2 && c.g.cn == 3) ? kxk_ext(c.g) : 0;
     LaneCoords L;
-    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, c.ray.rot, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L);
+    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, c.ray.rot, rc, t.npx, c.ray.radial, 0, c.ray.n_int, L, ext);
     TileBox b = reduce_box<K, NW>(L, red, tid);
     int interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L.ok == 0xFu) & (L.inside == 0xFu))) ? 1 : 0;
     const int lo = wave_min_to_lane63(L.idx_lo), nhi = wave_min_to_lane63(-L.idx_hi);
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(NT) void k_tile_boxes(TileArgs a_)  // a.boxes: wri
     if (mpoly) {
         __syncthreads();  // red / red2 are reused
         LaneCoords L2;
-        lane_coords<VAR_W, ROT, K, 0, 0, 1, 0, NN>(c, c.ray.rot, rc, t.npx, c.ray.radial_m, 0, c.ray.n_int, L2);
+        lane_coords<VAR_W, ROT, K, 0, 0, 1, 0, NN>(c, c.ray.rot, rc, t.npx, c.ray.radial_m, 0, c.ray.n_int, L2, ext);
         b = reduce_box<K, NW>(L2, red, tid);
         interior = __syncthreads_and((int)(t.active & (t.npx == kPX) & (L2.ok == 0xFu) & (L2.inside == 0xFu)));
         interior = interior ? 3 : 0;  // (not interior any more: an ordinary tile, evaluated through w)

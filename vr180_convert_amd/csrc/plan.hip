@@ -829,17 +829,21 @@ static LaunchPlan decide_launch(const v1c_plan* p, const DevUnit* du, int n)
     return d;
 }
 
-// device copy of the units of a launch longer than the kernel arguments hold: a ring slot (class comment of v1c_plan)
+// device copy of the units of a launch longer than the kernel arguments hold: a ring slot (class comment of v1c_plan).
+// The caller holds ring_mu from here until ring_done() has recorded the slot's event behind the remap launch that reads it: the slot's
+// bookkeeping (ring_used / ring_last / ring_ev) is only complete then, and a second thread that picked the same slot in between would
+// see the stale state, skip its hipStreamWaitEvent and overwrite records a launch in flight is still reading (advisor finding of round
+// 4).  Everything between the two calls is asynchronous launches: the critical section is a few microseconds.
 static int ring_put(v1c_plan* p, hipStream_t st, const DevUnit* du, int n, const DevUnit** out, int* slot_out)
 {
-    std::lock_guard<std::mutex> lk(p->ring_mu);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess)
         cap = hipStreamCaptureStatusNone;
     int slot;
     if (cap != hipStreamCaptureStatusNone) {
         if (p->capture_next >= v1c_plan::kCaptureSlots)
-            return fail(V1C_E_UNSUPPORTED, "too many graph-captured launches of more than 16 units for one plan");
+            return fail(V1C_E_UNSUPPORTED, "too many graph-captured launches of more than 16 units for one plan (v1c_plan_release_captures "
+                                           "hands the slots out again once their graphs are destroyed)");
         slot = v1c_plan::kRingSlots + p->capture_next++;
         *slot_out = -1;
     } else {
@@ -859,9 +863,19 @@ static int ring_done(v1c_plan* p, hipStream_t st, int slot)
 {
     if (slot < 0)
         return V1C_OK;
-    std::lock_guard<std::mutex> lk(p->ring_mu);
     HIP_TRY(hipEventRecord(p->ring_ev[slot], st));
     p->ring_last[slot] = st, p->ring_used[slot] = true;
+    return V1C_OK;
+}
+
+// Graph-captured launches of more than 16 units take one of the plan's kCaptureSlots capture-owned unit buffers each (a graph owns what
+// it replays).  Once every graph that recorded such a launch of this plan has been destroyed the caller may hand the slots out again.
+extern "C" int v1c_plan_release_captures(v1c_plan* p)
+{
+    if (!p)
+        return fail(V1C_E_INVALID, "plan is NULL");
+    std::lock_guard<std::mutex> lk(p->ring_mu);
+    p->capture_next = 0;
     return V1C_OK;
 }
 
@@ -920,7 +934,9 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         uint32_t* flags = d.need_fixup ? p->ctx.tile_flags : nullptr;
         LaunchUnits lu{u, nullptr, n};
         int slot = -1;
+        std::unique_lock<std::mutex> ring_lk(p->ring_mu, std::defer_lock);  // slot selection ... the slot's event (ring_put's comment)
         if (d.fast && n > kInlineUnits) {
+            ring_lk.lock();
             int rc = ring_put(p, st, u, n, &lu.dev, &slot);
             if (rc)
                 return rc;
@@ -966,6 +982,8 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             if (rc)
                 return rc;
         }
+        if (ring_lk.owns_lock())
+            ring_lk.unlock();
         p->last_launch.store(kind | (d.need_fixup ? V1C_LAUNCH_FIXUP : 0), std::memory_order_relaxed);
         if (d.need_fixup) {
             HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, unit_args(u, n), n, st));

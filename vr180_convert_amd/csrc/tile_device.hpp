@@ -83,6 +83,17 @@ struct DstSize {
 struct RowColTabs {
     const double *col_s, *col_c, *col_h, *row_s, *row_c, *row_h;
 };
+// the kernel-argument segment of a mirror kernel as the ABI lays it out (natural alignment, declaration order): the argument block
+// behind the head (tests/test_resource_budget.py checks the same offset in the code object's metadata)
+struct MirrorKernargs {
+    const TileBox* pairs;
+    unsigned tiles_x_magic, gx_rest, rows_strip, dst_wh;
+    const double* rowcol_tables;
+    const KernelCtx* ctxp;
+    unsigned kb_mh;
+    TileArgs args;
+};
+static_assert(offsetof(MirrorKernargs, args) == kMirrorHeadBytes, "kernel_args<kMirrorHeadBytes>() must point at the TileArgs block");
 // the six tables of a plan from the base of their buffer (plan.hip: col_s | col_c | col_h of wpad entries, row_s | row_c | row_h of dst_h)
 __device__ __forceinline__ RowColTabs rowcol_tables_at(const double* base, int dst_w, int dst_h)
 {
@@ -351,8 +362,12 @@ __device__ __forceinline__ void load_rowcol(const Tables& P, int xc, int jc, Row
 template <int VAR_W, int ROT, int K, int OWN, int INTERIOR, int MPOLY, int MIRROR = 0, int NN = 0, typename TabPtr>
 // `rot`: the rotation that applies (ROT != 0): the unit's own record -- the host stores the EFFECTIVE matrix there, the unit's override
 // or the chain's composed rotation (plan.hip: fill_unit) -- or c.ray.rot (k_tile_boxes)
+// `ext` (K = 4 / 8, BGR, BORDER_CONSTANT: kxk_ext()): a pixel counts as `inside` when its K x K footprint OVERLAPS the source instead of
+// lying inside it -- the consumer stages the box with the border colour around the image (stage_load_ext), so the taps beyond the edge
+// read what remapBicubic / remapLanczos4's constant-border branch substitutes for them (oracle/vr180_oracle.c:415-449) and the
+// pixel never takes the per-pixel patch path.
 __device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowCol& rc, int npx, TabPtr tab,
-                                            int tab0, int tabn, LaneCoords& L)
+                                            int tab0, int tabn, LaneCoords& L, int ext = 0)
 {
     ray_cref P = c.ray;
     geom_cref g = c.g;
@@ -521,9 +536,12 @@ __device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowC
         // test); the bilinear path additionally wants 8 readable bytes per row for its global-memory
         // fallback, hence w - 2 there
         constexpr int off = K / 2 - 1;
+        // (ext: top-left tap in [-(K - 1), len - 1], i.e. the footprint shares at least one row and one column with the source)
+        const int lo_e = (K != 2 && ext) ? K - 1 : 0;
+        const unsigned wb = (K != 2 && ext) ? (unsigned)(g.src_w + K - 1) : (unsigned)max(g.src_w - (K - 1), 0);
+        const unsigned hb = (K != 2 && ext) ? (unsigned)(g.src_h + K - 1) : (unsigned)max(g.src_h - (K - 1), 0);
         const bool in = K == 2 ? okk & ((unsigned)ix < (unsigned)max(g.src_w - 2, 0)) & ((unsigned)iy < (unsigned)max(g.src_h - 1, 0))
-                               : okk & ((unsigned)(ix - off) < (unsigned)max(g.src_w - (K - 1), 0)) &
-                                     ((unsigned)(iy - off) < (unsigned)max(g.src_h - (K - 1), 0));
+                               : okk & ((unsigned)(ix - off + lo_e) < wb) & ((unsigned)(iy - off + lo_e) < hb);
         L.inside |= in ? 1u << k : 0u;
     }
 }
@@ -693,6 +711,57 @@ __device__ __forceinline__ void stage_load(const ChunkMap& M, const uint8_t* __r
                     if (goff + bb < src_bytes)
                         w[bb >> 2] |= (uint32_t)src[goff + bb] << (8 * (bb & 3));
                 S.w0[q] = w[0], S.w1[q] = w[1], S.w2[q] = w[2];
+            }
+        }
+    }
+}
+
+// ---- the same for a box that leaves the source (bicubic / Lanczos4, BORDER_CONSTANT): the border colour around the image ----
+// remapBicubic / remapLanczos4 give a tap outside the source the border value (the constant-border branch: oracle/vr180_oracle.c:415-449,
+// sample_table in v1c_core.hpp).  A box staged with that colour in every cell outside the image lets the K x K gather serve such
+// footprints like any other: where the image circle touches the frame (radius = "max", what "auto" finds for a full-frame circle: the
+// reference's defaults, remapper.py:333,416) whole tiles next to the poles have every footprint cross the edge, and the per-pixel
+// patch path they took was a tail of ~30 waves that doubled the launch (C1L 0.189 against 0.092 ms with the circle 0.5 % inside).
+// Chunks are 4 pixels starting at a multiple of 4 columns: they straddle the right edge only (src_w not a multiple of 4).
+__device__ __forceinline__ int kxk_ext(geom_cref g)
+{
+    return g.border == V1C_BORDER_CONSTANT ? 1 : 0;
+}
+__device__ __forceinline__ bool box_leaves_source(const TileBox& b, geom_cref g)
+{
+    return (b.x0 < 0) | (b.y0 < 0) | (b.x0 + 4 * b.cpr > g.src_w) | (b.y0 + b.nrows > g.src_h);
+}
+template <bool ZERO, int NQ = 4>
+__device__ __forceinline__ void stage_load_ext(const ChunkMap& M, const uint8_t* __restrict__ src, uint32_t spitch, geom_cref g, Staged& S)
+{
+    const uint32_t c0 = g.cval[0], c1 = g.cval[1], c2 = g.cval[2];
+    const uint32_t p0 = c0 | (c1 << 8) | (c2 << 16) | (c0 << 24), p1 = c1 | (c2 << 8) | (c0 << 16) | (c1 << 24),
+                   p2 = c2 | (c0 << 8) | (c1 << 16) | (c2 << 24);  // four border pixels
+    const int wb = g.src_w * 3;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        if (ZERO)
+            S.w0[q] = S.w1[q] = S.w2[q] = 0;
+        if (M.valid & (1u << q)) {
+            const int row = (int)M.row[q], xb = (int)M.xbyte[q];  // (signed: the box may start left of / above the image)
+            const bool row_in = (unsigned)row < (unsigned)g.src_h;
+            if (row_in & (xb >= 0) & (xb + 12 <= wb)) {
+                struct u96 {
+                    uint32_t a, b, c;
+                };
+                typedef u96 __attribute__((aligned(4), may_alias)) u96a4;
+                const u96 v = *(const u96a4*)(src + (__umul24((uint32_t)row, spitch) + (uint32_t)xb));
+                S.w0[q] = v.a, S.w1[q] = v.b, S.w2[q] = v.c;
+            } else if (row_in & (xb >= 0) & (xb < wb)) {  // the chunk straddles the right edge: pixel by pixel
+                uint32_t w[3] = {p0, p1, p2};
+                const uint32_t goff = __umul24((uint32_t)row, spitch) + (uint32_t)xb;
+#pragma unroll 1
+                for (int bb = 0; bb < 12; bb++)
+                    if (xb + bb < wb)
+                        w[bb >> 2] = (w[bb >> 2] & ~(0xffu << (8 * (bb & 3)))) | ((uint32_t)src[goff + bb] << (8 * (bb & 3)));
+                S.w0[q] = w[0], S.w1[q] = w[1], S.w2[q] = w[2];
+            } else {
+                S.w0[q] = p0, S.w1[q] = p1, S.w2[q] = p2;
             }
         }
     }
@@ -1204,6 +1273,10 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
     // two units, the radial-table slice and the row / column table entries (one exposed latency)
     const TileBox b = load_tile_box(boxes, t.box_tile);
     const bool tail = box_touches_image_end(b, g);
+    // bicubic / Lanczos4 with BORDER_CONSTANT: footprints that cross the edge of the source are served from the box too (lane_coords' `ext`;
+    // the plan's boxes were computed the same way: k_tile_boxes)
+    const int ext = (K != 2 && !LEAN) ? kxk_ext(g) : 0;
+    const bool ext_box = K != 2 && ext && box_leaves_source(b, g);
     // lean batch path (further down): bilinear, more than two units, an interior tile whose table slice
     // and box fit -- the box is the same for all units, only the alignment of a source can differ
     // (the host launches the lean kernel only when every source is dword-aligned and every group has
@@ -1219,7 +1292,9 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
         const bool fits = box_fits(b, src, spitch, 4 * NT, LEAN ? 2 * half_dwords : half_dwords);
         if (fits) {
-            if (tail)
+            if (K != 2 && ext_box)  // (the box leaves the source: border colour around the image)
+                stage_load_ext<!PAIR>(M, src, spitch, g, S);
+            else if (tail)
                 stage_load<true, !PAIR>(M, src, spitch, src_bytes, S);
             else
                 stage_load<false, !PAIR>(M, src, spitch, src_bytes, S);
@@ -1331,13 +1406,13 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
         return;
     LaneCoords L;
     if (OWN == 0 && interior && mpoly)
-        lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, 0, 1, 1, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L, ext);
     else if (interior)
-        lane_coords<VAR_W, ROT, K, OWN, 1, 0, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, OWN, 1, 0, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L, ext);
     else if (tab_lds)
-        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z0].rot, rc, t.npx, (const double*)tabw, b.idx0, b.nidx, L, ext);
     else
-        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z0].rot, rc, t.npx, P.radial, 0, P.n_int, L);
+        lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z0].rot, rc, t.npx, P.radial, 0, P.n_int, L, ext);
     const bool incomplete = L.ok != (1u << t.npx) - 1;
     V1C_STAMP(3);  // coordinates
 
@@ -1619,14 +1694,18 @@ __device__ __forceinline__ void rot_unit_tile(args_cref a, int z, int btx, int b
         }
         __syncthreads();  // `red` is reused below
     }
-    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z].rot, rc, t.npx, P.radial, 0, P.n_int, L);
+    const int ext = K != 2 ? kxk_ext(g) : 0;
+    lane_coords<VAR_W, ROT, K, OWN, 0, 0, 0, NN>(c, U[z].rot, rc, t.npx, P.radial, 0, P.n_int, L, ext);
     const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
     const bool use_lds = box_fits(b, src, spitch, 4 * NT, kBoxBytes / 4);
     if (use_lds) {
         ChunkMap M;
         make_chunk_map<NT>(b, tid, M);
         Staged S;
-        stage_load<true, true>(M, src, spitch, src_bytes, S);
+        if (K != 2 && ext && box_leaves_source(b, g))
+            stage_load_ext<true>(M, src, spitch, g, S);
+        else
+            stage_load<true, true>(M, src, spitch, src_bytes, S);
         stage_store(M, S, boxw);
     }
     __syncthreads();

@@ -173,6 +173,11 @@ class Plan:
         rc = _native.lib().v1c_plan_run(self._h, _stream_ptr(self.device), units, int(n))
         _native.check(rc, "v1c_plan_run")
 
+    def release_captures(self) -> None:
+        """Hand the plan's capture-owned unit buffers out again (``v1c_plan_release_captures``): a graph-captured launch of more than
+        16 units keeps one of 4; call this once the graphs that recorded them are destroyed."""
+        _native.check(_native.lib().v1c_plan_release_captures(self._h), "v1c_plan_release_captures")
+
     def get_map(self, rot: Any = None) -> tuple[torch.Tensor, torch.Tensor]:
         w, h = self.dst_wh
         xm = torch.empty((h, w), dtype=torch.float32, device=self.device)
