@@ -425,6 +425,39 @@ def cold_call(cfg, dev, V, transformer_builder):
     return {"plan_create_ms": round(create, 3), "first_call_ms": round(first, 3), "second_call_ms": round(second, 3)}
 
 
+def new_radius_cost(cfg, dev, V, transformer_builder):
+    """What radius="auto" -- the reference's default, remapper.py:333,416 -- costs per image when the image circle changes from image to
+    image: the device-resident form (estimate, maximum, scale and remap on the stream: no synchronisation, one plan for every radius)
+    against the exact form (estimates brought to the host, a plan per new radius).  Wall time per apply_lr_tensors call, ms; discs of
+    different radii in turn so that every call sees a radius its predecessor did not."""
+    from vr180_convert_amd import remapper as R
+
+    size = cfg["size"]
+    yy, xx = torch.meshgrid(torch.arange(size, device=dev), torch.arange(size, device=dev), indexing="ij")
+    rr = (xx - size / 2) ** 2 + (yy - size / 2) ** 2
+    base = torch.randint(40, 256, (size, size, 3), dtype=torch.uint8, device=dev)
+    n_img = 12
+    imgs = [base * (rr <= (size / 2 - 3 - 1.5 * k) ** 2)[..., None].to(torch.uint8) for k in range(n_img)]
+    sbs = torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)
+    t = transformer_builder(cfg)
+    out = {}
+    for key, on_dev in (("new_radius_ms", True), ("new_radius_exact_ms", False)):
+        try:
+            V.apply_lr_tensors(t, imgs[0], imgs[1], out=sbs, size_output=(size, size), interpolation=cfg["interp"], radius="auto", auto_radius_on_device=on_dev)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for k in range(2, n_img, 2):
+                V.apply_lr_tensors(t, imgs[k], imgs[k + 1], out=sbs, size_output=(size, size), interpolation=cfg["interp"], radius="auto",
+                                   auto_radius_on_device=on_dev)
+            torch.cuda.synchronize(dev)
+            out[key] = round((time.perf_counter() - t0) * 1e3 / ((n_img - 2) // 2), 4)
+        except Exception as e:  # noqa: BLE001 - must never break the bench line
+            out[key] = repr(e)
+    out["new_radius_note"] = ("radius='auto' per L+R pair whose image circle differs from the previous pair's, wall ms per call: on the device "
+                              "(v1c_plan_run_auto: no sync, one plan) / exact (estimates to the host, plan per radius)")
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -775,6 +808,8 @@ def main() -> None:
                     line["cold_C4_8192_lanczos4"] = cold_call(WORKLOADS["C4"], dev, V, build_transformer)
                 except Exception as e:  # noqa: BLE001
                     line["cold_C4_8192_lanczos4"] = {"error": repr(e)}
+            if not args.no_cold_extra and not frames and not single and not strong and cn == 3 and cfg.get("spec") is None:
+                line["cold"].update(new_radius_cost(cfg, dev, V, build_transformer))
             if not args.no_cpu_baseline and not frames:
                 cb, parity = cpu_baseline(cfg, left_h, right_h, gpu_out)
                 line["cpu_baseline"] = cb

@@ -174,6 +174,17 @@ int v1c_plan_path(const v1c_plan* plan);
  * per plan: each keeps its ring slot).  One plan may be run from several threads / streams.   */
 int v1c_plan_run(v1c_plan* plan, void* stream, const v1c_unit* units, int n_units);
 
+/* v1c_plan_run with the radius read from DEVICE memory: radius="auto" -- the reference's default, remapper.py:333,416 -- without a host
+ * round trip or a plan per image.  Replaces get_radius_smart("auto") (remapper.py:82-84: the max over the images of get_radius) feeding
+ * get_map's DenormalizeTransformer(scale=(radius, radius)) (remapper.py:51-57).  `rad_dev`: n_rad (radius, status) pairs in device memory as
+ * v1c_get_radius_async writes them; the launch uses max(radius) -- clamped to 4 x the larger source dimension in magnitude; NaN (every
+ * pixel the border colour) if any status is set, where the reference raises IndexError.  The plan's own radius is ignored, so one plan
+ * serves every image of a stream.  At most 16 units; chains EquirectangularEncoder() * [one rotation] * radial stages whose table needs
+ * no fix-up pass -- anything else returns V1C_E_UNSUPPORTED and the caller takes the radius to the host (v1c_get_radius).  Launch-only,
+ * graph-capturable; one plan may be used from several streams (ordered by an event).                                              */
+int v1c_plan_run_auto(v1c_plan* plan, void* stream, const v1c_unit* units, int n_units,
+                      const double* rad_dev, int n_rad);
+
 /* Hand the plan's capture-owned unit buffers out again (see v1c_plan_run: a recorded launch of more
  * than 16 units keeps one of 4 for the graph that replays it).  Call it once every graph that
  * recorded such a launch of this plan has been destroyed -- a process that re-captures over and

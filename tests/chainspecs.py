@@ -100,6 +100,22 @@ FULL_CASES = {
 }
 FULL_STRIDE = 256  # rows / columns kept verbatim in the fixtures
 
+# Chains that do not start with EquirectangularEncoder(is_latitude_y=True), at sizes the tile kernels are selected for: the reference's
+# own test chains (tests/test_remapper.py:42-91: five FisheyeEncoders, the rotator and the polynomial between equidistant encoder and
+# decoder), is_latitude_y=False, a rotation behind a radial stage, a non-square planar output.  (spec, size_output, size_input, radius)
+PLANAR_CASES = {f"apply_{m}": ([("fisheye_enc", m), EQUI], (1024, 1024), (1024, 1024), 512.0)
+                for m in ["rectilinear", "stereographic", "equidistant", "equisolid", "orthographic"]}
+PLANAR_CASES.update({
+    "transformer_rotator": ([("fisheye_enc", "equidistant"), ("rot", ry(math.pi / 4)), EQUI], (1024, 1024), (1024, 1024), 512.0),
+    "transformer_poly": ([("fisheye_enc", "equidistant"), ("poly", [0, 1, -0.1]), EQUI], (1024, 1024), (1024, 1024), 512.0),
+    "equirect_lat_x": ([("equirect_enc", False), EQUI], (1024, 1024), (1024, 1024), 512.0),
+    "equirect_lat_x_rot": ([("equirect_enc", False), ("rot", ry(0.3)), ("poly", [0, 1, -0.1]), EQUI], (1024, 1024), (1024, 1024), 512.0),
+    "rot_after_radial": ([("equirect_enc", True), ("poly", [0, 1, -0.1]), ("rot", ry(0.3)), EQUI], (1024, 1024), (1024, 1024), 512.0),
+    "planar_rot_small_angle": ([("fisheye_enc", "stereographic"), ("rot_quat", rotvec_quat([0.02, -0.05, 0.03])), ("fisheye_dec", "equisolid")],
+                               (1024, 1024), (1024, 1024), 512.0),
+    "planar_nonsquare": ([("fisheye_enc", "stereographic"), ("zoom", 1.25), EQUI], (1536, 1024), (1080, 1920), 540.0),
+})
+
 
 def c5_spec(frame: int, eye: int) -> list[tuple]:
     """BASELINE config 5: per-frame calibration quaternion, L = conj(half_q), R = half_q."""

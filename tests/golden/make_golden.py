@@ -242,8 +242,30 @@ def match_lr_golden() -> None:
     print("match_lr.npz:", {k: v.shape for k, v in out.items()})
 
 
+def planar_golden() -> None:
+    """get_map of the reference for chainspecs.PLANAR_CASES at full size: SHA-256 of the 1/32-pixel bucket planes, every 256th row and
+    column verbatim, the NaN count (FisheyeEncoder("orthographic") / ("equisolid") beyond their domain, transformer.py:370-372)."""
+    import warnings
+
+    warnings.simplefilter("ignore")
+    out = {}
+    for name, (spec, size_out, size_in, radius) in CS.PLANAR_CASES.items():
+        xm, ym = get_map(to_reference(spec), radius=radius, size_input=size_in, size_output=size_out)
+        bx, by = CS.buckets(xm), CS.buckets(ym)
+        out[f"{name}__sha_bx"] = np.frombuffer(hashlib.sha256(bx.tobytes()).digest(), np.uint8)
+        out[f"{name}__sha_by"] = np.frombuffer(hashlib.sha256(by.tobytes()).digest(), np.uint8)
+        s = CS.FULL_STRIDE
+        out[f"{name}__rows_x"], out[f"{name}__rows_y"] = xm[::s].copy(), ym[::s].copy()
+        out[f"{name}__cols_x"], out[f"{name}__cols_y"] = xm[:, ::s].copy(), ym[:, ::s].copy()
+        out[f"{name}__nan"] = np.int64(np.isnan(xm).sum())
+        print(f"planar {name:24s} {xm.shape} nan={int(np.isnan(xm).sum())} sha_bx={hashlib.sha256(bx.tobytes()).hexdigest()[:16]}")
+    np.savez_compressed(Path(__file__).resolve().parent / "maps_planar.npz", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "rotation_match":
+    if len(sys.argv) > 1 and sys.argv[1] == "planar":
+        planar_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rotation_match":
         rotation_match_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "match_lr":
         match_lr_golden()
@@ -251,3 +273,4 @@ if __name__ == "__main__":
         main()
         rotation_match_golden()
         match_lr_golden()
+        planar_golden()

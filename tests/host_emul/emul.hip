@@ -56,17 +56,21 @@ int emul_get_map(const v1c_chain* ch, const double* rot_or_null, int w, int h, i
             }
         return 0;
     }
-    RayAnalysis a = analyze_chain(*ch);
+    // as plan.hip: the plan's host-side derivation (radial_fit.hpp), fits uncached
+    RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
+        return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
+    });
+    const RayAnalysis& a = H.a;
     if (!a.ok)
         return 1;
-    RadialTable T = build_radial_table(a.radial, table_intervals_for(3.14159265358979323846 / a.norm_s));  // as plan.hip
+    const RadialTable& T = H.table;
     if (stats) {
         stats[2] = T.var_is_w;
         stats[3] = T.n_invalid;
     }
-    if (!ray_table_usable(T))
+    if (!H.usable)
         return 2;
-    RayHostTables ht = build_ray_host_tables(a, w, h);
+    const RayHostTables& ht = H.ht;
     RayParams P{};
     P.col_s = ht.col_s.data(), P.col_c = ht.col_c.data(), P.col_h = ht.col_h.data();
     P.row_s = ht.row_s.data(), P.row_c = ht.row_c.data(), P.row_h = ht.row_h.data();
@@ -77,6 +81,11 @@ int emul_get_map(const v1c_chain* ch, const double* rot_or_null, int w, int h, i
     P.rx = a.rx, P.ry = a.ry, P.cx = a.cx, P.cy = a.cy;
     P.rx32 = 32.0 * a.rx, P.ry32 = 32.0 * a.ry, P.cx32 = 32.0 * a.cx, P.cy32 = 32.0 * a.cy;
     P.n_int_f = (double)P.n_int;
+    P.gen_mode = a.gen_mode;
+    if (H.has_pre) {
+        P.pre_s = H.pre_s.coef.data(), P.pre_c = H.pre_c.coef.data();
+        P.pre_var_is_w = H.pre_s.var_is_w, P.pre_inv_step = H.pre_s.inv_step, P.pre_n_int = H.pre_s.n_int;
+    }
     double R[9];
     const bool use_rot = rot_or_null || a.has_rot;
     for (int q = 0; q < 9; q++)
@@ -95,8 +104,31 @@ int emul_get_map(const v1c_chain* ch, const double* rot_or_null, int w, int h, i
     if (stats) {
         stats[0] = 1;
         stats[1] = nfix;
-        stats[4] = !a.has_rot && !rot_or_null && ray_reach_is_safe(T, ht.m_reach);
+        stats[4] = !a.has_rot && !rot_or_null && ray_reach_is_safe(T, H.reach_norot);
     }
+    return 0;
+}
+
+// What the plan derives from a chain and an output size (radial_fit.hpp: build_ray_plan_host), for tests that assert which path a
+// chain takes: out[0] = analysis ok, [1] = usable, [2] = base, [3] = gen_mode, [4] = main table fn, [5] = its variable (0 m / 1 w),
+// [6] = intervals, [7] = first interval below level 1, [8] = below level 2, [9] = first flagged, [10] = one entry per lane provable
+// for the plan's own rotation / none (ray_entry_is_shared at its reach), [11] = no fix-up pass needed.
+int emul_plan_info(const v1c_chain* ch, int w, int h, long long* out)
+{
+    std::memset(out, 0, 12 * sizeof(long long));
+    RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
+        return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
+    });
+    out[0] = H.a.ok, out[2] = H.a.base, out[3] = H.a.gen_mode;
+    if (!H.a.ok)
+        return 0;
+    const RadialTable& T = H.table;
+    out[1] = H.usable, out[4] = T.fn, out[5] = T.var_is_w, out[6] = T.n_int;
+    out[7] = T.first_below_level[1], out[8] = T.first_below_level[2], out[9] = T.first_invalid;
+    const double reach = H.a.has_rot ? H.reach_rot : H.reach_norot;
+    const bool safe = H.a.has_rot ? (H.reach_rot < 2.0 && H.pre_safe && ray_reach_is_safe(T, reach)) : ray_reach_is_safe(T, reach);  // as plan.hip
+    out[10] = safe && ray_entry_is_shared(T, reach, H.step);
+    out[11] = safe;
     return 0;
 }
 

@@ -206,9 +206,12 @@ CUTS = {
     "nearest": (CS.FULL_CASES["C2"][0], 512, 0, "ray"),
     "fixup_back_hemisphere": (CS.SMALL_CASES["back_hemisphere"][0], 512, 1, "ray"),
     "fixup_poly_c0": (CS.SMALL_CASES["poly_c0"][0], 512, 1, "ray"),
-    "literal_fisheye_to_fisheye": (CS.SMALL_CASES["transformer_rotator"][0], 512, 4, "literal"),
-    "literal_rot_after_radial": (CS.SMALL_CASES["rot_after_radial"][0], 512, 1, "literal"),
-    "literal_orthographic_nan": (CS.SMALL_CASES["apply_orthographic"][0], 512, 1, "literal"),
+    # (fused since round 5: planar chains, a rotation behind radial stages -- tests/test_gpu_round5.py has them at full size)
+    "planar_fisheye_to_fisheye_rotated": (CS.SMALL_CASES["transformer_rotator"][0], 512, 4, "planar"),
+    "rot_after_radial": (CS.SMALL_CASES["rot_after_radial"][0], 512, 1, "ray"),
+    "planar_orthographic_nan": (CS.SMALL_CASES["apply_orthographic"][0], 512, 1, "planar"),
+    # (still the fp64 interpreter: decoders, i.e. chains that do not end in a radial composite)
+    "literal_equirect_decoder": (CS.SMALL_CASES["equirect_decoder"][0], 512, 1, "literal"),
 }
 
 

@@ -88,6 +88,191 @@ def test_kxk_edge_footprints_with_a_rotation_per_unit(V, oracle_mod, dev, interp
         assert np.array_equal(got, want), (interp, f, int((got != want).sum()))
 
 
+# ---------------------------------------------------------------------------- planar / general modes (SURVEY.md 8a "planar mode")
+@pytest.mark.parametrize("name", list(CS.PLANAR_CASES))
+def test_planar_and_general_modes_device_maps_vs_reference(V, golden_dir, name):
+    """v1c_plan_get_map of the chains the fused path serves since round 5 against the REFERENCE's get_map at full size: every 256th row
+    and column in the same 1/32-pixel buckets (NaN <=> NaN), SHA-256 of the whole bucket planes equal."""
+    import hashlib
+
+    from test_oracle_golden import assert_maps_match
+
+    g = np.load(golden_dir / "maps_planar.npz")
+    spec, out, inp, radius = CS.PLANAR_CASES[name]
+    xm, ym = V.get_map(CS.to_product(spec), radius=radius, size_input=inp, size_output=out)
+    s = CS.FULL_STRIDE
+    assert_maps_match(xm[::s], ym[::s], g[f"{name}__rows_x"], g[f"{name}__rows_y"], name + " rows")
+    assert_maps_match(xm[:, ::s], ym[:, ::s], g[f"{name}__cols_x"], g[f"{name}__cols_y"], name + " cols")
+    assert int(np.isnan(xm).sum()) == int(g[f"{name}__nan"])
+    assert hashlib.sha256(CS.buckets(xm).tobytes()).digest() == g[f"{name}__sha_bx"].tobytes()
+    assert hashlib.sha256(CS.buckets(ym).tobytes()).digest() == g[f"{name}__sha_by"].tobytes()
+
+
+PLANAR_KINDS = {
+    # the kernel family a bilinear PAIR of the chain must reach (a single image / a batch of three: mirror / batch likewise, or tile)
+    "apply_rectilinear": "mirror", "apply_stereographic": "mirror", "apply_equidistant": "mirror", "transformer_poly": "mirror",
+    "planar_nonsquare": "mirror",
+}
+
+
+@pytest.mark.parametrize("interp", [1, 4, 0, 2])
+@pytest.mark.parametrize("name", list(CS.PLANAR_CASES))
+def test_planar_and_general_modes_pixels_on_the_tile_kernels(V, oracle_mod, dev, name, interp):
+    """The reference's own test chains (tests/test_remapper.py:42-91) and their relatives at 1024 x 1024 on the LDS-tiled kernels: a
+    pair, a single image and a batch of three, every byte against the oracle (fp64 chain stage by stage + cv2.remap restated) --
+    including the NaN rim of FisheyeEncoder("orthographic") (border colour) -- and the kernel family asserted: never the generic kernel."""
+    from vr180_convert_amd import remapper
+
+    O = oracle_mod
+    spec, (wo, ho), (hs, ws), radius = CS.PLANAR_CASES[name]
+    imgs = [_noise(hs, ws, 900 + k) for k in range(3)]
+    for im in imgs:
+        im[:3], im[-3:], im[:, :3], im[:, -3:] = 0, 0, 0, 0
+    xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+    want = [O.remap(im, xm, ym, interp, 0, (4, 5, 6)) for im in imgs]
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    t = CS.to_product(spec)
+    for group in (srcs[:2], srcs[:1], srcs):
+        dsts = [torch.full((ho, wo, 3), 99, dtype=torch.uint8, device=dev) for _ in group]
+        paths = V.remap_tensors(t, group, dsts, radius=radius, interpolation=interp, boarder_value=(4, 5, 6))
+        assert paths in (["planar"], ["ray"]), paths
+        kind = remapper.last_launch_kinds()[0].split("+")[0]
+        assert kind in ("tile", "mirror", "batch"), (name, interp, len(group), kind)
+        if interp == 1 and len(group) == 2 and name in PLANAR_KINDS:
+            assert kind == PLANAR_KINDS[name], (name, kind)
+        for k, d in enumerate(dsts):
+            got = d.cpu().numpy()
+            assert np.array_equal(got, want[k]), (name, interp, len(group), k, int((got != want[k]).sum()))
+
+
+def test_the_references_ten_test_calls_as_written(V, oracle_mod, tmp_path):
+    """tests/test_remapper.py:42-109 of the reference, call for call -- apply() of one file with six encoders * FisheyeDecoder and with the
+    rotator / polynomial between equidistant encoder and decoder, apply_lr() with left_path == right_path (the split-in-halves branch)
+    -- with their arguments (256 x 256 outputs, the default Lanczos4 and BORDER_CONSTANT, radius="max"), which the reference only
+    smoke-tests: here every output byte is compared with the oracle's and the launch must have been a tile kernel."""
+    from vr180_convert_amd import _io, remapper
+    from vr180_convert_amd import transformer as T
+    from vr180_convert_amd.quat import from_euler_angles
+    from vr180_convert_amd.synth import pattern
+
+    O = oracle_mod
+    img = pattern(256, 256)
+    path = tmp_path / "test.png"
+    _io.imwrite(path, img)
+    img = _io.imread(path)
+    rot = ("rot", CS.ry(np.pi / 4))
+    calls = []
+    for fmt in ["rectilinear", "stereographic", "equidistant", "equisolid", "orthographic"]:
+        calls.append((T.FisheyeEncoder(fmt) * T.FisheyeDecoder("equidistant"), [("fisheye_enc", fmt), CS.EQUI]))
+    calls.append((T.EquirectangularEncoder() * T.FisheyeDecoder("equidistant"), [("equirect_enc", True), CS.EQUI]))
+    for tr, sp in ((T.Euclidean3DRotator(from_euler_angles(0.0, np.pi / 4, 0.0)), rot), (T.PolynomialScaler([0, 1, -0.1]), ("poly", [0, 1, -0.1]))):
+        calls.append((T.FisheyeEncoder("equidistant") * tr * T.FisheyeDecoder("equidistant"), [("fisheye_enc", "equidistant"), sp, CS.EQUI]))
+    for k, (t, spec) in enumerate(calls):
+        out = tmp_path / f"test.{k}.png"
+        got = V.apply(t, in_paths=path, out_paths=out, radius="max", size_output=(256, 256))[0]
+        kinds = [x.split("+")[0] for x in remapper.last_launch_kinds()]
+        assert kinds and all(x in ("tile", "mirror", "batch") for x in kinds), (spec, kinds)
+        want = O.apply(spec, [img], size_output=(256, 256), interpolation=4, radius="max")[0]
+        assert np.array_equal(got, want), (spec, int((got != want).sum()))
+        assert np.array_equal(_io.imread(out), want)
+    for tr, sp in ((T.Euclidean3DRotator(from_euler_angles(0.0, np.pi / 4, 0.0)), rot), (T.PolynomialScaler(), ("poly", [0, 1]))):
+        t = T.EquirectangularEncoder() * tr * T.FisheyeDecoder("equidistant")
+        spec = [("equirect_enc", True), sp, CS.EQUI]
+        out = tmp_path / f"test.lr.{tr.__class__.__name__}.png"
+        V.apply_lr(t, left_path=path, right_path=path, out_path=out, radius="max", size_output=(256, 256))
+        kinds = [x.split("+")[0] for x in remapper.last_launch_kinds()]
+        assert kinds and all(x in ("tile", "mirror", "batch") for x in kinds), (spec, kinds)
+        halves = [np.ascontiguousarray(img[:, :128]), np.ascontiguousarray(img[:, 128:])]
+        want = O.apply_lr(spec, halves[0], halves[1], size_output=(256, 256), interpolation=4, radius="max")
+        assert np.array_equal(_io.imread(out), want), spec
+
+
+# ---------------------------------------------------------------------------- radius="auto" on the device
+def _disc(h, w, r, seed, cx=None, cy=None):
+    """A noisy image circle of radius r on black (what get_radius looks for: transformer.py:125-140)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    cx, cy = (w / 2 if cx is None else cx), (h / 2 if cy is None else cy)
+    img = rng.integers(40, 256, (h, w, 3), dtype=np.uint8)
+    img[(xx - cx) ** 2 + (yy - cy) ** 2 > r * r] = 0
+    return img
+
+
+@pytest.mark.parametrize("interp", [4, 1])
+def test_auto_radius_on_the_device_equals_the_host_radius_path(V, oracle_mod, golden_dir, dev, interp):
+    """apply_lr_tensors(radius="auto", auto_radius_on_device=True): the estimate of every image stays on the device (v1c_get_radius_async),
+    a one-thread kernel takes the maximum and sets the Denormalize scale, the launch reduces its boxes itself -- no synchronisation, ONE
+    plan whatever the radius.  Bytes equal to the exact path (radius brought to the host: a plan per radius) and to the oracle, for the
+    reference's own get_radius fixtures (tests/golden/radius.npz: the NEGATIVE radius a clean disc yields -- the 180-degree flip
+    quirk --, speckle around the threshold) and discs of several radii through one and the same plan."""
+    from vr180_convert_amd import remapper
+
+    O = oracle_mod
+    g = np.load(golden_dir / "radius.npz")
+    t = CS.to_product([("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI])
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    pairs = [(g["landscape_img"], g["noisy_img"]), (g["noisy_img"], g["landscape_img"])]
+    pairs += [(_disc(480, 640, r0, 3), _disc(480, 640, r1, 4, cx=300)) for r0, r1 in ((200, 231), (150.5, 120), (239, 238))]
+    n_plans = None
+    for k, (a, b) in enumerate(pairs):
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        r_ref = max(O.get_radius(a), O.get_radius(b))  # get_radius_smart("auto"), remapper.py:83-84
+        la, lb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        got = V.apply_lr_tensors(t, la, lb, size_output=(640, 512), interpolation=interp, radius="auto", auto_radius_on_device=True)
+        kinds = remapper.last_launch_kinds()
+        assert kinds and kinds[0] in ("tile", "rot_pair"), kinds
+        exact = V.apply_lr_tensors(t, la, lb, size_output=(640, 512), interpolation=interp, radius="auto", auto_radius_on_device=False)
+        want = O.apply_lr(spec, a, b, size_output=(640, 512), interpolation=interp, radius=r_ref)
+        assert np.array_equal(exact.cpu().numpy(), want), (k, "exact path")
+        assert np.array_equal(got.cpu().numpy(), want), (k, r_ref, int((got.cpu().numpy() != want).sum()))
+    # the reference raises IndexError for an image without a black border (radius.npz: noborder_raises); the exact path does too,
+    # the device-resident one cannot -- the radius becomes NaN and the output the border colour
+    full = torch.full((480, 640, 3), 90, dtype=torch.uint8, device=dev)
+    disc = torch.from_numpy(_disc(480, 640, 200, 9)).to(dev)
+    with pytest.raises(IndexError):
+        V.apply_lr_tensors(t, full, disc, size_output=(640, 512), interpolation=interp, radius="auto", auto_radius_on_device=False)
+    out = V.apply_lr_tensors(t, full, disc, size_output=(640, 512), interpolation=interp, radius="auto", auto_radius_on_device=True,
+                             boarder_value=(1, 2, 3))
+    assert torch.equal(out, torch.tensor([1, 2, 3], dtype=torch.uint8, device=dev).expand_as(out))
+    # per-eye transformers: per-eye radius (remapper.py:460-473)
+    tl = CS.to_product([("equirect_enc", True), ("rot", CS.ry(0.05)), CS.EQUI])
+    a, b = _disc(480, 640, 180, 5), _disc(480, 640, 222, 6)
+    got = V.apply_lr_tensors((tl, t), torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), size_output=(640, 512), interpolation=interp,
+                             radius="auto", auto_radius_on_device=True)
+    want = O.apply_lr(([("equirect_enc", True), ("rot", CS.ry(0.05)), CS.EQUI], spec), a, b, size_output=(640, 512), interpolation=interp, radius="auto")
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_apply_lr_auto_radius_is_graph_capturable_end_to_end(V, oracle_mod, dev):
+    """radius="auto" -- the reference's default -- recorded into a graph: estimate, maximum, scale and remap are four launches and no
+    synchronisation.  The graph is replayed on NEW pixels with ANOTHER image circle in the same buffers: the radius follows the image."""
+    from vr180_convert_amd import remapper
+
+    O = oracle_mod
+    spec = [("equirect_enc", True), CS.EQUI]
+    t = CS.to_product(spec)
+    imgs = [(_disc(512, 512, 250, 1), _disc(512, 512, 240, 2)), (_disc(512, 512, 199.5, 3), _disc(512, 512, 221, 4))]
+    left, right = (torch.from_numpy(x).to(dev) for x in imgs[0])
+    out = torch.zeros((512, 1024, 3), dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        V.apply_lr_tensors(t, left, right, out=out, size_output=(512, 512), radius="auto", auto_radius_on_device=True)  # (creates the plan)
+    torch.cuda.synchronize()
+    n_plans = len(remapper._PLANS)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        V.apply_lr_tensors(t, left, right, out=out, size_output=(512, 512), radius="auto")  # (capturing: the device-resident form by itself)
+    for a, b in imgs[::-1] + imgs:
+        left.copy_(torch.from_numpy(a).to(dev)), right.copy_(torch.from_numpy(b).to(dev))
+        out.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = O.apply_lr(spec, a, b, size_output=(512, 512), interpolation=4, radius="auto")
+        assert np.array_equal(out.cpu().numpy(), want)
+    assert len(remapper._PLANS) == n_plans  # one plan served every radius
+
+
 def test_unit_ring_from_six_threads_without_syncs(V, oracle_mod, dev):
     """One plan, six threads with a stream each, eight back-to-back launches of 20 units per thread with nothing synchronised in
     between: up to 48 launches queue up against the ring's four slots.  A slot's bookkeeping is only complete once the event behind the

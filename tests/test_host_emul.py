@@ -43,7 +43,10 @@ def test_ray_path_expected_coverage(emul_lib, oracle_mod):
         "apply_equirectangular": (True, 0, False), "c2_poly": (True, 1, False), "c4_rot_poly": (True, 1, False),
         "c5_calib_left": (True, 0, False), "zoom": (True, 0, False), "nonsquare": (True, 0, False),
         "poly_c0": (True, 0, True), "poly_signchange": (True, 0, True), "back_hemisphere": (True, 0, True),
-        "apply_rectilinear": (False, 0, False), "rot_after_radial": (False, 0, False), "equirect_lat_x": (False, 0, False),
+        # round 5: chains that do not start with EquirectangularEncoder(is_latitude_y=True) (SURVEY.md 8a "planar mode")
+        "apply_rectilinear": (True, 0, False), "apply_orthographic": (True, 1, True), "transformer_poly": (True, 1, False),
+        "transformer_rotator": (True, 0, None), "rot_after_radial": (True, 0, False), "equirect_lat_x": (True, 0, False),
+        "equirect_decoder": (False, 0, False),
     }
     for name, (ray, var_w, fix) in expect.items():
         spec, out, inp, radius = CS.SMALL_CASES[name]
@@ -52,7 +55,45 @@ def test_ray_path_expected_coverage(emul_lib, oracle_mod):
         assert (rc == 0) == ray, name
         if ray:
             assert st[2] == var_w, name
-            assert (st[1] > 0) == fix, (name, st)
+            assert fix is None or (st[1] > 0) == fix, (name, st)
+
+
+def plan_info(E, ch, W, H):
+    out = (C.c_longlong * 12)()
+    assert E.emul_plan_info(C.byref(ch), W, H, out) == 0
+    keys = ["ok", "usable", "base", "gen_mode", "fn", "var_is_w", "n_int", "below_lv1", "below_lv2", "first_invalid", "shared_entry", "no_fixup"]
+    return dict(zip(keys, list(out)))
+
+
+@pytest.mark.parametrize("name", list(CS.PLANAR_CASES))
+def test_planar_and_general_modes_full_size_vs_reference(emul_lib, oracle_mod, golden_dir, name):
+    """The chains the fused path serves since round 5 -- planar (fisheye -> fisheye), is_latitude_y=False, a rotation behind radial
+    stages -- through the product's per-pixel code compiled for the host, at 1024 x 1024 and a non-square size: the bucket planes are
+    SHA-equal to the REFERENCE's get_map (tests/golden/make_golden.py planar), NaN pattern included (orthographic: the pixels the
+    reference makes NaN take the interpreter, which makes them NaN too)."""
+    g = np.load(golden_dir / "maps_planar.npz")
+    spec, out, inp, radius = CS.PLANAR_CASES[name]
+    ch = oracle_mod.chain_from_spec(spec, radius=radius, size_input=inp, size_output=out)
+    info = plan_info(emul_lib, ch, out[0], out[1])
+    assert info["ok"] and info["usable"], info
+    rc, xm, ym, st = emul_map(emul_lib, ch, out[0], out[1], 1)
+    assert rc == 0 and st[0] == 1
+    s = CS.FULL_STRIDE
+    assert_maps_match(xm[::s], ym[::s], g[f"{name}__rows_x"], g[f"{name}__rows_y"], name + " rows")
+    assert_maps_match(xm[:, ::s], ym[:, ::s], g[f"{name}__cols_x"], g[f"{name}__cols_y"], name + " cols")
+    assert int(np.isnan(xm).sum()) == int(g[f"{name}__nan"])
+    assert hashlib.sha256(CS.buckets(xm).tobytes()).digest() == g[f"{name}__sha_bx"].tobytes()
+    assert hashlib.sha256(CS.buckets(ym).tobytes()).digest() == g[f"{name}__sha_by"].tobytes()
+    if info["no_fixup"]:
+        assert st[1] == 0
+    # which form of the kernels the plan may use: unrotated planar chains whose composite is defined everywhere prove "one table entry
+    # per lane, no fix-up pass" like BASELINE's configurations do (mirror / batch kernels)
+    expect_fast = {"apply_rectilinear", "apply_stereographic", "apply_equidistant", "transformer_poly", "equirect_lat_x", "planar_nonsquare"}
+    if name in expect_fast:
+        assert info["shared_entry"] and info["no_fixup"], info
+    assert info["base"] == (0 if name == "rot_after_radial" else 2 if name.startswith("equirect_lat_x") else 1)
+    assert info["gen_mode"] == {"transformer_rotator": 2, "planar_rot_small_angle": 2, "rot_after_radial": 2, "equirect_lat_x": 1,
+                                "equirect_lat_x_rot": 1}.get(name, 0)
 
 
 @pytest.mark.parametrize("name", ["C1", "C2", "C3"])

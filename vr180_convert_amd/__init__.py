@@ -15,7 +15,8 @@ from .chain import (
     TransformerBase,
     ZoomTransformer,
 )
-from .remapper import anaglyph_tensors, apply, apply_lr, apply_lr_tensors, get_map, remap_tensors
+from .remapper import (anaglyph_tensors, apply, apply_lr, apply_lr_tensors, auto_radius_tensor, get_map, remap_tensors,
+                       remap_tensors_auto)
 from .sharding import remap_sharded
 
 __all__ = [
@@ -37,5 +38,7 @@ __all__ = [
     "apply_lr_tensors",
     "anaglyph_tensors",
     "remap_tensors",
+    "remap_tensors_auto",
+    "auto_radius_tensor",
     "remap_sharded",
 ]

@@ -368,4 +368,33 @@ hipError_t launch_get_radius(const uint8_t* img, int h, int w, int64_t pitch, in
     return hipGetLastError();
 }
 
+// ---- a radius that never leaves the device (v1c_plan_run_auto) ----
+// get_radius_smart("auto") = max over the images of get_radius (remapper.py:83-84); get_map gives the Denormalize stage scale = (radius,
+// radius) (remapper.py:55).  One thread takes the maximum of the n estimates v1c_get_radius_async left on the device (rad[2 k] = radius,
+// rad[2 k + 1] = 0 / 1 "no black border": the reference raises IndexError there -- the device path cannot, the radius becomes NaN and
+// every pixel the border colour), clamps it to the magnitude the plan's proofs were taken for and writes the four numbers of the
+// plan-resident context the kernels read: stream-ordered, graph-capturable, no host round trip.
+__global__ void k_patch_radius(KernelCtx* ctx, const double* __restrict__ rad, int n, double r_limit)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    double r = rad[0];
+    bool bad = rad[1] != 0.0;
+    for (int k = 1; k < n; k++) {
+        r = rad[2 * k] > r ? rad[2 * k] : r;  // Python's max(): keeps the first of equal values, NaN never wins
+        bad |= rad[2 * k + 1] != 0.0;
+    }
+    r = fmin(fmax(r, -r_limit), r_limit);
+    if (bad)
+        r = NAN;
+    ctx->ray.rx = r, ctx->ray.ry = r;
+    ctx->ray.rx32 = 32.0 * r, ctx->ray.ry32 = 32.0 * r;
+}
+
+hipError_t launch_patch_radius(KernelCtx* ctx_dev, const double* rad_dev, int n, double r_limit, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_patch_radius, dim3(1), dim3(64), 0, stream, ctx_dev, rad_dev, n, r_limit);
+    return hipGetLastError();
+}
+
 }  // namespace v1c

@@ -444,7 +444,7 @@ int tile_half_dwords(const void* host_boxes, size_t n_tiles)
     const TileBox* b = (const TileBox*)host_boxes;
     int m = 256;
     for (size_t i = 0; i < n_tiles; i++) {
-        if (b[i].cpr <= 0 || b[i].cpr > kMaxCpr || b[i].nrows * b[i].cpr > 1024)
+        if (b[i].cpr <= 0 || b[i].cpr > kMaxCpr || b[i].nrows * b[i].cpr > 2048)  // (the pair code stages up to 8 x 256 chunks: shared_map_tile)
             continue;
         const int need = b[i].nrows * (b[i].cpr * 4 + 4);
         if (need <= kMaxHalfDwords)
@@ -485,7 +485,7 @@ int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int 
     std::vector<float> cost(ntile);
     for (unsigned i = 0; i < ntile; i++) {
         const int need = b[i].cpr > 0 ? b[i].nrows * (b[i].cpr * 4 + 4) : 0;
-        const bool stageable = b[i].cpr > 0 && b[i].cpr <= kMaxCpr && b[i].nrows * b[i].cpr <= 1024 && need <= half_dwords;
+        const bool stageable = b[i].cpr > 0 && b[i].cpr <= kMaxCpr && b[i].nrows * b[i].cpr <= 2048 && need <= half_dwords;
         cost[i] = b[i].cpr <= 0 ? 0.5f : 1.0f + (stageable ? 0.0f : 4.0f) + (need > lean_half ? 0.5f : 0.0f) + (b[i].interior ? 0.0f : 0.5f) + (float)need / 16384.0f;
     }
     // candidates: one block, then strips of 16, 8, 4, 2 tile rows (forced: V1C_XCD_STRIPS = strips per XCD, rounded to
@@ -594,13 +594,18 @@ static void launch_boxes_k(const KernelCtx& c, const TileArgs& a, bool shared_en
         else                                                                                           \
             hipLaunchKernelGGL((k_tile_boxes<VW, RT, K, NT, 1>), grid, block, 0, stream, a);           \
     } while (0)
+    const bool gen = c.ray.gen_mode != 0;  // the general modes (lat_x, radial stages in front of the rotation): ROT = 2
     if (c.ray.var_is_w) {
-        if (rot)
+        if (gen)
+            V1C_BOXES(1, 2);
+        else if (rot)
             V1C_BOXES(1, 1);
         else
             V1C_BOXES(1, 0);
     } else {
-        if (rot)
+        if (gen)
+            V1C_BOXES(0, 2);
+        else if (rot)
             V1C_BOXES(0, 1);
         else
             V1C_BOXES(0, 0);
@@ -673,6 +678,8 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
     lean = lean && lean_raw_nwp > 0;  // (the register-staged lean kernel is an A/B partner: tuning build only)
 #endif
     lean = lean && units_dword_aligned(lu);
+    const bool gen = c.ray.gen_mode != 0;  // the general modes run the pair instantiation of k_ray_lin3_tile<..., ROT = 2> (plan-time boxes only)
+    lean = lean && !gen;
     // Whatever does not take the lean batch kernel (NEAREST, bicubic / Lanczos4, unaligned sources, one or two units left over) is served
     // TWO units per workgroup by the pair code: round 1 measured the general loop -- up to 8 units per workgroup, 100 - 124 VGPRs -- no
     // faster pair by pair (C3 277 against 267 us), and its 24 instantiations were the last kernels that spilled scalar registers into
@@ -762,7 +769,7 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
 #endif
 #define V1C_TILE_P(VW, RT, BX, OW, PR)                                                                                                \
     do {                                                                                                                              \
-        if constexpr (K == 2 && BX == 1) {                                                                                            \
+        if constexpr (K == 2 && BX == 1 && RT != 2) {                                                                                 \
             if (lean) {                                                                                                               \
                 /* (running the remaining tiles on a side stream, forked and joined with events so that their */                      \
                 /* latency-bound kernel overlaps the lean one, measured 4 % slower on C3 than back to back) */                        \
@@ -817,17 +824,30 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
     } while (0)
     if (!bx)
         use_rot = true;  // (units override the rotation: plan.hip passes any_rot || has_rot)
+    // (the general modes have no form without plan-time boxes: plan.hip sends units that override their rotation to the interpreter)
+#define V1C_TILE_GEN(VW)              \
+    do {                              \
+        if (shared_entry)             \
+            V1C_TILE_O(VW, 2, 1, 0);  \
+        else                          \
+            V1C_TILE_O(VW, 2, 1, 1);  \
+    } while (0)
     if (c.ray.var_is_w) {
-        if (use_rot)
+        if (gen && bx)
+            V1C_TILE_GEN(1);
+        else if (use_rot)
             V1C_TILE(1, 1);
         else
             V1C_TILE(1, 0);
     } else {
-        if (use_rot)
+        if (gen && bx)
+            V1C_TILE_GEN(0);
+        else if (use_rot)
             V1C_TILE(0, 1);
         else
             V1C_TILE(0, 0);
     }
+#undef V1C_TILE_GEN
 #undef V1C_TILE
 #undef V1C_TILE_O
 #undef V1C_TILE_P

@@ -209,6 +209,8 @@ struct v1c_plan {
     double ray_step = 0;                // largest angle between horizontally adjacent output rays
     int mp_valid_upto = -1;             // m-polynomial table (when uploaded): intervals 0 .. this are all valid at the
                                         // level a lane needs (shared_entry_level)
+    int gen_mode = 0;                   // RayParams::gen_mode of the plan (general modes: no per-unit rotations, no cn / mirror kernels)
+    TableStep step;                     // how far the main table's variable moves between adjacent output pixels
     double m_reach_norot = 0;           // largest m an unrotated ray reaches
     std::vector<double> g_bounds;       // radial_table_g_bounds(table): |G| over the entries 0 .. i
     // The tile-flag words are per plan: a ray pass sets them, the fix-up pass behind it consumes and clears
@@ -220,6 +222,13 @@ struct v1c_plan {
     hipStream_t flags_stream = nullptr;
     bool flags_pending = false;
     std::atomic<int> last_launch{-1};   // V1C_LAUNCH_* of the most recent launch group of v1c_plan_run (tests: v1c_plan_last_launch)
+    // v1c_plan_run_auto: a second device copy of the context whose Denormalize scale a small kernel rewrites from a device-resident radius
+    // in front of every such launch (created on first use); launches on different streams are ordered by an event, like the flag words
+    KernelCtx* ctx_dyn = nullptr;
+    std::mutex dyn_mu;
+    hipEvent_t dyn_ev = nullptr;
+    hipStream_t dyn_stream = nullptr;
+    bool dyn_pending = false;
     std::vector<void*> allocs;
 };
 
@@ -296,6 +305,8 @@ extern "C" int v1c_plan_destroy(v1c_plan* p)
         (void)hipFree(d);
     if (p->flags_ev)
         (void)hipEventDestroy(p->flags_ev);
+    if (p->dyn_ev)
+        (void)hipEventDestroy(p->dyn_ev);
     for (hipEvent_t e : p->ring_ev)
         if (e)
             (void)hipEventDestroy(e);
@@ -331,8 +342,12 @@ static int plan_common(v1c_plan* p, int device, int src_h, int src_w, int dst_h,
 namespace {
 struct FitKey {
     std::string ops;  // the radial stages, byte for byte
-    int n_int;
-    bool operator==(const FitKey& o) const { return n_int == o.n_int && ops == o.ops; }
+    int n_int, fn, force_var;
+    double m_max, m_front;
+    bool operator==(const FitKey& o) const
+    {
+        return n_int == o.n_int && fn == o.fn && force_var == o.force_var && m_max == o.m_max && m_front == o.m_front && ops == o.ops;
+    }
 };
 struct FitEntry {
     FitKey key;
@@ -342,10 +357,10 @@ struct FitEntry {
 std::mutex g_fit_mu;
 std::list<FitEntry> g_fits;  // front = most recently used
 
-FitKey fit_key(const std::vector<v1c_op>& radial, int n_int)
+FitKey fit_key(const std::vector<v1c_op>& radial, int n_int, int fn, double m_max, int force_var, double m_front = 0)
 {
     FitKey k;
-    k.n_int = n_int;
+    k.n_int = n_int, k.fn = fn, k.m_max = m_max, k.force_var = force_var, k.m_front = m_front;
     if (!radial.empty())
         k.ops.assign((const char*)radial.data(), radial.size() * sizeof(v1c_op));
     return k;
@@ -361,22 +376,25 @@ FitEntry& fit_entry(const FitKey& key, Make make)
             return g_fits.front();
         }
     g_fits.push_front(FitEntry{key, make(), nullptr});
-    while (g_fits.size() > 16)
+    while (g_fits.size() > 24)
         g_fits.pop_back();
     return g_fits.front();
 }
 }  // namespace
 
-static RadialTable cached_radial_table(const std::vector<v1c_op>& radial, int n_int)
+static RadialTable cached_radial_table(const TableSpec& sp)
 {
     std::lock_guard<std::mutex> lk(g_fit_mu);
-    return *fit_entry(fit_key(radial, n_int), [&] { return std::make_shared<const RadialTable>(build_radial_table(radial, n_int)); }).table;
+    return *fit_entry(fit_key(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front), [&] {
+                return std::make_shared<const RadialTable>(build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front));
+            }).table;
 }
 
+// (the key of the table the polynomials belong to: the spec it was fitted from, variable chosen)
 static MPolyTable cached_mpoly_table(const std::vector<v1c_op>& radial, const RadialTable& table)
 {
     std::lock_guard<std::mutex> lk(g_fit_mu);
-    FitEntry& e = fit_entry(fit_key(radial, table.n_int), [&] { return std::make_shared<const RadialTable>(table); });
+    FitEntry& e = fit_entry(fit_key(radial, table.n_int, table.fn, table.m_max, -2 - table.var_is_w), [&] { return std::make_shared<const RadialTable>(table); });
     if (!e.mpoly)
         e.mpoly = std::make_shared<const MPolyTable>(fit_mpoly_table(radial, table));
     return *e.mpoly;
@@ -434,15 +452,17 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
         p->ctx.chain = (const v1c_chain*)d;
     }
 
-    p->ana = analyze_chain(*chain);
+    RayPlanHost H = build_ray_plan_host(*chain, dst_w, dst_h, [](const TableSpec& sp) { return cached_radial_table(sp); });
+    p->ana = H.a;
     if (p->ana.ok) {
-        // NormalizeTransformer + lon = x * pi/2: adjacent output pixels' rays are <= pi / s apart
-        p->ray_step = 3.14159265358979323846 / p->ana.norm_s;
-        p->table = cached_radial_table(p->ana.radial, table_intervals_for(p->ray_step));
-        if (ray_table_usable(p->table)) {
+        p->ray_step = H.ray_step;
+        p->step = H.step;
+        p->table = H.table;
+        p->gen_mode = H.a.gen_mode;
+        if (H.usable) {
             p->mode = MODE_RAY;
             const RayAnalysis& a = p->ana;
-            const RayHostTables ht = build_ray_host_tables(a, dst_w, dst_h);
+            const RayHostTables& ht = H.ht;
             RayParams& r = p->ctx.ray;
             // the six row / column tables in ONE buffer, in the order col_s | col_c | col_h (wpad entries each) | row_s | row_c | row_h
             // (dst_h each): the mirror kernels get its base among their preloaded arguments and derive the others (tile_device.hpp:
@@ -461,6 +481,15 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 r.col_s = base, r.col_c = base + wpad, r.col_h = base + 2 * wpad;
                 r.row_s = base + 3 * wpad, r.row_c = base + 3 * wpad + hh, r.row_h = base + 3 * wpad + 2 * hh;
             }
+            r.gen_mode = a.gen_mode;
+            r.pre_s = r.pre_c = nullptr, r.pre_var_is_w = 0, r.pre_inv_step = 0, r.pre_n_int = 0, r.pad3 = 0;
+            if (H.has_pre) {
+                if ((rc = upload(p, H.pre_s.coef, &r.pre_s)) || (rc = upload(p, H.pre_c.coef, &r.pre_c))) {
+                    v1c_plan_destroy(p);
+                    return rc;
+                }
+                r.pre_var_is_w = H.pre_s.var_is_w, r.pre_inv_step = H.pre_s.inv_step, r.pre_n_int = H.pre_s.n_int;
+            }
             r.inv_step = p->table.inv_step;
             r.n_int = p->table.n_int;
             r.var_is_w = p->table.var_is_w;
@@ -470,19 +499,20 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             r.rx = a.rx, r.ry = a.ry, r.cx = a.cx, r.cy = a.cy;
             r.rx32 = 32.0 * a.rx, r.ry32 = 32.0 * a.ry, r.cx32 = 32.0 * a.cx, r.cy32 = 32.0 * a.cy;
             r.n_int_f = (double)r.n_int;
-            p->m_reach_norot = ht.m_reach;
+            p->m_reach_norot = H.reach_norot;
             p->g_bounds = radial_table_g_bounds(p->table);
-            p->ray_no_rot_safe = !a.has_rot && ray_reach_is_safe(p->table, ht.m_reach);
+            p->ray_no_rot_safe = !a.has_rot && ray_reach_is_safe(p->table, H.reach_norot);
             p->front_hemisphere = ht.front_hemisphere;
-            p->ray_plan_rot_safe = a.has_rot && ht.front_hemisphere && ray_reach_is_safe(p->table, rotated_reach(a.rot));
-            p->plan_shared_entry = (p->ray_no_rot_safe && ray_entry_is_shared(p->table, ht.m_reach, p->ray_step)) ||
-                                   (p->ray_plan_rot_safe && ray_entry_is_shared(p->table, rotated_reach(a.rot), p->ray_step));
+            // (general modes: the S / Cm tables must cover every pixel too; their rotated reach is the cone's, radial_fit.hpp)
+            p->ray_plan_rot_safe = a.has_rot && H.reach_rot < 2.0 && H.pre_safe && ray_reach_is_safe(p->table, H.reach_rot);
+            p->plan_shared_entry = (p->ray_no_rot_safe && ray_entry_is_shared(p->table, H.reach_norot, p->step)) ||
+                                   (p->ray_plan_rot_safe && ray_entry_is_shared(p->table, H.reach_rot, p->step));
             // polynomials in m on the same intervals: tiles whose intervals all qualify need no fp64
             // square root (w-tables) and no fp64 index arithmetic (tile_device.hpp, lane_coords<..., MPOLY>)
             r.radial_m = nullptr, r.mp_first_ok = r.n_int, r.inv_step_f = (float)r.inv_step;
             if (p->plan_shared_entry && !p->disable_shared_entry && !p->disable_mpoly) {
-                const double reach = a.has_rot ? rotated_reach(a.rot) : ht.m_reach;
-                const int lv = shared_entry_level(p->table, p->ray_step);
+                const double reach = a.has_rot ? H.reach_rot : H.reach_norot;
+                const int lv = shared_entry_level(p->table, p->step);
                 const MPolyTable mp = cached_mpoly_table(p->ana.radial, p->table);
                 const int first = lv > 0 ? mpoly_first_ok(mp, p->table, reach, lv) : r.n_int;
                 if (first < r.n_int / 2) {  // worth a second table: most of the image qualifies
@@ -501,10 +531,10 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                              r.mp_first_ok, r.n_int);
             if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                 std::fprintf(stderr,
-                             "[v1c] ray plan: var=%s n_int=%d first_invalid=%d first_below_level1=%d first_below_level2=%d m_reach=%.6f "
-                             "ray_step=%.3e no_rot_safe=%d plan_rot_safe=%d shared_entry=%d\n",
-                             r.var_is_w ? "w" : "m", r.n_int, p->table.first_invalid, p->table.first_below_level[1], p->table.first_below_level[2],
-                             ht.m_reach, p->ray_step, (int)p->ray_no_rot_safe, (int)p->ray_plan_rot_safe, (int)p->plan_shared_entry);
+                             "[v1c] ray plan: base=%d gen_mode=%d fn=%d var=%s n_int=%d first_invalid=%d first_below_level1=%d first_below_level2=%d m_reach=%.6f "
+                             "reach_rot=%.6f step=%.3e no_rot_safe=%d plan_rot_safe=%d shared_entry=%d pre=%d pre_safe=%d\n",
+                             a.base, a.gen_mode, p->table.fn, r.var_is_w ? "w" : "m", r.n_int, p->table.first_invalid, p->table.first_below_level[1], p->table.first_below_level[2],
+                             ht.m_reach, H.reach_rot, p->step.of(p->table), (int)p->ray_no_rot_safe, (int)p->ray_plan_rot_safe, (int)p->plan_shared_entry, (int)H.has_pre, (int)H.pre_safe);
             // tile flags for kMaxUnitsPerLaunch units
             void* d = nullptr;
             const size_t nflag = (size_t)p->tiles * kMaxUnitsPerLaunch * sizeof(uint32_t);
@@ -557,7 +587,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
             }
             // source boxes of the tiled kernel, computed once (BGR, constant border, linear/cubic/lanczos4)
             const Geom& g = p->ctx.g;
-            if (cn_kernel_supports(g) && p->plan_shared_entry && !p->disable_shared_entry) {
+            if (cn_kernel_supports(g) && p->plan_shared_entry && !p->disable_shared_entry && p->gen_mode == 0) {
                 // grayscale / BGRA: the same boxes, consumed by k_ray_lin_cn
                 void* bx = nullptr;
                 e = hipMalloc(&bx, tile_box_bytes(g));
@@ -737,7 +767,7 @@ extern "C" int v1c_plan_path(const v1c_plan* p)
 {
     if (!p)
         return fail(V1C_E_INVALID, "plan is NULL");
-    return p->mode == MODE_RAY ? 1 : 0;
+    return p->mode == MODE_RAY ? (p->ana.base == 1 ? 2 : 1) : 0;
 }
 
 static int fill_unit(const v1c_plan* p, const v1c_unit& in, DevUnit& out)
@@ -780,7 +810,8 @@ struct LaunchPlan {
     bool coords_bounded = false; // every |32 x|, |32 y| < 2^21
 };
 
-static LaunchPlan decide_launch(const v1c_plan* p, const DevUnit* du, int n)
+// `r32_limit` > 0: bound the coordinates for |32 radius| up to it instead of the plan's own Denormalize scale (v1c_plan_run_auto)
+static LaunchPlan decide_launch(const v1c_plan* p, const DevUnit* du, int n, double r32_limit = 0)
 {
     LaunchPlan d;
     for (int k = 0; k < n; k++)
@@ -812,10 +843,11 @@ static LaunchPlan decide_launch(const v1c_plan* p, const DevUnit* du, int n)
             if (d.coords_bounded) {
                 const RayParams& rp = p->ctx.ray;
                 const double gb = covered ? radial_table_g_bound(p->table, p->g_bounds, rotated ? rotated_reach(r) : p->m_reach_norot) : INFINITY;
-                d.coords_bounded = gb * std::fabs(rp.rx32) + std::fabs(rp.cx32) < 2097152.0 && gb * std::fabs(rp.ry32) + std::fabs(rp.cy32) < 2097152.0;
+                const double ax = r32_limit > 0 ? r32_limit : std::fabs(rp.rx32), ay = r32_limit > 0 ? r32_limit : std::fabs(rp.ry32);
+                d.coords_bounded = gb * ax + std::fabs(rp.cx32) < 2097152.0 && gb * ay + std::fabs(rp.cy32) < 2097152.0;
             }
             d.shared_entry = d.shared_entry && covered &&
-                             (rotated ? ray_entry_is_shared(p->table, rotated_reach(r), p->ray_step) : p->plan_shared_entry);
+                             (rotated ? ray_entry_is_shared(p->table, rotated_reach(r), p->step) : p->plan_shared_entry);
             if (d.mpoly_all) {  // (same interval bound as mpoly_first_ok: reach + 2 for the fp32 index)
                 const double mr = rotated ? rotated_reach(r) : p->m_reach_norot;
                 const double u_reach = (p->table.var_is_w ? std::sqrt(mr / 2) : mr) * (1 + 1e-9);
@@ -911,7 +943,8 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         // must follow (its flag words cover kMaxUnitsPerLaunch unit slots) or the generic kernels serve it (by-value arguments)
         int n = std::min(v1c_plan::kRingUnits, n_units - base);
         LaunchPlan d = decide_launch(p, du + base, n);
-        const bool literal = d.any_rot && p->n_rot_stages > 1;
+        // (the general modes -- lat_x, radial stages in front of the rotation -- have their reach, boxes and proofs for the plan's own rotation only)
+        const bool literal = d.any_rot && (p->n_rot_stages > 1 || p->gen_mode != 0);
         if (n > kMaxUnitsPerLaunch && (literal || !d.fast || d.need_fixup || p->ctx.g.cn != 3)) {
             n = kMaxUnitsPerLaunch;
             d = decide_launch(p, du + base, n);
@@ -920,7 +953,7 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         base += n;
         // units overriding one of SEVERAL rotate stages take the interpreter (rare); all other
         // cases run the ray pass and, unless provably unnecessary, the fix-up pass
-        if (d.any_rot && p->n_rot_stages > 1) {
+        if (literal) {
             HIP_TRY(launch_remap(MODE_LITERAL, p->ctx, unit_args(u, n), n, st));
             p->last_launch.store(V1C_LAUNCH_GENERIC, std::memory_order_relaxed);
             continue;
@@ -994,6 +1027,73 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
     return V1C_OK;
 }
 
+// The same launch with the radius taken from device memory: remapper.py:379-386 with radius="auto" -- get_radius_smart's max over the
+// images of get_radius (:83-84) becomes the Denormalize scale (radius, radius) of get_map (:55) -- without the value ever visiting the
+// host.  `rad_dev`: n_rad (radius, status) pairs as v1c_get_radius_async writes them.  Nothing of the plan that depends on the radius is
+// used: the launch runs the kernels that reduce their source boxes themselves (the per-unit-rotation family, identity where nothing
+// rotates), reads the scale from a second plan-resident context a one-thread kernel has just rewritten, and is only taken when the
+// plan proves -- for ANY radius up to r_limit in magnitude -- that no fix-up pass is needed.  Launch-only: graph-capturable.
+extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* units, int n_units, const double* rad_dev, int n_rad)
+{
+    if (!p || !units || n_units <= 0 || !rad_dev || n_rad <= 0)
+        return fail(V1C_E_INVALID, "v1c_plan_run_auto: bad arguments");
+    if (n_units > kInlineUnits)
+        return fail(V1C_E_UNSUPPORTED, "v1c_plan_run_auto: at most 16 units per call");
+    if (p->mode != MODE_RAY || p->gen_mode != 0 || p->ana.base != 0 || p->n_rot_stages > 1 || p->disable_fast)
+        return fail(V1C_E_UNSUPPORTED, "v1c_plan_run_auto: chains of the form EquirectangularEncoder() * [one rotation] * radial stages only");
+    DeviceGuard dg(p->device);
+    if (!dg.ok)
+        return fail(V1C_E_NODEVICE, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    const Geom& g = p->ctx.g;
+    DevUnit du[kInlineUnits];
+    bool aligned = true;
+    for (int k = 0; k < n_units; k++) {
+        int rc = fill_unit(p, units[k], du[k]);
+        if (rc)
+            return rc;
+        if (!du[k].has_rot && !p->ana.has_rot)
+            for (int q = 0; q < 9; q++)
+                du[k].rot[q] = (q % 4 == 0) ? 1.0 : 0.0;
+        du[k].has_rot = 1;  // (every unit carries its effective rotation: the kernels without plan-time boxes read it)
+        aligned = aligned && ((((uintptr_t)du[k].src) | (uintptr_t)du[k].src_pitch) & 3u) == 0;
+    }
+    // any radius a caller can mean: the image circle a few times the source's size at most (the patch kernel clamps to it)
+    const double r_limit = 4.0 * (double)std::max(g.src_h, g.src_w);
+    const LaunchPlan d = decide_launch(p, du, n_units, 32.0 * r_limit);
+    if (!d.fast || d.need_fixup)
+        return fail(V1C_E_UNSUPPORTED, "v1c_plan_run_auto: this chain needs a fix-up pass (or 64-bit offsets): use the radius on the host");
+    const bool shared = d.shared_entry && !p->disable_shared_entry;
+    if (g.cn != 3 && !(shared && aligned && cn_kernel_supports(g)))
+        return fail(V1C_E_UNSUPPORTED, "v1c_plan_run_auto: grayscale / BGRA need dword-aligned sources and one table entry per lane");
+    std::lock_guard<std::mutex> lk(p->dyn_mu);
+    if (!p->ctx_dyn) {
+        void* dctx = nullptr;
+        HIP_TRY(hipMalloc(&dctx, sizeof(KernelCtx)));
+        p->allocs.push_back(dctx);
+        HIP_TRY(hipMemcpy(dctx, &p->ctx, sizeof(KernelCtx), hipMemcpyHostToDevice));
+        HIP_TRY(hipEventCreateWithFlags(&p->dyn_ev, hipEventDisableTiming));
+        p->ctx_dyn = (KernelCtx*)dctx;
+    }
+    if (p->dyn_pending && p->dyn_stream != st)
+        HIP_TRY(hipStreamWaitEvent(st, p->dyn_ev, 0));
+    HIP_TRY(launch_patch_radius(p->ctx_dyn, rad_dev, n_rad, r_limit, st));
+    LaunchUnits lu{du, nullptr, n_units};
+    int kind = V1C_LAUNCH_GENERIC;
+    if (g.cn != 3) {
+        kind = V1C_LAUNCH_CN_ROT;
+        HIP_TRY(launch_ray_lin_cn(p->ctx, p->ctx_dyn, lu, nullptr, true, nullptr, 12, st));
+    } else {
+        kind = V1C_LAUNCH_TILE;
+        HIP_TRY(launch_ray_lin3_tile(p->ctx, p->ctx_dyn, lu, nullptr, true, nullptr, p->half_dwords, shared, d.mpoly_all && !p->disable_mpoly, nullptr, 0,
+                                     p->lean_half, p->strip_len, p->lean_raw_nwp, st, d.coords_bounded && !p->disable_coords_bounded, &kind));
+    }
+    HIP_TRY(hipEventRecord(p->dyn_ev, st));
+    p->dyn_stream = st, p->dyn_pending = true;
+    p->last_launch.store(kind, std::memory_order_relaxed);
+    return V1C_OK;
+}
+
 extern "C" int v1c_plan_get_map(v1c_plan* p, void* stream, float* xmap, float* ymap, int64_t map_pitch,
                                 const double* rot_or_null)
 {
@@ -1013,7 +1113,7 @@ extern "C" int v1c_plan_get_map(v1c_plan* p, void* stream, float* xmap, float* y
         ua.u[0].has_rot = 1;
         for (int q = 0; q < 9; q++)
             ua.u[0].rot[q] = rot_or_null[q];
-        if (p->n_rot_stages > 1)
+        if (p->n_rot_stages > 1 || p->gen_mode != 0)
             mode = MODE_LITERAL;
     }
     HIP_TRY(launch_get_map(mode, p->ctx, ua, xmap, ymap, map_pitch, (hipStream_t)stream));

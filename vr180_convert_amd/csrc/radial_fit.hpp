@@ -26,16 +26,40 @@
 
 namespace v1c {
 
+// Chain shapes the fused path serves (everything else: the fp64 interpreter), with B = the stage behind Normalize:
+//   base 0: B = EquirectangularEncoder(is_latitude_y=True)  (transformer.py:546-555)  -- BASELINE's configurations
+//   base 1: B = nothing: the normalised plane point itself ("planar": FisheyeEncoder(...) * ... chains; 7 of the
+//           reference's 10 test chains, tests/test_remapper.py:42-91)
+//   base 2: B = EquirectangularEncoder(is_latitude_y=False) (transformer.py:557-566)
+// followed by   (Radial|Zoom)* [`pre`]   Rotate*   (Radial|Zoom)* [`radial`]   Denormalize.
+// Without a rotation everything radial is one composite (`radial`; `pre` stays empty).  With a rotation behind radial stages (`pre`
+// not empty: base 0 / 1 only) the ray enters 3-D through v = (sin t d_x, sin t d_y, cos t), t = F_pre(theta) (transformer.py:502-507):
+// RayParams::gen_mode 2; base 2 runs gen_mode 1.
 struct RayAnalysis {
-    bool ok = false;         // chain has the shape the ray kernel handles
-    bool has_rot = false;
+    bool ok = false;         // chain has a shape the fused kernels handle
+    bool has_rot = false;    // a rotation applies in the kernels (gen modes: always, identity if the chain has none)
+    int base = 0;            // 0 equirect lat_y, 1 planar, 2 equirect lat_x
+    int gen_mode = 0;        // RayParams::gen_mode: 0 classic, 1 lat_x, 2 pre-rotation radial stages
     double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // composition of consecutive rotate stages
     double norm_cx = 0, norm_cy = 0, norm_s = 1;  // Normalize
     double rx = 1, ry = 1, cx = 0, cy = 0;        // Denormalize
-    std::vector<v1c_op> radial;                   // radial / zoom stages, in order
+    std::vector<v1c_op> pre;                      // radial / zoom stages in front of the rotation (gen_mode 2)
+    std::vector<v1c_op> radial;                   // radial / zoom stages behind it (all of them when nothing rotates)
+};
+
+// what a table tabulates, as a function of the table variable u (m, or w = sqrt(m / 2)); F = composite of the stages given
+enum {
+    FN_RAY_G = 0,     // F(theta) / sin(theta),        m = 1 - cos(theta): the ray path's radial factor
+    FN_PLANAR_G = 1,  // F(t) / t,                     m = t^2 = xn^2 + yn^2: planar chains without a rotation
+    FN_PLANAR_S = 2,  // sin(F(t)) / t                 } the ray a planar point enters 3-D with:
+    FN_PLANAR_CM = 3, // 1 - cos(F(t))                 } v = (S xn, S yn, 1 - Cm)
+    FN_RAY_S = 4,     // sin(F(theta)) / sin(theta)    } the same behind an EquirectangularEncoder: v = (S v_x, S v_y, 1 - Cm)
+    FN_RAY_CM = 5,    // 1 - cos(F(theta))
 };
 
 struct RadialTable {
+    int fn = FN_RAY_G;
+    double m_max = 0;       // the table covers m in [0, m_max]
     int var_is_w = 0;
     int n_int = 0;
     double inv_step = 0;
@@ -50,21 +74,32 @@ struct RadialTable {
 constexpr double kTableMMax = 1.9375;  // theta up to ~159.6 deg
 constexpr int kTableIntervals = 1024;
 
-// Does the chain look like Normalize, EquirectEnc(lat_y), Rotate*, (Radial|Zoom)*, Denormalize ?
+inline bool is_radial_op(const v1c_op& op)
+{
+    return op.opcode == V1C_OP_RADIAL || op.opcode == V1C_OP_ZOOM || op.opcode == V1C_OP_ZOOM_INV;
+}
+
+// Does the chain look like Normalize, [EquirectEnc], (Radial|Zoom)*, Rotate*, (Radial|Zoom)*, Denormalize ?  (RayAnalysis)
 inline RayAnalysis analyze_chain(const v1c_chain& ch)
 {
     RayAnalysis a;
     const int n = ch.n_ops;
-    if (n < 3 || ch.ops[0].opcode != V1C_OP_NORMALIZE || ch.ops[n - 1].opcode != V1C_OP_DENORMALIZE)
-        return a;
-    if (ch.ops[1].opcode != V1C_OP_EQUIRECT_ENC || ch.ops[1].iparam != 1)
+    if (n < 2 || ch.ops[0].opcode != V1C_OP_NORMALIZE || ch.ops[n - 1].opcode != V1C_OP_DENORMALIZE)
         return a;
     a.norm_cx = ch.ops[0].p[0];
     a.norm_cy = ch.ops[0].p[1];
     a.norm_s = ch.ops[0].p[2];
     const v1c_op& dn = ch.ops[n - 1];
     a.rx = dn.p[0], a.ry = dn.p[1], a.cx = dn.p[2], a.cy = dn.p[3];
-    int k = 2;
+    int k = 1;
+    if (n >= 3 && ch.ops[1].opcode == V1C_OP_EQUIRECT_ENC) {
+        a.base = ch.ops[1].iparam == 1 ? 0 : 2;
+        k = 2;
+    } else {
+        a.base = 1;
+    }
+    for (; k < n - 1 && is_radial_op(ch.ops[k]); k++)
+        a.pre.push_back(ch.ops[k]);
     for (; k < n - 1 && ch.ops[k].opcode == V1C_OP_ROTATE; k++) {
         // v' = M_k (M_{k-1} ... v): left-multiply
         const double* m = ch.ops[k].p;
@@ -78,10 +113,21 @@ inline RayAnalysis analyze_chain(const v1c_chain& ch)
     }
     for (; k < n - 1; k++) {
         const v1c_op& op = ch.ops[k];
-        if (op.opcode == V1C_OP_RADIAL || op.opcode == V1C_OP_ZOOM || op.opcode == V1C_OP_ZOOM_INV)
+        if (is_radial_op(op))
             a.radial.push_back(op);
         else
-            return a;  // rotation after a radial stage, decoders ...: literal path
+            return a;  // a second rotation behind radial stages, decoders ...: literal path
+    }
+    if (!a.has_rot) {  // nothing rotates: one radial composite
+        a.radial.insert(a.radial.begin(), a.pre.begin(), a.pre.end());
+        a.pre.clear();
+    }
+    if (a.base == 2) {
+        if (!a.pre.empty())
+            return a;  // (lat_x, radial stages, rotation: not served)
+        a.gen_mode = 1, a.has_rot = true;  // identity unless the chain rotates
+    } else if (a.has_rot && (a.base == 1 || !a.pre.empty())) {
+        a.gen_mode = 2;  // the ray is entered through the S / Cm tables (for a planar base also with F_pre = identity)
     }
     a.ok = true;
     return a;
@@ -136,18 +182,40 @@ inline bool composite_F(const std::vector<v1c_op>& st, long double theta, long d
     return true;
 }
 
+// value of table function `fn` at table variable u (m when !var_is_w, else w = sqrt(m / 2))
+inline bool table_fn(const std::vector<v1c_op>& st, int fn, int var_is_w, long double u, long double& g)
+{
+    if (!(u > 0))
+        return false;
+    long double t, den;  // argument of the composite and the denominator
+    if (fn == FN_RAY_G || fn == FN_RAY_S || fn == FN_RAY_CM) {
+        const long double w = var_is_w ? u : sqrtl(u / 2);
+        if (!(w < 1))
+            return false;
+        t = 2 * asinl(w);                             // theta
+        den = 2 * w * sqrtl((1 - w) * (1 + w));       // sin(theta)
+    } else {
+        t = var_is_w ? u * (long double)1.41421356237309504880168872420969808L : sqrtl(u);  // m = t^2, w = t / sqrt(2)
+        den = t;
+    }
+    long double f;
+    if (!composite_F(st, t, f))
+        return false;
+    switch (fn) {
+    case FN_RAY_G:
+    case FN_PLANAR_G: g = f / den; break;
+    case FN_RAY_S:
+    case FN_PLANAR_S: g = sinl(f) / den; break;
+    default: {
+        const long double sh = sinl(f / 2);
+        g = 2 * sh * sh;
+    }
+    }
+    return std::isfinite((double)g);
+}
 inline bool G_of_u(const std::vector<v1c_op>& st, int var_is_w, long double u, long double& g)
 {
-    long double w = var_is_w ? u : sqrtl(u / 2);
-    if (!(w > 0) || !(w < 1))
-        return false;
-    const long double theta = 2 * asinl(w);
-    const long double rho = 2 * w * sqrtl((1 - w) * (1 + w));  // sin(theta)
-    long double f;
-    if (!composite_F(st, theta, f))
-        return false;
-    g = f / rho;
-    return std::isfinite((double)g);
+    return table_fn(st, FN_RAY_G, var_is_w, u, g);
 }
 
 // solve V c = y, V[i][k] = z_i^k, (n x n), long double, partial pivoting
@@ -228,12 +296,14 @@ inline void fit_parallel_for(int n, F&& body)
 // tolerance).  The level is stored in the two low mantissa bits of c7; the DOUBLE Horner the
 // kernels run is validated with those bits already in place.  tile_device.hpp uses pixel 1's
 // entry for all 4 pixels of a lane wherever the level allows.
-inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w, int n_int = kTableIntervals)
+inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w, int n_int = kTableIntervals, int fn = FN_RAY_G,
+                                    double m_max = kTableMMax)
 {
     RadialTable T;
+    T.fn = fn, T.m_max = m_max;
     T.var_is_w = var_is_w;
     T.n_int = n_int;
-    T.u_max = var_is_w ? std::sqrt(kTableMMax / 2) : kTableMMax;
+    T.u_max = var_is_w ? std::sqrt(m_max / 2) : m_max;
     // a step that is exactly representable keeps t = u * inv_step monotone and cheap
     T.inv_step = std::ldexp(std::floor(std::ldexp(T.n_int / T.u_max, 20)), -20);
     const long double step = 1.0L / (long double)T.inv_step;
@@ -257,7 +327,7 @@ inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w,
             bool good = true;
             for (int k = 0; k < n && good; k++) {
                 zn[k] = 0.5L * (zlo + zhi) + 0.5L * (zhi - zlo) * cheb[k];
-                good = G_of_u(st, var_is_w, a + step * (zn[k] + 0.5L), y[k]);
+                good = table_fn(st, fn, var_is_w, a + step * (zn[k] + 0.5L), y[k]);
             }
             if (!good || !solve_vandermonde(n, zn, y, c))
                 continue;
@@ -272,7 +342,7 @@ inline RadialTable fit_radial_table(const std::vector<v1c_op>& st, int var_is_w,
             std::vector<long double> gt(ntest), zt(ntest);
             for (int q = 0; q < ntest && good; q++) {
                 zt[q] = zlo + (zhi - zlo) * (q + 0.5L) / ntest;
-                good = G_of_u(st, var_is_w, a + step * (zt[q] + 0.5L), gt[q]);
+                good = table_fn(st, fn, var_is_w, a + step * (zt[q] + 0.5L), gt[q]);
                 gmax = fmaxl(gmax, fabsl(gt[q]));
             }
             for (int q = 0; q < ntest && good; q++) {
@@ -338,7 +408,7 @@ inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTab
             const long double zr = 0.5L + lv + 0.01L;
             // (nothing to cover left of u = 0: the table variable is never negative)
             const long double wl = fmaxl((i + 0.5L - zr) * step, T.var_is_w ? 1e-6L * step : 0.0L), wh = (i + 0.5L + zr) * step;
-            if (T.var_is_w ? !(wh < 1) : !(wh < 2))
+            if ((T.fn == FN_RAY_G || T.fn == FN_RAY_S || T.fn == FN_RAY_CM) && (T.var_is_w ? !(wh < 1) : !(wh < 2)))
                 continue;
             const long double dl = m_of_u(wl) - mc, dh = m_of_u(wh) - mc, scale = fmaxl(fabsl(dl), fabsl(dh));
             long double dn[16], y[16], c[16];
@@ -346,7 +416,7 @@ inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTab
             for (int k = 0; k < n && good; k++) {
                 const long double d = 0.5L * (dl + dh) + 0.5L * (dh - dl) * cheb[k];
                 dn[k] = d / scale;
-                good = G_of_u(st, 0, (long double)mc + d, y[k]);
+                good = table_fn(st, T.fn, 0, (long double)mc + d, y[k]);
             }
             if (!good || !solve_vandermonde(n, dn, y, c))
                 continue;
@@ -365,7 +435,7 @@ inline MPolyTable fit_mpoly_table(const std::vector<v1c_op>& st, const RadialTab
             for (int q = 0; q < ntest && good; q++) {
                 const long double u = wl + (wh - wl) * (q + 0.5L) / ntest;
                 mt[q] = (double)m_of_u(u);  // the kernel holds m as a double
-                good = G_of_u(st, 0, (long double)mt[q], gt[q]);
+                good = table_fn(st, T.fn, 0, (long double)mt[q], gt[q]);
                 gmax = fmaxl(gmax, fabsl(gt[q]));
             }
             for (int q = 0; q < ntest && good; q++) {
@@ -398,41 +468,77 @@ inline int mpoly_first_ok(const MPolyTable& M, const RadialTable& T, double m_re
     return first;
 }
 
-// level a lane needs so that pixel 1's entry covers its 4 pixels (see ray_entry_is_shared); 0 if none
-inline int shared_entry_level(const RadialTable& T, double ray_step)
+// How far the table variable moves between horizontally adjacent output pixels, at most: `m` for tables in m, `w` for tables in w.
+// Ray tables: adjacent rays are at most `ray_step` radians apart (rotations preserve angles), |d m| <= |d v| <= angle and
+// |d w| = |d sin(theta / 2)| <= angle / 2.  Planar tables (m = xn^2 + yn^2, w = t / sqrt(2)): |d m| <= 2 t_max dx + dx^2, |d w| = dx / sqrt(2).
+struct TableStep {
+    double m = 0, w = 0;
+    double of(const RadialTable& T) const { return T.var_is_w ? w : m; }
+};
+inline TableStep ray_table_step(double ray_step)
 {
-    const double delta = T.inv_step * (T.var_is_w ? 0.5 : 1.0) * ray_step;
+    return TableStep{ray_step, 0.5 * ray_step};
+}
+inline TableStep planar_table_step(double dx, double x_max)
+{
+    return TableStep{2 * x_max * dx + dx * dx, dx * 0.70710678118654757};
+}
+
+// level a lane needs so that pixel 1's entry covers its 4 pixels (see ray_entry_is_shared); 0 if none
+inline int shared_entry_level(const RadialTable& T, const TableStep& st)
+{
+    const double delta = T.inv_step * st.of(T);
     for (int lv = 1; lv <= 2; lv++)
         if (delta <= 0.499 * lv)
             return lv;
     return 0;
 }
 
-// Choose the table variable: m when that fits the front hemisphere (theta <= 90 deg) without a
-// flagged interval, otherwise whichever of m / w flags fewer intervals there.
-inline RadialTable build_radial_table(const std::vector<v1c_op>& st, int n_int = kTableIntervals)
+// flagged intervals of a table up to m = m_front
+inline int table_bad_upto(const RadialTable& T, double m_front)
 {
-    auto bad_front = [](const RadialTable& T) {
-        const double u_front = T.var_is_w ? std::sqrt(0.5) : 1.0;
-        const int last = std::min(T.n_int, (int)(u_front * T.inv_step) + 1);
-        int bad = 0;
-        for (int i = 0; i < last; i++)
-            bad += std::isnan(T.coef[(size_t)i * kRadialCoefs]);
-        return bad;
-    };
-    RadialTable M = fit_radial_table(st, 0, n_int);
-    if (bad_front(M) == 0)
-        return M;
-    RadialTable W = fit_radial_table(st, 1, n_int);
-    return bad_front(W) < bad_front(M) ? W : M;
+    const double u_front = T.var_is_w ? std::sqrt(m_front / 2) : m_front;
+    const int last = std::min(T.n_int, (int)(u_front * T.inv_step) + 1);
+    int bad = 0;
+    for (int i = 0; i < last; i++)
+        bad += std::isnan(T.coef[(size_t)i * kRadialCoefs]);
+    return bad;
 }
 
-// Separable tables of the ray path (host copies) and the largest table variable any pixel of
-// an UNROTATED chain can reach.
+// Choose the table variable: m when that fits the front hemisphere (theta <= 90 deg; planar tables: the whole table) without a
+// flagged interval, otherwise whichever of m / w flags fewer intervals there.
+// (`m_front` <= 0: the front hemisphere for ray tables, the whole table for planar ones)
+inline RadialTable build_radial_table(const std::vector<v1c_op>& st, int n_int = kTableIntervals, int fn = FN_RAY_G, double m_max = kTableMMax,
+                                      int force_var = -1, double m_front = 0)
+{
+    if (!(m_front > 0))
+        m_front = (fn == FN_RAY_G || fn == FN_RAY_S || fn == FN_RAY_CM) ? 1.0 : m_max;
+    if (force_var >= 0)
+        return fit_radial_table(st, force_var, n_int, fn, m_max);
+    RadialTable M = fit_radial_table(st, 0, n_int, fn, m_max);
+    if (table_bad_upto(M, m_front) == 0)
+        return M;
+    RadialTable W = fit_radial_table(st, 1, n_int, fn, m_max);
+    return table_bad_upto(W, m_front) < table_bad_upto(M, m_front) ? W : M;
+}
+
+// Separable tables of the fused path (host copies) and the largest value of the BASE variable any pixel reaches: m = 1 - v_z of the
+// unrotated ray (bases 0 and 2), xn^2 + yn^2 (base 1).
+//
+// What the six tables hold, by base (the kernels' formulas are written for base 0 and serve the others through these substitutions):
+//   base 0 (equirect lat_y)   col: sin(lon), cos(lon), 1 - cos(lon)       row: sin(lat), cos(lat), 1 - cos(lat)
+//        v = (row_c col_s, row_s, row_c col_c),  m = row_h + row_c col_h
+//   base 1 (planar)           col: xn, xn^2, xn^2                          row: yn, 1, yn^2
+//        the same expressions give (xn, yn, .) and m = yn^2 + xn^2 (= the reference's x**2 + y**2, transformer.py:271), so an
+//        unrotated planar chain runs the unrotated ray kernels unchanged: x = G(m) r_x xn + c_x with G = F(t) / t tabulated in m = t^2
+//   base 2 (equirect lat_x)   col: sin(lat), cos(lat), cos(lat) [sic]      row: sin(lon), cos(lon), 1 - cos(lon)
+//        v = (col_s, col_c row_s, col_c row_c)  (transformer.py:557-566): RayParams::gen_mode 1 (gen_vector, v1c_core.hpp), which
+//        reads the column's cosine where the other modes read 1 - cos (one loader for both general modes)
 struct RayHostTables {
     std::vector<double> col_s, col_c, col_h, row_s, row_c, row_h;
     double m_reach = 0;
-    bool front_hemisphere = false;  // every unrotated ray has v_z >= 0 (|lon|, |lat| <= 90 deg)
+    double t_max = 0, x_max = 0;    // base 1: largest sqrt(xn^2 + yn^2), largest |xn|
+    bool front_hemisphere = false;  // every unrotated ray has v_z >= 0 (|lon|, |lat| <= 90 deg); base 1: true (unused)
 };
 
 #pragma clang fp contract(off)  // follow the reference's rounding order for lat / lon
@@ -440,46 +546,63 @@ inline RayHostTables build_ray_host_tables(const RayAnalysis& a, int dst_w, int 
 {
     RayHostTables t;
     const double half_pi = 1.5707963267948966;
-    // padded to a multiple of 4 columns (last entry replicated): kernels_fast.hip reads 4 at a time
+    // padded to a multiple of 4 columns (last entry replicated): the kernels read 4 at a time
     const int wpad = (dst_w + 3) & ~3;
     t.col_s.resize(wpad), t.col_c.resize(wpad), t.col_h.resize(wpad);
     t.row_s.resize(dst_h), t.row_c.resize(dst_h), t.row_h.resize(dst_h);
     double h_max = 0, h_min = 1e300;
     for (int i = 0; i < dst_w; i++) {
-        // NormalizeTransformer (transformer.py:162) then lon = x * (pi/2) (:547)
+        // NormalizeTransformer (transformer.py:162) then lon = x * (pi/2) (:547; lat for is_latitude_y=False, :558)
         const double xn = ((double)i - a.norm_cx) / a.norm_s * 2;
-        const double lon = xn * half_pi;
-        const double sh = std::sin(lon * 0.5);
-        t.col_s[i] = std::sin(lon), t.col_c[i] = std::cos(lon), t.col_h[i] = 2 * sh * sh;
+        if (a.base == 1) {
+            t.col_s[i] = xn, t.col_c[i] = t.col_h[i] = xn * xn;
+        } else {
+            const double lon = xn * half_pi;
+            const double sh = std::sin(lon * 0.5);
+            t.col_s[i] = std::sin(lon), t.col_c[i] = std::cos(lon), t.col_h[i] = a.base == 2 ? t.col_c[i] : 2 * sh * sh;
+        }
         h_max = std::max(h_max, t.col_h[i]), h_min = std::min(h_min, t.col_h[i]);
     }
     for (int i = dst_w; i < wpad; i++)
         t.col_s[i] = t.col_s[dst_w - 1], t.col_c[i] = t.col_c[dst_w - 1], t.col_h[i] = t.col_h[dst_w - 1];
     for (int j = 0; j < dst_h; j++) {
         const double yn = ((double)j - a.norm_cy) / a.norm_s * 2;  // :163
-        const double lat = yn * half_pi;                            // :546
+        if (a.base == 1) {
+            t.row_s[j] = yn, t.row_c[j] = 1.0, t.row_h[j] = yn * yn;
+            t.m_reach = std::max(t.m_reach, t.row_h[j] + h_max);
+            continue;
+        }
+        const double lat = yn * half_pi;                            // :546 (lon for is_latitude_y=False, :559)
         const double sh = std::sin(lat * 0.5);
         t.row_s[j] = std::sin(lat), t.row_c[j] = std::cos(lat), t.row_h[j] = 2 * sh * sh;
-        t.m_reach = std::max(t.m_reach, t.row_h[j] + std::max(t.row_c[j] * h_max, t.row_c[j] * h_min));
+        if (a.base == 0)
+            t.m_reach = std::max(t.m_reach, t.row_h[j] + std::max(t.row_c[j] * h_max, t.row_c[j] * h_min));
+        else  // m = 1 - col_c row_c  (col_h holds col_c)
+            t.m_reach = std::max(t.m_reach, 1.0 - std::min(t.row_c[j] * h_max, t.row_c[j] * h_min));
     }
+    t.t_max = a.base == 1 ? std::sqrt(t.m_reach) : 0.0;
+    t.x_max = a.base == 1 ? std::sqrt(h_max) : 0.0;
     t.front_hemisphere = true;
-    for (int i = 0; i < dst_w; i++)
-        t.front_hemisphere &= t.col_c[i] >= -1e-12;
-    for (int j = 0; j < dst_h; j++)
-        t.front_hemisphere &= t.row_c[j] >= -1e-12;
+    if (a.base != 1) {
+        for (int i = 0; i < dst_w; i++)
+            t.front_hemisphere &= t.col_c[i] >= -1e-12;
+        for (int j = 0; j < dst_h; j++)
+            t.front_hemisphere &= t.row_c[j] >= -1e-12;
+    }
     return t;
 }
 #pragma clang fp contract(fast)
 
-// true when the ray path should be used at all: at most a quarter of the front hemisphere's
-// intervals are flagged
-inline bool ray_table_usable(const RadialTable& T)
+// true when the table should be used at all: at most a quarter of the intervals up to m_front are flagged (ray tables: the front
+// hemisphere, m_front = 1).  Planar tables: up to three quarters -- FisheyeEncoder("orthographic") is NaN beyond t = 1
+// (transformer.py:372), i.e. on half of a square output's table, by the reference's own arithmetic; those pixels take the fix-up pass
+inline bool ray_table_usable(const RadialTable& T, double m_front = 1.0, int max_bad_quarters = 1)
 {
-    const int front = std::min(T.n_int, T.var_is_w ? (int)(std::sqrt(0.5) * T.inv_step) : (int)(1.0 * T.inv_step));
+    const int front = std::min(T.n_int, T.var_is_w ? (int)(std::sqrt(m_front / 2) * T.inv_step) : (int)(m_front * T.inv_step));
     int bad = 0;
     for (int i = 0; i < front; i++)
         bad += std::isnan(T.coef[(size_t)i * kRadialCoefs]);
-    return bad * 4 < front;
+    return bad * 4 < front * max_bad_quarters;
 }
 
 // Largest m = 1 - (R v)_z over unit vectors v of the front hemisphere (v_z >= 0): the minimum of
@@ -488,16 +611,23 @@ inline double rotated_reach(const double* rot)
 {
     return rot[8] >= 0 ? 1.0 + std::sqrt(rot[6] * rot[6] + rot[7] * rot[7]) : 2.0;
 }
+// ... over the cone of half-angle theta_max about the axis: the angle between r2 (a unit row of R) and the axis is alpha, the largest
+// angle between r2 and a v of the cone min(pi, alpha + theta_max)  (theta_max = pi / 2: rotated_reach)
+inline double rotated_reach_cone(const double* rot, double theta_max)
+{
+    const double alpha = std::acos(std::min(1.0, std::max(-1.0, rot[8])));
+    const double worst = std::min(3.14159265358979323846, alpha + theta_max * (1 + 1e-9) + 1e-12);
+    return 1.0 - std::cos(worst);
+}
 
 // true when one table entry may serve the 4 horizontally adjacent pixels of a lane
 // (tile_device.hpp, OWN = 0): with pixel 1's entry centred at zc, |t_1 - zc| <= 0.5 and
 // |t_k - t_1| <= 2 * delta, so every pixel stays inside the validated range |z| <= 0.5 + level
 // when delta <= level / 2 -- provided every entry a pixel can select has that level.
-// delta = table units per output pixel: adjacent rays are at most `ray_step` radians apart
-// (rotations preserve angles), |d m| <= |d v| <= angle and |d w| = |d sin(theta/2)| <= angle / 2.
-inline bool ray_entry_is_shared(const RadialTable& T, double m_reach, double ray_step)
+// delta = table units per output pixel (TableStep).
+inline bool ray_entry_is_shared(const RadialTable& T, double m_reach, const TableStep& st)
 {
-    const double delta = T.inv_step * (T.var_is_w ? 0.5 : 1.0) * ray_step;
+    const double delta = T.inv_step * st.of(T);
     const double u = (T.var_is_w ? std::sqrt(m_reach / 2) : m_reach) * (1 + 1e-9);
     for (int lv = 1; lv <= 2; lv++)
         if (delta <= 0.499 * lv && u * T.inv_step + 1.0 < (double)T.first_below_level[lv])
@@ -505,15 +635,111 @@ inline bool ray_entry_is_shared(const RadialTable& T, double m_reach, double ray
     return false;
 }
 
-// table resolution for an output whose adjacent rays are `ray_step` apart: the finest of
-// 1024 / 512 / 256 intervals that keeps a lane's 4 pixels within one level-2 entry
-inline int table_intervals_for(double ray_step)
+// table resolution for an output whose adjacent pixels are `st` apart in the table variable: the finest of 1024 / 512 / 256
+// intervals that keeps a lane's 4 pixels within one level-2 entry.  (Coarser tables for small outputs -- the reference's own tests
+// remap to 256 x 256, tests/test_remapper.py:73, whose adjacent rays are further apart than a 256-interval table allows -- were
+// tried in round 5: a degree-7 piece of a 128-interval table validates at level 2 on the first 49 intervals only, of 64 a single one,
+// so no lane could share an entry there either; small outputs keep the 256-interval table and the kernels with a per-pixel entry.)
+constexpr int kTableIntervalsMin = 256;
+inline int table_intervals_for(const TableStep& st, double m_max = kTableMMax)
 {
-    // delta <= 0.998 with inv_step <= n / u_max; m: u_max = 1.9375 (the larger delta per interval count)
-    for (int n = kTableIntervals; n > 256; n /= 2)
-        if ((n / kTableMMax) * ray_step * 1.0 <= 0.99 && (n / std::sqrt(kTableMMax / 2)) * 0.5 * ray_step <= 0.99)
+    // delta <= 0.998 with inv_step <= n / u_max
+    for (int n = kTableIntervals; n > kTableIntervalsMin; n /= 2)
+        if ((n / m_max) * st.m <= 0.99 && (n / std::sqrt(m_max / 2)) * st.w <= 0.99)
             return n;
-    return 256;
+    return kTableIntervalsMin;
+}
+
+inline bool ray_reach_is_safe(const RadialTable& T, double m_reach);
+
+// ---- everything a plan derives from a chain and an output size on the host (plan.hip; tests/host_emul runs the same function) ----
+struct TableSpec {
+    const std::vector<v1c_op>* stages;
+    int fn, n_int;
+    double m_max;
+    int force_var;  // -1: choose m / w; 0 / 1: that variable (the S and Cm tables of a plan share one index)
+    double m_front; // the variable is chosen by the flagged intervals up to here (0: build_radial_table's default)
+};
+struct RayPlanHost {
+    RayAnalysis a;
+    bool usable = false;       // false: the interpreter serves the chain
+    RayHostTables ht;
+    RadialTable table;         // the main table: G of the stages behind the rotation (all radial stages when nothing rotates)
+    TableStep step;            // ... and how far its variable moves between adjacent pixels
+    double ray_step = 0;       // largest angle between horizontally adjacent output rays (ray tables)
+    double reach_norot = 0;    // main-table m an unrotated plan reaches (classic and planar plans)
+    double reach_rot = 0;      // ... the plan's own rotation reaches (has_rot); 2 = anything
+    bool has_pre = false;      // gen_mode 2
+    RadialTable pre_s, pre_c;  // FN_*_S / FN_*_CM of a.pre, one variable and step for both
+    bool pre_safe = true;      // no pixel's base variable lands in a flagged interval of them
+};
+
+// `fit`: RadialTable(const TableSpec&) -- plan.hip passes its per-process cache of fits, the tests fit directly
+template <typename Fit>
+inline RayPlanHost build_ray_plan_host(const v1c_chain& ch, int dst_w, int dst_h, Fit&& fit)
+{
+    RayPlanHost H;
+    H.a = analyze_chain(ch);
+    const RayAnalysis& a = H.a;
+    if (!a.ok)
+        return H;
+    H.ht = build_ray_host_tables(a, dst_w, dst_h);
+    const RayHostTables& ht = H.ht;
+    const double dx = 2.0 / std::fabs(a.norm_s);                       // adjacent pixels in normalised units
+    const double base_ray_step = 1.5707963267948966 * dx;              // bases 0 / 2: lon (lat) = x * pi / 2
+    H.has_pre = a.gen_mode == 2;
+    if (a.base == 1 && !a.has_rot) {
+        // planar, nothing rotates: the main table is G = F(t) / t in m = t^2 up to the corners of the output (5 % beyond them: the
+        // proofs about the table's end -- ray_entry_is_shared, the fp32 index of the m-polynomials -- want a few intervals of margin)
+        const double m_max = std::max(ht.m_reach * 1.05, 1e-6);
+        H.step = planar_table_step(dx, ht.x_max);
+        H.table = fit(TableSpec{&a.radial, FN_PLANAR_G, table_intervals_for(H.step, m_max), m_max, -1, ht.m_reach});
+        H.reach_norot = ht.m_reach;
+        H.usable = ray_table_usable(H.table, ht.m_reach, 3);
+        return H;
+    }
+    double theta_max = 1.5707963267948966;  // largest angle off the axis an unrotated ray has where it meets the rotation
+    H.ray_step = base_ray_step;
+    if (H.has_pre) {
+        // S and Cm of the stages in front of the rotation, in the base variable (planar: m = t^2 up to the corners; equirect: m = 1 - v_z)
+        const bool planar = a.base == 1;
+        const double m_max = planar ? std::max(ht.m_reach * 1.05, 1e-6) : kTableMMax;
+        const int fs = planar ? FN_PLANAR_S : FN_RAY_S, fc = planar ? FN_PLANAR_CM : FN_RAY_CM;
+        const double m_front = planar ? ht.m_reach : 1.0;
+        H.pre_s = fit(TableSpec{&a.pre, fs, kTableIntervals, m_max, -1, m_front});
+        H.pre_c = fit(TableSpec{&a.pre, fc, kTableIntervals, m_max, H.pre_s.var_is_w, m_front});
+        if (!ray_table_usable(H.pre_s, m_front, planar ? 3 : 1) || !ray_table_usable(H.pre_c, m_front, planar ? 3 : 1))
+            return H;
+        const double base_reach = ht.m_reach;
+        H.pre_safe = ray_reach_is_safe(H.pre_s, base_reach) && ray_reach_is_safe(H.pre_c, base_reach);
+        // how fast the ray turns per unit of the base point, and how far off the axis it gets: sampled (F_pre is smooth where it is
+        // finite; 2 % on top)
+        const double t_hi = planar ? ht.t_max : std::acos(std::max(-1.0, 1.0 - std::min(base_reach, 2.0)));
+        const int ns = 4096;
+        long double lip = 1, th = 0, f_prev = 0;
+        bool any = false;
+        for (int q = 1; q <= ns; q++) {
+            const long double t = (long double)t_hi * q / ns;
+            long double f;
+            if (!composite_F(a.pre, t, f))
+                continue;
+            const long double den = planar ? t : sinl(t);
+            if (den > 0)
+                lip = fmaxl(lip, fabsl(sinl(f)) / den);
+            if (any)
+                lip = fmaxl(lip, fabsl(f - f_prev) * ns / (long double)t_hi);
+            th = fmaxl(th, fabsl(f));
+            f_prev = f, any = true;
+        }
+        theta_max = (double)th;
+        H.ray_step = (double)lip * 1.02 * (planar ? dx : base_ray_step);
+    }
+    H.step = ray_table_step(H.ray_step);
+    H.table = fit(TableSpec{&a.radial, FN_RAY_G, table_intervals_for(H.step), kTableMMax, -1, 0.0});
+    H.usable = ray_table_usable(H.table);
+    H.reach_norot = ht.m_reach;
+    H.reach_rot = H.has_pre ? rotated_reach_cone(a.rot, theta_max) : (ht.front_hemisphere ? rotated_reach(a.rot) : 2.0);
+    return H;
 }
 
 // Upper bounds of |G|: entry i of the result bounds every table entry 0 .. i over its whole validated range |z| <= 2.5 (sum of the

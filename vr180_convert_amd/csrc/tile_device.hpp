@@ -333,7 +333,8 @@ __device__ __forceinline__ void load_rowcol(const Tables& P, int xc, int jc, Row
 {
     rc.sl = P.row_s[jc], rc.cl = P.row_c[jc], rc.hl = P.row_h[jc];
     const double* __restrict__ ps = P.col_s + xc;
-    const double* __restrict__ pq = (ROT ? P.col_c : P.col_h) + xc;
+    // (ROT = 2, the general modes: the third column table -- 1 - cos(lon) / xn^2, or the cosine itself for lat_x plans: gen_vector)
+    const double* __restrict__ pq = (ROT == 1 ? P.col_c : P.col_h) + xc;
 #pragma unroll
     for (int k = 0; k < kPX; k++)
         rc.slon[k] = ps[k], rc.qlon[k] = pq[k];
@@ -375,7 +376,7 @@ __device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowC
     const double rx32 = P.rx32, ry32 = P.ry32, cx32 = P.cx32, cy32 = P.cy32;
 
     double A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, C0 = 0, C1 = 0, C2 = 0;
-    if (ROT) {
+    if (ROT == 1) {
         A0 = rot[0] * cl, B0 = rot[2] * cl, C0 = rot[1] * sl;
         A1 = rot[3] * cl, B1 = rot[5] * cl, C1 = rot[4] * sl;
         A2 = rot[6] * cl, B2 = rot[8] * cl, C2 = rot[7] * sl;
@@ -388,10 +389,16 @@ __device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowC
     double fx_[kPX], fy_[kPX], tt[kPX], mm[kPX];
     int idx[kPX];
     unsigned in_table = MPOLY ? 0xFu : 0u;
+    unsigned gen_bad = 0;  // ROT = 2: pixels whose base variable lies outside the S / Cm tables (RayParams::gen_mode 2)
 #pragma unroll
     for (int k = 0; k < kPX; k++) {
         double m;
-        if (ROT) {
+        if (ROT == 2) {
+            // the general modes (lat_x; radial stages in front of the rotation): the rotated ray by gen_vector, the very function the
+            // generic kernel's ray_eval calls
+            if (!gen_vector(P, rot, sl, cl, hl, slon[k], qlon[k], fx_[k], fy_[k], m))
+                gen_bad |= 1u << k;
+        } else if (ROT) {
             fx_[k] = fma(A0, slon[k], fma(B0, qlon[k], C0));
             fy_[k] = fma(A1, slon[k], fma(B1, qlon[k], C1));
             m = 1.0 - fma(A2, slon[k], fma(B2, qlon[k], C2));
@@ -411,6 +418,8 @@ __device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowC
         in_table |= (unsigned)ir < (unsigned)P.n_int ? 1u << k : 0u;
         idx[k] = min(ir, P.n_int - 1);  // clamped: always a readable entry
     }
+    if (ROT == 2)
+        in_table &= ~gen_bad;
 
     // radial table: one entry (that of pixel 1) serves all 4 pixels where it may
     double G[kPX];
@@ -655,8 +664,9 @@ struct ChunkMap {
     unsigned valid;      // bit q: chunk q exists
 };
 
+// (`ch0`: first chunk of the round -- boxes of more than 4 NT chunks are staged in two rounds by the pair code: shared_map_tile)
 template <int NT, int NQ = 4>
-__device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkMap& M)
+__device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkMap& M, int ch0 = 0)
 {
     const int nchunks = b.nrows * b.cpr;
     const int lpw = b.cpr * 4 + 4;  // LDS row pitch in dwords (+4: rotate the banks from row to row)
@@ -670,7 +680,7 @@ __device__ __forceinline__ void make_chunk_map(const TileBox& b, int tid, ChunkM
     M.valid = 0;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const uint32_t ch = tid + q * NT;
+        const uint32_t ch = ch0 + tid + q * NT;
 #if V1C_CHUNK_MAP_FP32
         const uint32_t r = (uint32_t)(((float)ch + 0.5f) * rcpr), col = ch - __umul24(r, (uint32_t)b.cpr);
 #else
@@ -1286,21 +1296,30 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
     ChunkMap M;
     make_chunk_map<NT>(b, tid, M);
 
-    auto issue = [&](int z, Staged& S) -> bool {  // start the box loads of unit z; false: it must gather from global memory
+    // The pair code stages boxes of up to 8 NT chunks, in two rounds of 4 per thread (the second one below, behind the first round's LDS
+    // stores: no extra registers).  A 64 x 16 tile of an EquirectangularEncoder(is_latitude_y=False) chain has its long side along a
+    // meridian: bounding boxes of up to 1 900 chunks under Lanczos4 where the lat_y configurations stay below 1 000 -- a third of
+    // such a launch's tiles gathered every tap from global memory before (P3L 1.09 ms).
+    // (not in the unrotated bilinear pair instantiations: they are compiled for 6 waves per SIMD -- the second round's code cost them 41 - 59
+    // spilled VGPRs -- and the boxes of an unrotated chain's 2 x 2 footprints never come near 4 NT chunks)
+    constexpr bool kTwoRounds = PAIR && !LEAN && (ROT != 0 || K != 2);
+    constexpr int kMaxChunks = kTwoRounds ? 8 * NT : 4 * NT;
+    auto issue_m = [&](int z, Staged& S, const ChunkMap& Mx) -> bool {  // start the box loads of unit z; false: it must gather from global memory
         const uint8_t* __restrict__ src = !PAIR ? U[z].src : z == z0 ? usrc0 : z == z0 + 1 ? usrc1 : U[z].src;
         const uint32_t spitch = !PAIR ? (uint32_t)U[z].src_pitch : z == z0 ? upitch0 : z == z0 + 1 ? upitch1 : (uint32_t)U[z].src_pitch;
         const uint32_t src_bytes = (uint32_t)(g.src_h - 1) * spitch + (uint32_t)g.src_w * 3u;
-        const bool fits = box_fits(b, src, spitch, 4 * NT, LEAN ? 2 * half_dwords : half_dwords);
+        const bool fits = box_fits(b, src, spitch, kMaxChunks, LEAN ? 2 * half_dwords : half_dwords);
         if (fits) {
             if (K != 2 && ext_box)  // (the box leaves the source: border colour around the image)
-                stage_load_ext<!PAIR>(M, src, spitch, g, S);
+                stage_load_ext<!PAIR>(Mx, src, spitch, g, S);
             else if (tail)
-                stage_load<true, !PAIR>(M, src, spitch, src_bytes, S);
+                stage_load<true, !PAIR>(Mx, src, spitch, src_bytes, S);
             else
-                stage_load<false, !PAIR>(M, src, spitch, src_bytes, S);
+                stage_load<false, !PAIR>(Mx, src, spitch, src_bytes, S);
         }
         return fits;
     };
+    auto issue = [&](int z, Staged& S) -> bool { return issue_m(z, S, M); };
 
     // lean kernel: a box larger than one buffer takes both, one unit at a time
     const bool single = LEAN && b.nrows * (b.cpr * 4 + 4) > half_dwords;
@@ -1324,6 +1343,22 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
             stage_store(M, S0, boxw);
         if (fit1)
             stage_store(M, S1, boxw + half_dwords);
+    }
+    if (kTwoRounds && b.nrows * b.cpr > 4 * NT) {  // the second round of a large box (wave-uniform, rare: see kMaxChunks)
+        ChunkMap M2;
+        make_chunk_map<NT>(b, tid, M2, 4 * NT);
+        if (fit0)
+            issue_m(z0, S0, M2);
+        if (fit1)
+            issue_m(z0 + 1, S1, M2);
+        if (cells) {
+            stage_store_pair(M2, S0, S1, boxw);
+        } else {
+            if (fit0)
+                stage_store(M2, S0, boxw);
+            if (fit1)
+                stage_store(M2, S1, boxw + half_dwords);
+        }
     }
     if (tab_lds && tid < b.nidx * 4)
         ((d2*)tabw)[tid] = tv;

@@ -74,6 +74,19 @@ struct RayParams {
     const double* radial_m;
     int mp_first_ok;
     float inv_step_f;
+    // General modes (radial_fit.hpp: RayAnalysis; a rotation always applies, identity if the chain has none):
+    //   1: EquirectangularEncoder(is_latitude_y=False) -- v = (col_s, col_c row_s, col_c row_c), transformer.py:557-566;
+    //   2: radial stages in FRONT of the rotation -- the point enters 3-D through v = (sin t d_x, sin t d_y, cos t), t = F_pre(theta)
+    //      (equidistant_to_3d, transformer.py:502-507): v = (S b_x, S b_y, 1 - Cm) with the base point b = (row_c col_s, row_s), the base
+    //      variable m0 = row_h + row_c col_h (planar chains: b = (xn, yn), m0 = xn^2 + yn^2 through the substituted tables) and
+    //      S = sin(F_pre) / |b|, Cm = 1 - cos(F_pre) tabulated in m0 (or w0 = sqrt(m0 / 2)): pre_s / pre_c, degree 7 per interval,
+    //      every pixel its own entry.
+    int gen_mode;
+    int pre_var_is_w;
+    const double* pre_s;
+    const double* pre_c;
+    double pre_inv_step;
+    int pre_n_int, pad3;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -311,6 +324,44 @@ V1C_HDF double fast_sqrt_half(double m)
 #endif
 }
 
+// The rotated ray of the general modes (RayParams::gen_mode): fx, fy = its x / y components, m = 1 - its z component.  `q` = the
+// column's third table value: cos of the column angle in mode 1 (build_ray_host_tables stores it in col_h for base 2), 1 - cos(lon) /
+// xn^2 in mode 2.  False: the base variable lies outside the S / Cm tables (the caller leaves the pixel to the interpreter).
+// ONE definition for the generic kernel (ray_eval) and the tile kernels (lane_coords): both must agree bit for bit.
+// (`RP`: RayParams, or the constant-address-space view of it the tile kernels read the plan's context through)
+template <typename RP, typename RotPtr>
+V1C_HDF bool gen_vector(RP& P, RotPtr rot, double sl, double cl, double hl, double slon, double q, double& fx, double& fy,
+                        double& m)
+{
+    if (P.gen_mode == 1) {
+        const double vy = q * sl, vz = q * cl;
+        fx = fma(rot[0], slon, fma(rot[1], vy, rot[2] * vz));
+        fy = fma(rot[3], slon, fma(rot[4], vy, rot[5] * vz));
+        m = 1.0 - fma(rot[6], slon, fma(rot[7], vy, rot[8] * vz));
+        return true;
+    }
+    const double bx = cl * slon, by = sl;
+    const double m0 = fma(cl, q, hl);
+    const double u = P.pre_var_is_w ? fast_sqrt_half(m0) : m0;
+    const double t = u * P.pre_inv_step;
+    const int idx = table_index(t);
+    const bool in = (unsigned)idx < (unsigned)P.pre_n_int;
+    const int ic = in ? idx : 0;
+    const double z = t - ((double)ic + 0.5);
+    const double* cs = P.pre_s + (size_t)ic * kRadialCoefs;
+    const double* cc = P.pre_c + (size_t)ic * kRadialCoefs;
+    double S = cs[kRadialDegree], Cm = cc[kRadialDegree];
+#pragma unroll
+    for (int k = kRadialDegree - 1; k >= 0; k--)
+        S = fma(S, z, cs[k]), Cm = fma(Cm, z, cc[k]);
+    const double sx = S * bx, sy = S * by, vz = 1.0 - Cm;
+    fx = fma(rot[0], sx, fma(rot[1], sy, rot[2] * vz));
+    fy = fma(rot[3], sx, fma(rot[4], sy, rot[5] * vz));
+    // 1 - (R v)_z without the cancellation of 1 - (... + r22 (1 - Cm)): (1 - r22) + r22 Cm - r20 S b_x - r21 S b_y
+    m = fma(-rot[6], sx, fma(-rot[7], sy, fma(rot[8], Cm, 1.0 - rot[8])));
+    return in;  // (flagged intervals carry NaN coefficients: the coordinates come out NaN and fail the caller's range test)
+}
+
 V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], double sl, double cl, double hl,
                       double slon, double clon, double hlon, double& ox, double& oy)
 {
@@ -319,7 +370,12 @@ V1C_HDF bool ray_eval(const RayParams& P, bool use_rot, const double (&rot)[9], 
     double m, x32, y32;
     double sx_, sy_;  // the factors G multiplies: x32 = (G*kx)*sx_ + cx32, y32 = (G*ky)*sy_ + cy32
     double kx, ky;
-    if (use_rot) {
+    if (P.gen_mode) {
+        if (!gen_vector(P, rot, sl, cl, hl, slon, hlon, sx_, sy_, m))
+            return false;
+        kx = P.rx32, ky = P.ry32;
+        use_rot = true;
+    } else if (use_rot) {
         // R*v with v = (cl*slon, sl, cl*clon), grouped as (R_k0*cl)*slon + (R_k2*cl)*clon + R_k1*sl so
         // that the row-constant factors can be hoisted out of the pixel loop
         sx_ = fma(rot[0] * cl, slon, fma(rot[2] * cl, clon, rot[1] * sl));

@@ -127,8 +127,9 @@ class Plan:
 
     @property
     def path(self) -> str:
-        """'ray' (fused separable tables + radial table) or 'literal' (fp64 interpreter)."""
-        return "ray" if _native.lib().v1c_plan_path(self._h) == 1 else "literal"
+        """'ray' (fused separable tables + radial table), 'planar' (the same kernels on the normalised plane point: chains that do not start
+        with an EquirectangularEncoder) or 'literal' (fp64 interpreter)."""
+        return {1: "ray", 2: "planar"}.get(_native.lib().v1c_plan_path(self._h), "literal")
 
     def last_launch(self) -> str:
         """Kernel family of this plan's most recent launch group (``v1c_plan_last_launch``): 'generic', 'tile', 'mirror', 'batch',
@@ -167,6 +168,16 @@ class Plan:
                     self._memo.popitem(last=False)
                 except KeyError:  # another thread emptied it
                     break
+
+    def run_auto(self, srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor], rad: torch.Tensor, rots: Sequence[Any] | None = None) -> None:
+        """``v1c_plan_run_auto``: the launch with the radius read from device memory -- ``rad`` = float64 ``(n, 2)`` (radius, status)
+        pairs as ``v1c_get_radius_async`` writes them; the launch uses their maximum.  Raises NotImplementedError for chains /
+        geometries the device-resident form does not serve (the caller then takes the radius to the host)."""
+        if rad.dtype != torch.float64 or rad.dim() != 2 or rad.shape[1] != 2 or not rad.is_contiguous() or rad.device != self.device:
+            raise ValueError("rad must be a contiguous float64 (n, 2) tensor on the plan's device")
+        units = marshal_units(srcs, dsts, rots, src_hw=self.src_hw, dst_wh=self.dst_wh, cn=self.cn, device=self.device)
+        rc = _native.lib().v1c_plan_run_auto(self._h, _stream_ptr(self.device), units, len(srcs), rad.data_ptr(), int(rad.shape[0]))
+        _native.check(rc, "v1c_plan_run_auto")
 
     def run_units(self, units: Any, n: int) -> None:
         """Launch an already marshalled ``v1c_unit`` array (``marshal_units``) on the current stream."""
@@ -638,6 +649,44 @@ def apply(
     return results
 
 
+def auto_radius_tensor(images: Sequence[torch.Tensor], threshold: int = 10) -> torch.Tensor:
+    """``get_radius`` (transformer.py:108-140) of every image, left on the device: a float64 ``(n, 2)`` tensor of (radius, status) pairs
+    (``v1c_get_radius_async``; status 1.0 / radius NaN where the reference raises IndexError).  Current stream, nothing synchronised."""
+    dev = images[0].device
+    rad = torch.empty((len(images), 2), dtype=torch.float64, device=dev)
+    for k, im in enumerate(images):
+        _check_image_tensor(im, "image")
+        rc = _native.lib().v1c_get_radius_async(dev.index, _stream_ptr(dev), im.data_ptr(), im.shape[0], im.shape[1], im.stride(0), im.shape[2],
+                                                threshold, rad.data_ptr() + 16 * k)
+        _native.check(rc, "v1c_get_radius_async")
+    return rad
+
+
+def remap_tensors_auto(transformer: TransformerBase, srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor], *,
+                       rad: torch.Tensor | None = None, interpolation: int = INTER_LANCZOS4, boarder_mode: int = BORDER_CONSTANT,
+                       boarder_value: Any = 0, size_input: tuple[int, int] | None = None) -> None:
+    """``remap_tensors`` with ``radius="auto"`` -- the reference's default, remapper.py:333 -- and the radius never leaving the device:
+    estimated per image by ``v1c_get_radius_async`` (or given as ``rad``, ``auto_radius_tensor``), the maximum taken and the
+    Denormalize scale set by a one-thread kernel in front of the remap launch (``v1c_plan_run_auto``).  No stream synchronisation, no
+    plan per image (ONE plan serves every radius: it is keyed on the nominal radius "max"), graph-capturable once the plan exists.
+    Where the reference raises IndexError (an image without a black border) the radius becomes NaN and the output the border colour.
+    Raises NotImplementedError for chains the device-resident form does not serve (see include/vr180_remap.h)."""
+    if isinstance(transformer, (list, tuple)):
+        raise ValueError("remap_tensors_auto takes ONE transformer (per-eye transformers: one call per eye, as apply_lr does)")
+    dev = srcs[0].device
+    src_hw = (int(srcs[0].shape[0]), int(srcs[0].shape[1]))
+    dst_wh = (int(dsts[0].shape[1]), int(dsts[0].shape[0]))
+    size_in = tuple(size_input) if size_input is not None else src_hw
+    nominal = min(size_in[0] / 2, size_in[1] / 2)  # (any radius: the launch ignores the plan's own)
+    chain = _lower_cached(transformer, radius=nominal, size_input=size_in, size_output=dst_wh)
+    plan = _plan_for(chain, src_hw=src_hw, dst_wh=dst_wh, cn=int(srcs[0].shape[2]), interpolation=interpolation,
+                     border_mode=boarder_mode, border_value=boarder_value, device=dev)
+    if rad is None:
+        rad = auto_radius_tensor(srcs)
+    plan.run_auto(srcs, dsts, rad)
+    _TLS.plans = [plan]
+
+
 def apply_lr_tensors(
     transformer: TransformerBase | tuple[TransformerBase, TransformerBase],
     left: torch.Tensor,
@@ -649,9 +698,15 @@ def apply_lr_tensors(
     boarder_mode: int = BORDER_CONSTANT,
     boarder_value: Any = 0,
     radius: float | Literal["auto", "max"] = "auto",
+    auto_radius_on_device: bool | None = None,
 ) -> torch.Tensor:
     """Device-resident ``apply_lr`` (merge=False): both eyes are remapped by ONE launch straight
-    into the halves of the ``(H, 2W, C)`` side-by-side tensor (remapper.py:460-484, 517-518)."""
+    into the halves of the ``(H, 2W, C)`` side-by-side tensor (remapper.py:460-484, 517-518).
+
+    ``radius="auto"`` (the reference's default) has two forms.  The exact one brings each estimate to the host (one stream
+    synchronisation; raises IndexError like the reference when an image has no black border; a new radius is a new plan).
+    ``auto_radius_on_device=True`` keeps it on the device (``remap_tensors_auto``): no synchronisation, one plan for every radius,
+    graph-capturable; default (None): taken when the current stream is being captured into a graph, where a synchronisation is illegal."""
     w, h = size_output
     cn = left.shape[2]
     if out is None:
@@ -659,6 +714,23 @@ def apply_lr_tensors(
         if boarder_mode == _abi.BORDER_TRANSPARENT:
             out.zero_()
     halves = [out[:, :w], out[:, w:]]
+    if isinstance(radius, str) and radius == "auto":
+        on_dev = auto_radius_on_device
+        if on_dev is None:
+            on_dev = bool(torch.cuda.is_current_stream_capturing())
+        if on_dev:
+            try:
+                if isinstance(transformer, tuple):  # per-eye transformer AND per-eye radius (remapper.py:460-473)
+                    for t, im, d in zip(transformer, (left, right), halves):
+                        remap_tensors_auto(t, [im], [d], interpolation=interpolation, boarder_mode=boarder_mode, boarder_value=boarder_value)
+                else:
+                    remap_tensors_auto(transformer, [left, right], halves, interpolation=interpolation, boarder_mode=boarder_mode,
+                                       boarder_value=boarder_value, size_input=(int(left.shape[0]), int(left.shape[1])))
+                return out
+            except NotImplementedError:
+                if auto_radius_on_device is None and torch.cuda.is_current_stream_capturing():
+                    raise
+                # (this chain is not served by the device-resident form: the exact one below)
     if isinstance(transformer, tuple):
         # per-eye transformer AND per-eye radius estimate (remapper.py:460-473)
         r = [get_radius_smart(radius, [im]) for im in (left, right)]
