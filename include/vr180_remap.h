@@ -177,8 +177,8 @@ int v1c_plan_run(v1c_plan* plan, void* stream, const v1c_unit* units, int n_unit
 /* v1c_plan_run with the radius read from DEVICE memory: radius="auto" -- the reference's default, remapper.py:333,416 -- without a host
  * round trip or a plan per image.  Replaces get_radius_smart("auto") (remapper.py:82-84: the max over the images of get_radius) feeding
  * get_map's DenormalizeTransformer(scale=(radius, radius)) (remapper.py:51-57).  `rad_dev`: n_rad (radius, status) pairs in device memory as
- * v1c_get_radius_async writes them; the launch uses max(radius) -- clamped to 4 x the larger source dimension in magnitude; NaN (every
- * pixel the border colour) if any status is set, where the reference raises IndexError.  The plan's own radius is ignored, so one plan
+ * v1c_get_radius_async writes them; the launch uses max(radius) -- clamped to 4 x the larger source dimension in magnitude; if any status
+ * is set (the reference raises IndexError there) the map is sent far outside the source: every pixel the border colour.  The plan's own radius is ignored, so one plan
  * serves every image of a stream.  At most 16 units; chains EquirectangularEncoder() * [one rotation] * radial stages whose table needs
  * no fix-up pass -- anything else returns V1C_E_UNSUPPORTED and the caller takes the radius to the host (v1c_get_radius).  Launch-only,
  * graph-capturable; one plan may be used from several streams (ordered by an event).                                              */

@@ -38,7 +38,7 @@ KXK_EDGE_CASES = {
     "defaults_circle_touches_frame": ([("equirect_enc", True), CS.EQUI], (640, 640), (640, 640), 320.0, 0),
     "circle_beyond_the_frame": ([("equirect_enc", True), CS.EQUI], (600, 600), (640, 576), 330.0, (9, 200, 77)),
     "width_not_a_multiple_of_4": ([("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI], (499, 613), (704, 512), 320.0, (255, 1, 128)),
-    "rotated": ([("equirect_enc", True), ("rot", CS.ry(0.5)), CS.EQUI], (512, 512), (640, 512), 262.0, 37),
+    "rotated": ([("equirect_enc", True), ("rot", CS.ry(0.5)), CS.EQUI], (512, 512), (512, 512), 262.0, 37),
     "zoomed_out_wide_rim": ([("equirect_enc", True), ("zoom", 0.6), CS.EQUI], (300, 300), (512, 480), 150.0, (3, 2, 1)),
     "tiny_source": ([("equirect_enc", True), CS.EQUI], (9, 11), (448, 432), 5.0, (100, 150, 200)),
 }
@@ -218,11 +218,11 @@ def test_auto_radius_on_the_device_equals_the_host_radius_path(V, oracle_mod, go
         a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
         r_ref = max(O.get_radius(a), O.get_radius(b))  # get_radius_smart("auto"), remapper.py:83-84
         la, lb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
-        got = V.apply_lr_tensors(t, la, lb, size_output=(640, 512), interpolation=interp, radius="auto", auto_radius_on_device=True)
+        got = V.apply_lr_tensors(t, la, lb, size_output=(512, 512), interpolation=interp, radius="auto", auto_radius_on_device=True)
         kinds = remapper.last_launch_kinds()
-        assert kinds and kinds[0] in ("tile", "rot_pair"), kinds
-        exact = V.apply_lr_tensors(t, la, lb, size_output=(640, 512), interpolation=interp, radius="auto", auto_radius_on_device=False)
-        want = O.apply_lr(spec, a, b, size_output=(640, 512), interpolation=interp, radius=r_ref)
+        assert remapper.last_auto_radius_form() == "device" and kinds and kinds[0] in ("tile", "rot_pair"), (remapper.last_auto_radius_form(), kinds)
+        exact = V.apply_lr_tensors(t, la, lb, size_output=(512, 512), interpolation=interp, radius="auto", auto_radius_on_device=False)
+        want = O.apply_lr(spec, a, b, size_output=(512, 512), interpolation=interp, radius=r_ref)
         assert np.array_equal(exact.cpu().numpy(), want), (k, "exact path")
         assert np.array_equal(got.cpu().numpy(), want), (k, r_ref, int((got.cpu().numpy() != want).sum()))
     # the reference raises IndexError for an image without a black border (radius.npz: noborder_raises); the exact path does too,
@@ -230,16 +230,22 @@ def test_auto_radius_on_the_device_equals_the_host_radius_path(V, oracle_mod, go
     full = torch.full((480, 640, 3), 90, dtype=torch.uint8, device=dev)
     disc = torch.from_numpy(_disc(480, 640, 200, 9)).to(dev)
     with pytest.raises(IndexError):
-        V.apply_lr_tensors(t, full, disc, size_output=(640, 512), interpolation=interp, radius="auto", auto_radius_on_device=False)
-    out = V.apply_lr_tensors(t, full, disc, size_output=(640, 512), interpolation=interp, radius="auto", auto_radius_on_device=True,
+        V.apply_lr_tensors(t, full, disc, size_output=(512, 512), interpolation=interp, radius="auto", auto_radius_on_device=False)
+    out = V.apply_lr_tensors(t, full, disc, size_output=(512, 512), interpolation=interp, radius="auto", auto_radius_on_device=True,
                              boarder_value=(1, 2, 3))
+    assert remapper.last_auto_radius_form() == "device"
     assert torch.equal(out, torch.tensor([1, 2, 3], dtype=torch.uint8, device=dev).expand_as(out))
     # per-eye transformers: per-eye radius (remapper.py:460-473)
     tl = CS.to_product([("equirect_enc", True), ("rot", CS.ry(0.05)), CS.EQUI])
     a, b = _disc(480, 640, 180, 5), _disc(480, 640, 222, 6)
-    got = V.apply_lr_tensors((tl, t), torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), size_output=(640, 512), interpolation=interp,
+    got = V.apply_lr_tensors((tl, t), torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), size_output=(512, 512), interpolation=interp,
                              radius="auto", auto_radius_on_device=True)
-    want = O.apply_lr(([("equirect_enc", True), ("rot", CS.ry(0.05)), CS.EQUI], spec), a, b, size_output=(640, 512), interpolation=interp, radius="auto")
+    assert remapper.last_auto_radius_form() == "device"
+    # a non-square output looks beyond the front hemisphere: its table needs a fix-up pass, the exact form serves it (silently)
+    V.apply_lr_tensors(t, torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), size_output=(640, 512), interpolation=interp, radius="auto",
+                       auto_radius_on_device=True)
+    assert remapper.last_auto_radius_form() == "exact"
+    want = O.apply_lr(([("equirect_enc", True), ("rot", CS.ry(0.05)), CS.EQUI], spec), a, b, size_output=(512, 512), interpolation=interp, radius="auto")
     assert np.array_equal(got.cpu().numpy(), want)
 
 

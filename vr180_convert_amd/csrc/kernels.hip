@@ -371,10 +371,11 @@ hipError_t launch_get_radius(const uint8_t* img, int h, int w, int64_t pitch, in
 // ---- a radius that never leaves the device (v1c_plan_run_auto) ----
 // get_radius_smart("auto") = max over the images of get_radius (remapper.py:83-84); get_map gives the Denormalize stage scale = (radius,
 // radius) (remapper.py:55).  One thread takes the maximum of the n estimates v1c_get_radius_async left on the device (rad[2 k] = radius,
-// rad[2 k + 1] = 0 / 1 "no black border": the reference raises IndexError there -- the device path cannot, the radius becomes NaN and
-// every pixel the border colour), clamps it to the magnitude the plan's proofs were taken for and writes the four numbers of the
+// rad[2 k + 1] = 0 / 1 "no black border": the reference raises IndexError there -- the device path cannot: the whole map is sent far
+// outside the source instead (scale 0, centre at -40 000 px: every pixel the border colour under BORDER_CONSTANT, inside the range the
+// kernels' coordinate proofs hold for)), clamps it to the magnitude the plan's proofs were taken for and writes the numbers of the
 // plan-resident context the kernels read: stream-ordered, graph-capturable, no host round trip.
-__global__ void k_patch_radius(KernelCtx* ctx, const double* __restrict__ rad, int n, double r_limit)
+__global__ void k_patch_radius(KernelCtx* ctx, const double* __restrict__ rad, int n, double r_limit, double cx32, double cy32)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
@@ -385,15 +386,19 @@ __global__ void k_patch_radius(KernelCtx* ctx, const double* __restrict__ rad, i
         bad |= rad[2 * k + 1] != 0.0;
     }
     r = fmin(fmax(r, -r_limit), r_limit);
-    if (bad)
-        r = NAN;
+    if (bad || !(r == r)) {
+        r = 0.0;
+        cx32 = cy32 = -1280000.0;
+    }
     ctx->ray.rx = r, ctx->ray.ry = r;
     ctx->ray.rx32 = 32.0 * r, ctx->ray.ry32 = 32.0 * r;
+    ctx->ray.cx32 = cx32, ctx->ray.cy32 = cy32;
+    ctx->ray.cx = cx32 * 0.03125, ctx->ray.cy = cy32 * 0.03125;
 }
 
-hipError_t launch_patch_radius(KernelCtx* ctx_dev, const double* rad_dev, int n, double r_limit, hipStream_t stream)
+hipError_t launch_patch_radius(KernelCtx* ctx_dev, const double* rad_dev, int n, double r_limit, double cx32, double cy32, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_patch_radius, dim3(1), dim3(64), 0, stream, ctx_dev, rad_dev, n, r_limit);
+    hipLaunchKernelGGL(k_patch_radius, dim3(1), dim3(64), 0, stream, ctx_dev, rad_dev, n, r_limit, cx32, cy32);
     return hipGetLastError();
 }
 

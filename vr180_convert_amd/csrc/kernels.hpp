@@ -128,6 +128,6 @@ hipError_t launch_anaglyph(const uint8_t* left, int64_t left_pitch, const uint8_
 hipError_t launch_get_radius(const uint8_t* img, int h, int w, int64_t pitch, int cn, int threshold, double* out, hipStream_t stream);
 
 // v1c_plan_run_auto: the Denormalize scale of the device context `ctx_dev` from n (radius, status) pairs in device memory
-hipError_t launch_patch_radius(KernelCtx* ctx_dev, const double* rad_dev, int n, double r_limit, hipStream_t stream);
+hipError_t launch_patch_radius(KernelCtx* ctx_dev, const double* rad_dev, int n, double r_limit, double cx32, double cy32, hipStream_t stream);
 
 }  // namespace v1c

@@ -1077,7 +1077,7 @@ extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* unit
     }
     if (p->dyn_pending && p->dyn_stream != st)
         HIP_TRY(hipStreamWaitEvent(st, p->dyn_ev, 0));
-    HIP_TRY(launch_patch_radius(p->ctx_dyn, rad_dev, n_rad, r_limit, st));
+    HIP_TRY(launch_patch_radius(p->ctx_dyn, rad_dev, n_rad, r_limit, p->ctx.ray.cx32, p->ctx.ray.cy32, st));
     LaunchUnits lu{du, nullptr, n_units};
     int kind = V1C_LAUNCH_GENERIC;
     if (g.cn != 3) {

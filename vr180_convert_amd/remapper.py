@@ -225,6 +225,12 @@ def last_launch_kinds() -> list[str]:
     return [p.last_launch() for p in getattr(_TLS, "plans", [])]
 
 
+def last_auto_radius_form() -> str:
+    """Which form the calling thread's most recent ``apply_lr_tensors(radius="auto")`` took: 'device' (``remap_tensors_auto``: the radius
+    never left the GPU) or 'exact' (estimates brought to the host); '' before the first such call.  For tests and the bench."""
+    return getattr(_TLS, "auto_form", "")
+
+
 def clear_caches() -> None:
     """Forget every plan and lowered chain (cold-call measurements, tests)."""
     with _PLANS_LOCK:
@@ -669,7 +675,7 @@ def remap_tensors_auto(transformer: TransformerBase, srcs: Sequence[torch.Tensor
     estimated per image by ``v1c_get_radius_async`` (or given as ``rad``, ``auto_radius_tensor``), the maximum taken and the
     Denormalize scale set by a one-thread kernel in front of the remap launch (``v1c_plan_run_auto``).  No stream synchronisation, no
     plan per image (ONE plan serves every radius: it is keyed on the nominal radius "max"), graph-capturable once the plan exists.
-    Where the reference raises IndexError (an image without a black border) the radius becomes NaN and the output the border colour.
+    Where the reference raises IndexError (an image without a black border) the output is the border colour.
     Raises NotImplementedError for chains the device-resident form does not serve (see include/vr180_remap.h)."""
     if isinstance(transformer, (list, tuple)):
         raise ValueError("remap_tensors_auto takes ONE transformer (per-eye transformers: one call per eye, as apply_lr does)")
@@ -726,11 +732,13 @@ def apply_lr_tensors(
                 else:
                     remap_tensors_auto(transformer, [left, right], halves, interpolation=interpolation, boarder_mode=boarder_mode,
                                        boarder_value=boarder_value, size_input=(int(left.shape[0]), int(left.shape[1])))
+                _TLS.auto_form = "device"
                 return out
             except NotImplementedError:
                 if auto_radius_on_device is None and torch.cuda.is_current_stream_capturing():
                     raise
                 # (this chain is not served by the device-resident form: the exact one below)
+        _TLS.auto_form = "exact"
     if isinstance(transformer, tuple):
         # per-eye transformer AND per-eye radius estimate (remapper.py:460-473)
         r = [get_radius_smart(radius, [im]) for im in (left, right)]
