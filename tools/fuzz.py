@@ -6,7 +6,11 @@ strips, rest lists, the unit ring), cn 1 / 3 / 4, every interpolation and border
 and destination views (dword-aligned or not), per-unit rotations, apply_lr pairs; a share of the cases (--lut) runs cv2.remap alone
 (v1c_remap_lut) on random float32 maps sprinkled with NaN, infinities, 2^15 / 2^26 / 2^31-scale values and ties of the 1/32 grid.
 
-    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--lut 0.15] [--hot 0.3] [--log gpurun_out/fuzz.log]
+    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--lut 0.15] [--hot 0.3] [--api 0.1] [--auto 0.06] [--fused 0.06] [--log gpurun_out/fuzz.log]
+
+Round 5 added to the grammar: hot shapes of the chains that left the interpreter (planar fisheye -> fisheye, is_latitude_y=False, a
+rotation behind radial stages), outputs of 64 ... 416 px, launches recorded into a graph and replayed, radius='auto' with the radius on
+the device (--auto) and v1c_remap_fused through raw ctypes (--fused).
 
 Ill-conditioned pixels are left out and counted: where the chain amplifies a perturbation of the output position by 1e6 or more
 (measured on the oracle's fp64 map, `ill_conditioned`), the last bits of every intermediate -- they differ between glibc and the
@@ -184,10 +188,25 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
             mid.append(("zoom", float(rng.uniform(0.8, 1.3))))
         spec = [("equirect_enc", True)] + mid + [("fisheye_dec", "equidistant")]
         rot_at = 1 if rot_units else None
+        if (not rot_units) and rng.random() < 0.4:
+            # round 5: the chains that left the interpreter -- planar (fisheye -> fisheye: the reference's own test chains,
+            # tests/test_remapper.py:42-91), is_latitude_y=False, a rotation behind radial stages (baked into the plan)
+            fam = rng.random()
+            enc = ("equirect_enc", False) if fam < 0.25 else ("fisheye_enc", MODELS[int(rng.integers(5))])
+            mid2 = list(mid)
+            if rng.random() < 0.35:
+                mid2.insert(int(rng.integers(0, len(mid2) + 1)), ("rot", rand_rot(rng, rng.random() < 0.5).tolist()))
+            if fam >= 0.25 and rng.random() < 0.15:
+                enc = ("equirect_enc", True)  # (equirect, radial stage, rotation: the S / Cm tables behind an EquirectangularEncoder)
+                mid2 = [("poly", [0.0, 1.0, float(rng.uniform(-0.1, 0.05))]), ("rot", rand_rot(rng, False).tolist())]
+            dec = ("fisheye_dec", "equidistant") if rng.random() < 0.7 else ("fisheye_dec", MODELS[int(rng.integers(5))])
+            spec = [enc] + mid2 + [dec]
         cn = int(rng.choice([3, 3, 3, 3, 1, 4]))
         interp = int(rng.choice([1, 1, 1, 1, 1, 0, 2, 4]))
         border = int(rng.choice([0, 0, 0, 0, 0, 1, 4, 5]))
         ho = int(rng.integers(13, 66)) * 32 if rng.random() < 0.85 else int(rng.integers(416, 2100))
+        if rng.random() < 0.15:
+            ho = int(rng.integers(64, 417))  # small outputs (the reference's tests: 256 x 256): per-pixel table entries, tiny grids
         wo = max(1, ho + int(rng.choice([0, 0, 0, -64, -4, 4, 60, 64])) + (0 if rng.random() < 0.7 else int(rng.integers(-100, 30))))
         if interp in (2, 4):
             wo, ho = min(wo, 1100), min(ho, 1088)
@@ -234,6 +253,24 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
         if use_rot:
             kw["rotations"] = rots
         V.remap_tensors(t, srcs, dsts, radius=radius, interpolation=interp, boarder_mode=border, boarder_value=bval, **kw)
+        from vr180_convert_amd import remapper as _rm
+
+        if rng.random() < 0.12 and n <= 16 and all("+" not in k for k in _rm.last_launch_kinds()) and len(_rm.last_launch_kinds()) == 1:
+            # the same launch recorded into a graph and replayed on restored destinations (plan_run is launch-only; launch groups with a
+            # fix-up pass order their flag words across streams by an event of the plan and are left out here)
+            torch.cuda.synchronize()
+            for d in dsts:
+                d.copy_(torch.from_numpy(fill).to(dev))
+            st = torch.cuda.Stream(device=dev)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                V.remap_tensors(t, srcs, dsts, radius=radius, interpolation=interp, boarder_mode=border, boarder_value=bval, **kw)
+            for d in dsts:
+                d.copy_(torch.from_numpy(fill).to(dev))
+            torch.cuda.synchronize()
+            gr.replay()
+            torch.cuda.synchronize()
+            desc += " graph-replayed"
         got = [d.cpu().numpy() for d in dsts]
     from vr180_convert_amd import remapper
 
@@ -414,6 +451,102 @@ def api_case(rng, dev) -> tuple[str, int]:
     return desc, bad
 
 
+def auto_case(rng, dev) -> tuple[str, int]:
+    """radius='auto' with the radius never leaving the device (v1c_plan_run_auto; remapper.py:62-90 + :51-57): synthetic image
+    circles of random radius and offset, square-ish outputs, every interpolation, one transformer or one per eye -- against the
+    oracle's apply_lr(radius='auto'); where the device-resident form declines (fix-up pass needed) the exact one is compared."""
+    from vr180_convert_amd import remapper
+
+    mid = []
+    if rng.random() < 0.3:
+        mid.append(("poly", [0.0, 1.0, float(rng.uniform(-0.15, 0.08))]))
+    if rng.random() < 0.3:
+        mid.insert(0, ("rot", rand_rot(rng, False).tolist()))
+    spec = [("equirect_enc", True)] + mid + [("fisheye_dec", "equidistant" if rng.random() < 0.8 else MODELS[int(rng.integers(5))])]
+    cn = int(rng.choice([3, 3, 3, 1, 4]))
+    interp = int(rng.choice([4, 4, 1, 1, 0, 2]))
+    border = int(rng.choice([0, 0, 0, 1, 4]))
+    hs, ws = int(rng.integers(64, 900)), int(rng.integers(64, 900))
+    if rng.random() < 0.6:
+        ws = (ws + 3) & ~3
+    wo = int(rng.integers(64, 1100))
+    ho = wo if rng.random() < 0.7 else max(16, wo + int(rng.integers(-80, 80)))
+    tuple_t = rng.random() < 0.25
+
+    def disc():
+        im = rng.integers(30, 256, (hs, ws, cn), dtype=np.uint8)
+        yy, xx = np.mgrid[:hs, :ws]
+        r = min(hs, ws) * float(rng.uniform(0.25, 0.52))
+        cx, cy = ws / 2 + float(rng.uniform(-4, 4)), hs / 2 + float(rng.uniform(-4, 4))
+        im[((xx - cx) ** 2 + (yy - cy) ** 2) > r * r] = 0
+        return im
+
+    a, b = disc(), disc()
+    desc = f"AUTO spec={spec!r} cn={cn} interp={interp} border={border} out=({wo},{ho}) src=({ws},{hs}) tuple={tuple_t}"
+    try:
+        ra, rb = O.get_radius(a), O.get_radius(b)
+    except IndexError:
+        return desc + " (no black border: skipped)", 0
+    t = CS.to_product(spec)
+    tt = (t, t) if tuple_t else t
+    sbs = V.apply_lr_tensors(tt, torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), size_output=(wo, ho), interpolation=interp,
+                             boarder_mode=border, radius="auto", auto_radius_on_device=True)
+    form = remapper.last_auto_radius_form()
+    KINDS["auto:" + form] = KINDS.get("auto:" + form, 0) + 1
+    got = sbs.cpu().numpy()
+    bad = 0
+    for k, (im, r_used) in enumerate(((a, ra if tuple_t else max(ra, rb)), (b, rb if tuple_t else max(ra, rb)))):
+        xm, ym = O.get_map(spec, radius=r_used, size_input=(hs, ws), size_output=(wo, ho))
+        want = O.remap(im, xm, ym, interp, border, 0)
+        g = got[:, k * wo:(k + 1) * wo]
+        sing = ill_conditioned(spec, r_used, (hs, ws), (wo, ho))
+        if border in (1, 2, 3, 4):
+            sing |= ~((np.abs(xm) < 2.0 ** 20) & (np.abs(ym) < 2.0 ** 20))
+        d = (g != want).any(axis=2)
+        SINGULAR[0] += int((d & sing).sum())
+        bad += int((g != want)[~sing].sum())
+    return desc + f" form={form}", bad
+
+
+def fused_case(rng, dev) -> tuple[str, int]:
+    """v1c_remap_fused through raw ctypes (the one-shot export a foreign host binds: INTEGRATION.md): a lowered chain, pointers and
+    pitches, nothing of the Python plan cache in between."""
+    from vr180_convert_amd import _native
+    from vr180_convert_amd.chain import lower_for_get_map
+    from vr180_convert_amd.remapper import _stream_ptr, border_scalar
+
+    spec, _ = rand_spec(rng)
+    cn = int(rng.choice([3, 3, 1, 4]))
+    interp = int(rng.choice([1, 1, 0, 2, 4]))
+    border = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5]))
+    bval = tuple(int(x) for x in rng.integers(0, 256, 3))
+    wo, ho = rand_size(rng, 0.05), rand_size(rng, 0.05)
+    hs, ws = rand_size(rng, 0.05, 2), rand_size(rng, 0.05, 2)
+    if interp in (2, 4):
+        wo, ho = min(wo, 900), min(ho, 900)
+    radius = float(rng.uniform(0.3, 1.3) * min(ws, hs) / 2 + 1.0)
+    src = rng.integers(0, 256, (hs, ws, cn), dtype=np.uint8)
+    fill = rng.integers(0, 256, (ho, wo, cn), dtype=np.uint8)
+    s_d = make_view(rng, src, dev, allow_unaligned=True)
+    d_d = make_view(rng, fill.copy(), dev, allow_unaligned=True)
+    chain = lower_for_get_map(CS.to_product(spec), radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+    bv = border_scalar(bval)
+    import ctypes as C
+
+    rc = _native.lib().v1c_remap_fused(dev.index, _stream_ptr(dev), s_d.data_ptr(), hs, ws, s_d.stride(0), cn, d_d.data_ptr(), ho, wo, d_d.stride(0),
+                                       C.byref(chain), interp, border, bv.ctypes.data)
+    _native.check(rc, "v1c_remap_fused")
+    got = d_d.cpu().numpy()
+    xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+    want = O.remap(src, xm, ym, interp, border, bval, dst=fill.copy())
+    sing = ill_conditioned(spec, radius, (hs, ws), (wo, ho))
+    if border in (1, 2, 3, 4):
+        sing |= ~((np.abs(xm) < 2.0 ** 20) & (np.abs(ym) < 2.0 ** 20))
+    d = (got != want).any(axis=2)
+    SINGULAR[0] += int((d & sing).sum())
+    return f"FUSED spec={spec!r} cn={cn} interp={interp} border={border} bval={bval!r} out=({wo},{ho}) src=({ws},{hs}) radius={radius!r}", int((got != want)[~sing].sum())
+
+
 def radius_case(rng, dev) -> tuple[str, int]:
     """get_radius (transformer.py:108-140) as the device kernel against the oracle: random images with black margins, noise around the
     threshold, every channel count, pitched views, images wider than high and the other way round, none / several rises and falls"""
@@ -450,6 +583,8 @@ def main() -> int:
     ap.add_argument("--lut", type=float, default=0.15, help="share of cases that fuzz cv2.remap alone (v1c_remap_lut) on random maps")
     ap.add_argument("--hot", type=float, default=0.3, help="share of the chain cases drawn from the shapes the tuned kernels are selected for")
     ap.add_argument("--api", type=float, default=0.1, help="share of cases through apply() / apply_lr() on host arrays")
+    ap.add_argument("--auto", type=float, default=0.06, help="share of cases through apply_lr_tensors(radius='auto') with the radius on the device")
+    ap.add_argument("--fused", type=float, default=0.06, help="share of cases through v1c_remap_fused by raw ctypes")
     ap.add_argument("--only", type=int, default=None, help="run only this case number (reproduce)")
     ap.add_argument("--log", default=None)
     ap.add_argument("--trace", default=None, help="file that always holds the number of the case being run")
@@ -485,6 +620,10 @@ def main() -> int:
                 desc, bad = radius_case(rng, dev)
             elif r_kind < a.lut + 0.05 + a.api:
                 desc, bad = api_case(rng, dev)
+            elif r_kind < a.lut + 0.05 + a.api + a.auto:
+                desc, bad = auto_case(rng, dev)
+            elif r_kind < a.lut + 0.05 + a.api + a.auto + a.fused:
+                desc, bad = fused_case(rng, dev)
             else:
                 desc, bad = one_case(rng, dev, a.big)
         except Exception as e:  # noqa: BLE001 -- a refusal of the product (documented limits) is reported, not fatal

@@ -157,6 +157,12 @@ __host__ __device__ inline bool lean_raw_static_ok(const TileBox& b, int nwp, in
     return b.interior != 0 && b.nidx > 0 && b.nidx <= kTabSlice && raw_box_ok(b.x0, b.y0, b.cpr, b.nrows, nwp, src_h, src_w);
 }
 
+#ifndef V1C_LEAN_SYS_STORE
+// the batch kernel's stores at system scope like the mirror pair kernels' (store4<SYS = 1>: written through to memory, the two halves of a
+// 128-byte line two tiles share no longer leave L2 twice): a 16-unit C3 launch writes 398.4 MB for its 398.1 MB of output instead of
+// 422.9 MB, at 0.1780 against 0.1784 ms (profiles/r05c_mid/ab_c3_system_scope_stores.log; round 3 had measured the time only: "+-0")
+#define V1C_LEAN_SYS_STORE 1
+#endif
 template <int VAR_W, int ROT, int OWN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (OWN ? 5 : V1C_LEAN_WAVES), 8))) void k_ray_lin3_batch_lean_raw(TileArgs a_)
 {
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
             pix[k] = blend3<3>(__builtin_amdgcn_alignbyte(a1, a0, a), __builtin_amdgcn_alignbyte(a2, a1, a), __builtin_amdgcn_alignbyte(b1, b0, a),
                                __builtin_amdgcn_alignbyte(b2, b1, a), W[k]);
         }
-        store_interior(U, z0 + u, t, pix);
+        store_interior<V1C_LEAN_SYS_STORE>(U, z0 + u, t, pix);
         issued += 1;  // the unit's store (at least one instruction; more only make the next wait longer than needed)
         cur = cur == (uint32_t)(R - 1) * box_bytes ? 0u : cur + box_bytes;
         slot = slot == R - 1 ? 0 : slot + 1;
@@ -290,6 +296,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
 // load -> compute -> barrier prologue and 12 LDS reads per lane and unit); removed in round 4.)
 #ifndef V1C_ROTPAIR_WAVES
 #define V1C_ROTPAIR_WAVES 5
+#endif
+#ifndef V1C_ROTPAIR_XCOLS
+#define V1C_ROTPAIR_XCOLS 0  // 1 (A/B builds): grid columns padded to a multiple of 8, so that XCD x serves the tile COLUMNS x, x + 8, ...
+                             // (vertically adjacent tiles -- which share their halo rows -- on one L2) without any index arithmetic
 #endif
 constexpr int kRotPairRedInts = 32;
 
@@ -347,6 +357,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     int btx = blockIdx.x, bty = blockIdx.y;
     if (a.strip_len)
         xcd_tile(a.tiles_x_magic, a.strip_len, a.strip_magic, btx, bty);
+#if V1C_ROTPAIR_XCOLS
+    if (btx * kTW >= a.dst_w)  // (the grid's columns are padded to a multiple of 8: see the launcher)
+        return;
+#endif
     const int zA = 2 * (int)blockIdx.z, zB = zA + 1;
     const bool hasB = zB < a.n_units;
     const int slot_bytes = a.kb;
@@ -734,7 +748,7 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
         if (!bx && shared_entry && !rot_pair_off && !nn) {
             if (kind)
                 *kind = V1C_LAUNCH_ROT_PAIR;
-            const dim3 pgrid(grid.x, grid.y, (unsigned)((n_units + 1) / 2));
+            const dim3 pgrid(V1C_ROTPAIR_XCOLS ? ((grid.x + 7u) & ~7u) : grid.x, grid.y, (unsigned)((n_units + 1) / 2));
             const size_t plds = (size_t)std::max(2 * rot_pair_slot, kBoxBytes + 16) + kRotPairRedInts * sizeof(int);
             const bool mp = mpoly_all && c.ray.radial_m != nullptr;
             a.kb = rot_pair_slot;

@@ -1127,9 +1127,10 @@ __device__ __forceinline__ uint8_t* dst_ptr(units_cptr U, int z, const TileIds& 
     return U[z].dst + (__umul24((uint32_t)t.j, (uint32_t)U[z].dst_pitch) + (uint32_t)t.x0 * 3u);
 }
 
+template <int SYS = 0>
 __device__ __forceinline__ void store_interior(units_cptr U, int z, const TileIds& t, const uint32_t (&pix)[kPX])
 {
-    store4(dst_ptr(U, z, t), pix, 0xFu, dst_rows_dword_aligned(U, z));
+    store4<SYS>(dst_ptr(U, z, t), pix, 0xFu, dst_rows_dword_aligned(U, z));
 }
 
 // ---- slow-path patch (pixels with valid coordinates the tiled path did not produce) and store ----
