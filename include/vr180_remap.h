@@ -148,6 +148,13 @@ int v1c_device_count(void);
 /* Thread-local message of the last failing call ("" if none). */
 const char* v1c_last_error(void);
 
+/* NUMERICAL CONTRACT of every entry point that evaluates a chain: coordinates in float64, cast to float32 like remapper.py:58; the
+ * 1/32-pixel buckets cv2.remap derives from them equal the reference's, pixels equal the CPU oracle's byte for byte -- except at
+ * pixels where the CHAIN is ill-conditioned (a map coordinate moving by >= 1e6 x the perturbation of the output position: the pole of
+ * a rectilinear projection, stacked polynomials taking an angle to 1e12 rad): there the last bit of the platform's sin / cos / atan2
+ * decides the bucket.  BORDER_CONSTANT / BORDER_TRANSPARENT outputs are unaffected (such coordinates lie 1e6+ px outside the source);
+ * under the four source-reading border modes those pixels may differ from the reference's.  INTEGRATION.md section 2.             */
+
 /* Build a reusable plan for one (chain, geometry, interpolation, border) combination.
  * Replaces: chain construction + np.meshgrid + MultiTransformer.transform + astype(float32)
  * of get_map() (remapper.py:50-58) -- here nothing is materialised: the plan only holds the

@@ -36,8 +36,9 @@ int main()
     float* xm = (float*)std::malloc(sizeof(float) * W * H);
     float* ym = (float*)std::malloc(sizeof(float) * W * H);
     long long st[5];
-    // ray-shaped chains (equidistant, polynomial with even terms -> w table, rotation) and literal-only chains
-    for (int variant = 0; variant < 6; variant++) {
+    // ray-shaped chains (equidistant, polynomial with even terms -> w table, rotation), planar chains (fused since round 5: 4, 5), the
+    // general modes (6: lat_x, 7: planar + rotation, 8: a rotation behind a radial stage) and a literal-only chain (9: a decoder last)
+    for (int variant = 0; variant < 10; variant++) {
         v1c_chain ch;
         std::memset(&ch, 0, sizeof(ch));
         int n = 0;
@@ -49,15 +50,32 @@ int main()
             if (variant & 2)
                 set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_POLYNOMIAL, {0.0, 1.0, -0.1});
             set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_DEC_EQUIDISTANT, {});
-        } else {
+        } else if (variant < 6) {
             set_op(ch.ops[n++], V1C_OP_RADIAL, variant == 4 ? V1C_RAD_ENC_ORTHOGRAPHIC : V1C_RAD_ENC_STEREOGRAPHIC, {});  // NaN producer
             set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_DEC_EQUIDISTANT, {});
+        } else if (variant == 6) {
+            set_op(ch.ops[n++], V1C_OP_EQUIRECT_ENC, 0, {});
+            set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_DEC_EQUIDISTANT, {});
+        } else if (variant == 7) {
+            set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_ENC_EQUIDISTANT, {});
+            set_op(ch.ops[n++], V1C_OP_ROTATE, 0, {0.8, 0.0, 0.6, 0.0, 1.0, 0.0, -0.6, 0.0, 0.8});
+            set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_DEC_EQUIDISTANT, {});
+        } else if (variant == 8) {
+            set_op(ch.ops[n++], V1C_OP_EQUIRECT_ENC, 1, {});
+            set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_POLYNOMIAL, {0.0, 1.0, -0.1});
+            set_op(ch.ops[n++], V1C_OP_ROTATE, 0, {0.8, 0.0, 0.6, 0.0, 1.0, 0.0, -0.6, 0.0, 0.8});
+            set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_DEC_EQUIDISTANT, {});
+        } else {
+            set_op(ch.ops[n++], V1C_OP_RADIAL, V1C_RAD_ENC_EQUIDISTANT, {});
+            set_op(ch.ops[n++], V1C_OP_EQUIRECT_DEC, 1, {});
         }
         set_op(ch.ops[n++], V1C_OP_DENORMALIZE, 0, {20.0, 20.0, 24.0, 20.0});
         ch.n_ops = n;
         fails += emul_get_map(&ch, nullptr, W, H, 0, xm, ym, st) != 0;
         const int rc = emul_get_map(&ch, nullptr, W, H, 1, xm, ym, st);
-        fails += variant < 4 ? rc != 0 : rc == 0;  // only the equirect-first chains have the ray shape
+        fails += variant < 9 ? rc != 0 : rc == 0;  // everything but the decoder chain has a fused form
+        long long info[12];
+        fails += emul_plan_info(&ch, W, H, info) != 0;
         if (variant == 1) {  // per-unit rotation override
             const double r2[9] = {1, 0, 0, 0, 0.96, -0.28, 0, 0.28, 0.96};
             fails += emul_get_map(&ch, r2, W, H, 1, xm, ym, st) != 0;

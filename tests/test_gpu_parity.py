@@ -1573,6 +1573,8 @@ def test_bench_split_modes_rehearsal(split, workload):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["parity_vs_oracle"]["bytes_differing"] == 0, line["parity_vs_oracle"]
     assert line["config"]["split"] == split and line["scaling"] == ("weak" if split == "frames" else "strong")
+    # what the process group reported travels in the line: a single process says so ...
+    assert line["world_size_seen"] == 1 and line["backend"].startswith("none") and len(line["per_rank_kernel_ms"]) == 1
     if split == "frames":
         return
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", *common, "--no-cpu-baseline"], env=env, capture_output=True,
@@ -1580,6 +1582,8 @@ def test_bench_split_modes_rehearsal(split, workload):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line2["n_gpus"] == 2 and line2["scaling"] == "strong" and "REHEARSAL" in line2["data"]
+    # ... and N ranks show the backend and the world size torch.distributed saw (the rehearsal: gloo; the driver's run: nccl = RCCL)
+    assert line2["world_size_seen"] == 2 and line2["backend"] == "gloo" and len(line2["per_rank_kernel_ms"]) == 2
     # strong scaling: the job is ONE pair whatever the rank count
     px = 2 * 2048 * 2048
     assert abs(line2["value"] * line2["ms_per_step"] * 1e3 - px) / px < 0.02

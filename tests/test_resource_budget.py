@@ -90,6 +90,8 @@ def test_hot_kernels_keep_their_occupancy(product_kernels):
         r"k_ray_lin3_batch_lean_rawILi0ELi0ELi0EE": 80,     # C3 batches: 6
         r"k_ray_lin3_rot_pair_rawILi0ELi1ELi1EE": 96,       # C5 per-unit rotations: 5
         r"k_ray_lin3_tileILi1ELi1ELi1ELi8ELi0ELi1ELi0ELi0EE": 128,  # C4 Lanczos4 pair: 4
+        r"k_ray_lin3_tileILi[01]ELi[01]ELi1ELi4ELi0ELi1ELi0ELi0EE": 80,  # bicubic pairs: 6 (the two-round staging of round 5 had cost them 27 VGPRs)
+        r"k_ray_lin3_tileILi[01]ELi[01]ELi1ELi2ELi0ELi1ELi0ELi0EE": 96,  # bilinear pairs through the general tile kernel (rotated; rest tiles): 5
         r"k_ray_lin_cnILi1ELi0ELi[14]ELi0ELi2ELi1EE": 64,   # gray / BGRA bilinear pairs (w-table): 8
         r"k_ray_lin_cnILi0ELi0ELi[14]ELi0ELi2ELi1EE": 72,   # (m-table): 7
     }

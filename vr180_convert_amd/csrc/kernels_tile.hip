@@ -453,12 +453,16 @@ size_t tile_box_bytes(const Geom& g)
 // (capped at kMaxHalfDwords: larger boxes gather from global memory)
 constexpr int kMaxHalfDwords = 8192;  // 32 KB per buffer
 
-int tile_half_dwords(const void* host_boxes, size_t n_tiles)
+// `max_chunks`: boxes of more chunks are left out (they gather from global memory): 1024 = one staging round; the pair code stages a
+// second round (shared_map_tile) -- worth its LDS for bicubic / Lanczos4, whose global-memory path samples tap by tap (a lat_x Lanczos4
+// pair: 1.09 -> 0.12 ms), not for bilinear launches, where the larger buffers cost every tile occupancy (the same pair bilinear:
+// 0.050 -> 0.060 ms with them)
+int tile_half_dwords(const void* host_boxes, size_t n_tiles, int max_chunks)
 {
     const TileBox* b = (const TileBox*)host_boxes;
     int m = 256;
     for (size_t i = 0; i < n_tiles; i++) {
-        if (b[i].cpr <= 0 || b[i].cpr > kMaxCpr || b[i].nrows * b[i].cpr > 2048)  // (the pair code stages up to 8 x 256 chunks: shared_map_tile)
+        if (b[i].cpr <= 0 || b[i].cpr > kMaxCpr || b[i].nrows * b[i].cpr > max_chunks)
             continue;
         const int need = b[i].nrows * (b[i].cpr * 4 + 4);
         if (need <= kMaxHalfDwords)

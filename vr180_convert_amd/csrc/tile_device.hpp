@@ -1141,6 +1141,9 @@ __device__ __forceinline__ void patch_and_store(ctx_cref c, units_cptr U, int z,
     geom_cref g = c.g;
     const unsigned slow = L.ok & ~done;
     unsigned skip = 0;  // BORDER_TRANSPARENT: pixels the sampler leaves untouched (bilinear: 2 x 2 footprint not inside; K x K: centre tap outside)
+    // (Under BORDER_CONSTANT a valid K x K pixel that is not `inside` -- lane_coords' ext: the footprint overlaps the source -- has its whole
+    //  footprint outside and is the border value; giving it that value here instead of through the sampler's early return was measured:
+    //  C4 +0.7 %, C2C +1.5 % (profiles/r05c_mid/ab_far_pixels_border_value.log) -- the selects cost every tile more than the calls cost the few.)
     if (slow) {
         if (K == 2) {
             // one inlined copy in a rolled loop (a call would pin every live value above the 40
@@ -1301,9 +1304,15 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
     // stores: no extra registers).  A 64 x 16 tile of an EquirectangularEncoder(is_latitude_y=False) chain has its long side along a
     // meridian: bounding boxes of up to 1 900 chunks under Lanczos4 where the lat_y configurations stay below 1 000 -- a third of
     // such a launch's tiles gathered every tap from global memory before (P3L 1.09 ms).
-    // (not in the unrotated bilinear pair instantiations: they are compiled for 6 waves per SIMD -- the second round's code cost them 41 - 59
-    // spilled VGPRs -- and the boxes of an unrotated chain's 2 x 2 footprints never come near 4 NT chunks)
-    constexpr bool kTwoRounds = PAIR && !LEAN && (ROT != 0 || K != 2);
+    // (not in the bilinear pair instantiations of the classic modes: the unrotated ones are compiled for 6 waves per SIMD -- the second
+    // round's code cost them 41 - 59 spilled VGPRs -- and the boxes of their 2 x 2 footprints never come near 4 NT chunks)
+#ifndef V1C_TWO_ROUNDS
+#define V1C_TWO_ROUNDS 1
+#endif
+    // (nor in any other instantiation of the classic modes: bicubic 78 -> 105 VGPRs, 6 -> 4 waves per SIMD, C2C +18 %; Lanczos4 -- bound by
+    // its callee's 117 VGPRs either way -- C1L +3 %, C4 +0.8 % on one box (profiles/r05c_mid/ab_kxk_round4_ext_only_final.log); the general
+    // modes (ROT = 2) run at 4 waves anyway and are the ones whose boxes need it)
+    constexpr bool kTwoRounds = V1C_TWO_ROUNDS && PAIR && !LEAN && ROT == 2;
     constexpr int kMaxChunks = kTwoRounds ? 8 * NT : 4 * NT;
     auto issue_m = [&](int z, Staged& S, const ChunkMap& Mx) -> bool {  // start the box loads of unit z; false: it must gather from global memory
         const uint8_t* __restrict__ src = !PAIR ? U[z].src : z == z0 ? usrc0 : z == z0 + 1 ? usrc1 : U[z].src;

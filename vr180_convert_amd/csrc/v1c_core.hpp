@@ -333,14 +333,16 @@ template <typename RP, typename RotPtr>
 V1C_HDF bool gen_vector(RP& P, RotPtr rot, double sl, double cl, double hl, double slon, double q, double& fx, double& fy,
                         double& m)
 {
+    // (written so that everything that depends on the row only -- B_k, T_k's factors -- is common to the 4 pixels of a lane: the tile
+    //  kernels unroll the pixel loop and the compiler evaluates those once)
     if (P.gen_mode == 1) {
-        const double vy = q * sl, vz = q * cl;
-        fx = fma(rot[0], slon, fma(rot[1], vy, rot[2] * vz));
-        fy = fma(rot[3], slon, fma(rot[4], vy, rot[5] * vz));
-        m = 1.0 - fma(rot[6], slon, fma(rot[7], vy, rot[8] * vz));
+        // R (s_c, c_c s_r, c_c c_r) = R_k0 s_c + (R_k1 s_r + R_k2 c_r) c_c
+        const double B0 = fma(rot[1], sl, rot[2] * cl), B1 = fma(rot[4], sl, rot[5] * cl), B2 = fma(rot[7], sl, rot[8] * cl);
+        fx = fma(rot[0], slon, B0 * q);
+        fy = fma(rot[3], slon, B1 * q);
+        m = 1.0 - fma(rot[6], slon, B2 * q);
         return true;
     }
-    const double bx = cl * slon, by = sl;
     const double m0 = fma(cl, q, hl);
     const double u = P.pre_var_is_w ? fast_sqrt_half(m0) : m0;
     const double t = u * P.pre_inv_step;
@@ -348,17 +350,26 @@ V1C_HDF bool gen_vector(RP& P, RotPtr rot, double sl, double cl, double hl, doub
     const bool in = (unsigned)idx < (unsigned)P.pre_n_int;
     const int ic = in ? idx : 0;
     const double z = t - ((double)ic + 0.5);
-    const double* cs = P.pre_s + (size_t)ic * kRadialCoefs;
-    const double* cc = P.pre_c + (size_t)ic * kRadialCoefs;
-    double S = cs[kRadialDegree], Cm = cc[kRadialDegree];
+    typedef double __attribute__((ext_vector_type(2))) d2v;  // (entries are 64-byte aligned: 16-byte loads)
+    const d2v* cs = (const d2v*)(P.pre_s + (size_t)ic * kRadialCoefs);
+    const d2v* cc = (const d2v*)(P.pre_c + (size_t)ic * kRadialCoefs);
+    double es[kRadialCoefs], ec[kRadialCoefs];
+#pragma unroll
+    for (int k = 0; k < kRadialCoefs / 2; k++) {
+        const d2v a = cs[k], b = cc[k];
+        es[2 * k] = a.x, es[2 * k + 1] = a.y, ec[2 * k] = b.x, ec[2 * k + 1] = b.y;
+    }
+    double S = es[kRadialDegree], Cm = ec[kRadialDegree];
 #pragma unroll
     for (int k = kRadialDegree - 1; k >= 0; k--)
-        S = fma(S, z, cs[k]), Cm = fma(Cm, z, cc[k]);
-    const double sx = S * bx, sy = S * by, vz = 1.0 - Cm;
-    fx = fma(rot[0], sx, fma(rot[1], sy, rot[2] * vz));
-    fy = fma(rot[3], sx, fma(rot[4], sy, rot[5] * vz));
-    // 1 - (R v)_z without the cancellation of 1 - (... + r22 (1 - Cm)): (1 - r22) + r22 Cm - r20 S b_x - r21 S b_y
-    m = fma(-rot[6], sx, fma(-rot[7], sy, fma(rot[8], Cm, 1.0 - rot[8])));
+        S = fma(S, z, es[k]), Cm = fma(Cm, z, ec[k]);
+    // R (S b_x, S b_y, 1 - Cm) with the base point b = (cl slon, sl): S T_k + R_k2 (1 - Cm), T_k = (R_k0 cl) slon + R_k1 sl
+    const double vz = 1.0 - Cm;
+    const double T0 = fma(rot[0] * cl, slon, rot[1] * sl), T1 = fma(rot[3] * cl, slon, rot[4] * sl), T2 = fma(rot[6] * cl, slon, rot[7] * sl);
+    fx = fma(S, T0, rot[2] * vz);
+    fy = fma(S, T1, rot[5] * vz);
+    // 1 - (R v)_z without the cancellation of 1 - (... + r22 (1 - Cm)): (1 - r22) + r22 Cm - S T_2
+    m = fma(-S, T2, fma(rot[8], Cm, 1.0 - rot[8]));
     return in;  // (flagged intervals carry NaN coefficients: the coordinates come out NaN and fail the caller's range test)
 }
 
