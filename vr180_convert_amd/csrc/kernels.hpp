@@ -58,7 +58,8 @@ struct TileArgs {
     int n_units, upb;            // units of the launch, units per workgroup group
     int half_dwords, n_rest;     // LDS dwords per box buffer of the general pair / batch code; entries of rest_list
     unsigned tiles_x_magic, strip_len, strip_magic, rest_rows;  // xcd_tile(); rows of workgroups in front of the grid that serve rest_list
-    int mirror_h, kb, tiles_x, pad;  // kb: box buffer KB of the LDS-DMA kernels (bytes for k_ray_lin3_rot_pair_raw)
+    int mirror_h, kb, tiles_x, same_rot;  // kb: box buffer KB of the LDS-DMA kernels (bytes for k_ray_lin3_rot_pair_raw); same_rot: launches
+                                          // without plan-time boxes whose units all carry ONE rotation (v1c_plan_run_auto): pairs share coordinates
     // copies of what a workgroup needs for its FIRST vector loads (the row / column table entries of its tile): with the pointers here
     // those loads go out one scalar round trip earlier, next to the reads of the plan's context instead of behind them
     const double *col_s, *col_c, *col_h, *row_s, *row_c, *row_h;  // = ctx->ray.*
@@ -113,7 +114,8 @@ int tile_half_dwords(const void* host_boxes, size_t n_tiles, int max_chunks = 10
 // (radial_table_g_bound): k_ray_lin3_rot_pair_raw evaluates its speculative coordinates without the clamps of the cvRound trick
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,
                                 int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
-                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded = false, int* kind = nullptr);
+                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded = false, int* kind = nullptr,
+                                bool same_rot = false);
 int tile_xcd_strips(const void* host_boxes, const Geom& g, int half_dwords, int lean_half);
 int tile_lean_half_dwords(int half_dwords);
 // `raw_nwp` > 0: batches through k_ray_lin3_batch_lean_raw (boxes by LDS-DMA, buffers of raw_nwp KB: tile_lean_raw_passes)

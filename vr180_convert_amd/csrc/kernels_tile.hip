@@ -107,6 +107,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BOXES && P
     }
 }
 
+// Bicubic / Lanczos4 without plan-time boxes for units that all carry ONE rotation (radius = "auto" on the device, v1c_plan_run_auto):
+// a workgroup serves the tile for units 2 z and 2 z + 1 with one evaluation of the coordinates, one reduced box and one fetch of each
+// pixel's weight rows (rot_shared_pair_tile).  Launched for an even number of units.
+template <int VAR_W, int K, int OWN>
+__global__ __launch_bounds__(256) void k_ray_kxk_auto_pair(TileArgs a_)
+{
+    __shared__ __attribute__((aligned(16))) int red[16];
+    __shared__ __attribute__((aligned(16))) uint32_t boxw[2 * (kBoxBytes / 4) + 4 + kKxkExchangeBytes / 4];
+    args_cref a = kernel_args();
+    const glb_u32_ptr wtab = (glb_u32_ptr)args_ctx(a).itab;
+    rot_shared_pair_tile<VAR_W, K, OWN>(a, 2 * (int)blockIdx.z, 2 * (int)blockIdx.z + 1, (int)blockIdx.x, (int)blockIdx.y, red, boxw, wtab);
+}
+
 #ifdef V1C_TUNING
 // The lean batch path of shared_map_tile as a kernel of its own (bilinear, plan-time boxes, more than
 // two units per workgroup; register-staged boxes): the A/B partner (V1C_LEAN_RAW=0) of k_ray_lin3_batch_lean_raw, tuning build only.
@@ -398,14 +411,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_ROTPAIR
     bool fastA, fastB = false;
     int nB = 0;
     lane_coords<VAR_W, 1, 2, 0, (NC ? 1 : 2), MP>(c, U[zA].rot, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LA);
-    fastA = raw_box(reduce_box_all_nofence<NT / 64>(LA, red, tid), zA, bA);
+    const BoxAll baA = reduce_box_all_nofence<NT / 64>(LA, red, tid);
+    fastA = raw_box(baA, zA, bA);
     if (fastA) {
         const RawLanes m = raw_lanes(bA.cpr, lane);
         raw_box_dma(bA, m, U[zA].src, (uint32_t)U[zA].src_pitch, lane, wave, lds0);
     }
     if (hasB) {
-        lane_coords<VAR_W, 1, 2, 0, (NC ? 1 : 2), MP>(c, U[zB].rot, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
-        fastB = raw_box(reduce_box_all_nofence<NT / 64>(LB, red + 16, tid), zB, bB);
+        if (a.same_rot) {
+            // every unit of the launch carries the same rotation (radius = "auto" on the device: v1c_plan_run_auto): the two units of
+            // the workgroup share the map -- one evaluation of the coordinates, one box geometry (wave-uniform branch)
+            LB = LA;
+            fastB = raw_box(baA, zB, bB);
+        } else {
+            lane_coords<VAR_W, 1, 2, 0, (NC ? 1 : 2), MP>(c, U[zB].rot, rc, kPX, MP ? P.radial_m : P.radial, 0, P.n_int, LB);
+            fastB = raw_box(reduce_box_all_nofence<NT / 64>(LB, red + 16, tid), zB, bB);
+        }
         if (fastB) {
             const RawLanes m = raw_lanes(bB.cpr, lane);
             nB = raw_box_dma(bB, m, U[zB].src, (uint32_t)U[zB].src_pitch, lane, wave, lds0 + (uint32_t)slot_bytes);
@@ -655,7 +676,7 @@ hipError_t launch_tile_boxes(const KernelCtx& c, const KernelCtx* cdev, void* bo
 template <int K>
 static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const TileBox* bx,
                           int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half, int strip_len,
-                          int lean_raw_nwp, hipStream_t stream, bool coords_bounded, int* kind)
+                          int lean_raw_nwp, hipStream_t stream, bool coords_bounded, int* kind, bool same_rot)
 {
     const int n_units = lu.n;
     // with precomputed boxes a workgroup serves up to kUnitsPerBlock units that share the map
@@ -731,6 +752,24 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
     }();
     TileArgs a = tile_args(c, cdev, lu, flags);
     a.boxes = bx;
+    a.same_rot = (!bx && same_rot) ? 1 : 0;
+    if constexpr (K != 2) {
+        if (a.same_rot && n_units % 2 == 0 && c.g.interp != V1C_INTER_NEAREST) {
+            const dim3 pgrid(grid.x, grid.y, (unsigned)(n_units / 2));
+            if (c.ray.var_is_w) {
+                if (shared_entry)
+                    hipLaunchKernelGGL((k_ray_kxk_auto_pair<1, K, 0>), pgrid, block, 0, stream, a);
+                else
+                    hipLaunchKernelGGL((k_ray_kxk_auto_pair<1, K, 1>), pgrid, block, 0, stream, a);
+            } else {
+                if (shared_entry)
+                    hipLaunchKernelGGL((k_ray_kxk_auto_pair<0, K, 0>), pgrid, block, 0, stream, a);
+                else
+                    hipLaunchKernelGGL((k_ray_kxk_auto_pair<0, K, 1>), pgrid, block, 0, stream, a);
+            }
+            return;
+        }
+    }
     a.upb = upb, a.half_dwords = half_dwords;
     a.tiles_x = (int)grid.x;
     a.tiles_x_magic = (unsigned)(0x100000000ull / grid.x) + 1u;
@@ -883,15 +922,15 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
 // `flags`: the plan's tile-flag words when a fix-up pass follows this launch, else null.
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,
                                 int half_dwords, bool shared_entry, bool mpoly_all, const uint32_t* rest_list, int n_rest, int lean_half,
-                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded, int* kind)
+                                int strip_len, int lean_raw_nwp, hipStream_t stream, bool coords_bounded, int* kind, bool same_rot)
 {
     const TileBox* bx = (const TileBox*)boxes;
     if (kind)
         *kind = V1C_LAUNCH_TILE;  // (the general kernel, unless launch_tile_k picks the batch / rotation-pair kernel)
     switch (taps_of(c.g.interp)) {
-    case 2: launch_tile_k<2>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind); break;
-    case 4: launch_tile_k<4>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind); break;
-    case 8: launch_tile_k<8>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind); break;
+    case 2: launch_tile_k<2>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind, same_rot); break;
+    case 4: launch_tile_k<4>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind, same_rot); break;
+    case 8: launch_tile_k<8>(c, cdev, lu, flags, use_rot, bx, half_dwords, shared_entry, mpoly_all, rest_list, n_rest, lean_half, strip_len, lean_raw_nwp, stream, coords_bounded, kind, same_rot); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1058,6 +1058,9 @@ extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* unit
         du[k].has_rot = 1;  // (every unit carries its effective rotation: the kernels without plan-time boxes read it)
         aligned = aligned && ((((uintptr_t)du[k].src) | (uintptr_t)du[k].src_pitch) & 3u) == 0;
     }
+    bool same_rot = true;  // every unit the same rotation (no overrides, or identical ones): pairs of units share their coordinates
+    for (int k = 1; k < n_units && same_rot; k++)
+        same_rot = std::memcmp(du[k].rot, du[0].rot, sizeof(du[0].rot)) == 0;
     // any radius a caller can mean: the image circle a few times the source's size at most (the patch kernel clamps to it)
     const double r_limit = 4.0 * (double)std::max(g.src_h, g.src_w);
     const LaunchPlan d = decide_launch(p, du, n_units, 32.0 * r_limit);
@@ -1086,7 +1089,7 @@ extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* unit
     } else {
         kind = V1C_LAUNCH_TILE;
         HIP_TRY(launch_ray_lin3_tile(p->ctx, p->ctx_dyn, lu, nullptr, true, nullptr, p->half_dwords, shared, d.mpoly_all && !p->disable_mpoly, nullptr, 0,
-                                     p->lean_half, p->strip_len, p->lean_raw_nwp, st, d.coords_bounded && !p->disable_coords_bounded, &kind));
+                                     p->lean_half, p->strip_len, p->lean_raw_nwp, st, d.coords_bounded && !p->disable_coords_bounded, &kind, same_rot));
     }
     HIP_TRY(hipEventRecord(p->dyn_ev, st));
     p->dyn_stream = st, p->dyn_pending = true;

@@ -1234,6 +1234,76 @@ __device__ __forceinline__ void sample_and_store(ctx_cref c, units_cptr U, int z
     patch_and_store<K, NN>(c, U, z, t, L, pix, done, src);
 }
 
+// ---- K x K taps (bicubic / Lanczos4) of the two eyes of a pair from interleaved cells, against ONE fetch of each pixel's weight rows ----
+// `cells`: the (A_i, B_i) cells of the box `b` (stage_store_pair); `xch`: kKxkExchangeBytes of LDS behind them.
+template <int K, typename WPtr>
+__device__ __forceinline__ void kxk_pair_gather(int tid, const LaneCoords& L, const TileBox& b, uint32_t* cells, uint32_t* xch, WPtr wtab,
+                                                uint32_t (&pa)[kPX], uint32_t (&pb)[kPX])
+{
+    uint32_t* const boxw = cells;
+    constexpr int off = K / 2 - 1;
+    const int lpw = b.cpr * 4 + 4;
+    if (kLanesX == 16 && !V1C_KXK_OWN_LANES) {
+        // The gather runs in ANOTHER lane -> pixel mapping than the coordinates and the stores: slot k of lane l
+        // samples column 16 k + (l & 15) of the lane's tile row, so that the 16 lanes LDS serves together read
+        // ADJACENT cells (with 4 adjacent pixels per lane they read every 4th cell: 4-way bank conflicts at best;
+        // the Lanczos4 pair had its LDS 67 % busy, 59 % of that conflicts -- tools/ubench/lanczos_pair_forms.hip:
+        // sampler alone 1.29 - 1.93 -> 0.96 - 1.29 ms at C4's size).  Tap origin and weight entry travel as one
+        // dword through a wave-private KB of LDS behind the boxes, the two result pixels come back the same way
+        // (a wave's LDS operations execute in order: no barrier, only compiler fences).
+        const int lane = tid & 63;
+        uint32_t* xw = xch + (tid >> 6) * 256;  // [row of the wave][column of the tile]
+        u128 own;
+        uint32_t pk[kPX];
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+            const bool in = (L.inside >> k) & 1;
+            const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;  // < 2^14 cells
+            pk[k] = (lo << 10) | (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
+        }
+        own.x = pk[0], own.y = pk[1], own.z = pk[2], own.w = pk[3];
+        ((u128*)xw)[lane] = own;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t* col = xw + (lane >> 4) * 64 + (lane & 15);
+        uint32_t gk[kPX];
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            gk[k] = col[16 * k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // (requesting the weight row of slot k + 1 before slot k is blended -- 32 more VGPRs, the blend inlined in a
+        // rolled loop -- measured 5 % SLOWER on C4 than these four calls)
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const uint64_t pp = blend_table_pair<K>((lds_cell_ptr)boxw, gk[k] >> 10, lpw, wtab + (gk[k] & 1023u) * (K * K / 2));
+            pa[k] = (uint32_t)pp, gk[k] = (uint32_t)(pp >> 32);
+        }
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            col[16 * k] = pa[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        own = ((const u128*)xw)[lane];
+        pa[0] = own.x, pa[1] = own.y, pa[2] = own.z, pa[3] = own.w;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int k = 0; k < kPX; k++)
+            col[16 * k] = gk[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        own = ((const u128*)xw)[lane];
+        pb[0] = own.x, pb[1] = own.y, pb[2] = own.z, pb[3] = own.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPX; k++) {
+            const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
+            const bool in = (L.inside >> k) & 1;
+            const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
+            const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
+            const uint64_t pp = blend_table_pair<K>((lds_cell_ptr)boxw, lo, lpw, wtab + a * (K * K / 2));
+            pa[k] = (uint32_t)pp, pb[k] = (uint32_t)(pp >> 32);
+        }
+    }
+}
+
 // ---- one tile for up to `upb` units that share the map (plan-time boxes) ----
 // The units of one launch share the map (the reference computes ONE map per apply() call,
 // remapper.py:381-398: both eyes of a pair, all frames of a batch), so the workgroup evaluates the
@@ -1526,68 +1596,8 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
         if constexpr (K != 2) {
         if (nu == 2 && fit0 && fit1) {
             // K x K taps of both eyes against one fetch of the weight row
-            constexpr int off = K / 2 - 1;
-            const int lpw = b.cpr * 4 + 4;
             uint32_t pa[kPX], pb[kPX];
-            if (kLanesX == 16 && !V1C_KXK_OWN_LANES) {
-                // The gather runs in ANOTHER lane -> pixel mapping than the coordinates and the stores: slot k of lane l
-                // samples column 16 k + (l & 15) of the lane's tile row, so that the 16 lanes LDS serves together read
-                // ADJACENT cells (with 4 adjacent pixels per lane they read every 4th cell: 4-way bank conflicts at best;
-                // the Lanczos4 pair had its LDS 67 % busy, 59 % of that conflicts -- tools/ubench/lanczos_pair_forms.hip:
-                // sampler alone 1.29 - 1.93 -> 0.96 - 1.29 ms at C4's size).  Tap origin and weight entry travel as one
-                // dword through a wave-private KB of LDS behind the boxes, the two result pixels come back the same way
-                // (a wave's LDS operations execute in order: no barrier, only compiler fences).
-                const int lane = tid & 63;
-                uint32_t* xw = boxw + 2 * half_dwords + (tid >> 6) * 256;  // [row of the wave][column of the tile]
-                u128 own;
-                uint32_t pk[kPX];
-#pragma unroll
-                for (int k = 0; k < kPX; k++) {
-                    const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-                    const bool in = (L.inside >> k) & 1;
-                    const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;  // < 2^14 cells
-                    pk[k] = (lo << 10) | (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
-                }
-                own.x = pk[0], own.y = pk[1], own.z = pk[2], own.w = pk[3];
-                ((u128*)xw)[lane] = own;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint32_t* col = xw + (lane >> 4) * 64 + (lane & 15);
-                uint32_t gk[kPX];
-#pragma unroll
-                for (int k = 0; k < kPX; k++)
-                    gk[k] = col[16 * k];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // (requesting the weight row of slot k + 1 before slot k is blended -- 32 more VGPRs, the blend inlined in a
-                // rolled loop -- measured 5 % SLOWER on C4 than these four calls)
-#pragma unroll
-                for (int k = 0; k < kPX; k++) {
-                    const uint64_t pp = blend_table_pair<K>((lds_cell_ptr)boxw, gk[k] >> 10, lpw, wtab + (gk[k] & 1023u) * (K * K / 2));
-                    pa[k] = (uint32_t)pp, gk[k] = (uint32_t)(pp >> 32);
-                }
-#pragma unroll
-                for (int k = 0; k < kPX; k++)
-                    col[16 * k] = pa[k];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                own = ((const u128*)xw)[lane];
-                pa[0] = own.x, pa[1] = own.y, pa[2] = own.z, pa[3] = own.w;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-                for (int k = 0; k < kPX; k++)
-                    col[16 * k] = gk[k];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                own = ((const u128*)xw)[lane];
-                pb[0] = own.x, pb[1] = own.y, pb[2] = own.z, pb[3] = own.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < kPX; k++) {
-                    const int ix = L.sx[k] >> 5, iy = L.sy[k] >> 5;
-                    const bool in = (L.inside >> k) & 1;
-                    const uint32_t lo = in ? __umul24(iy - off - b.y0, lpw) + (uint32_t)(ix - off - b.x0) : 0u;
-                    const uint32_t a = (uint32_t)((L.sy[k] & 31) * 32 + (L.sx[k] & 31));
-                    const uint64_t pp = blend_table_pair<K>((lds_cell_ptr)boxw, lo, lpw, wtab + a * (K * K / 2));
-                    pa[k] = (uint32_t)pp, pb[k] = (uint32_t)(pp >> 32);
-                }
-            }
+            kxk_pair_gather<K>(tid, L, b, boxw, boxw + 2 * half_dwords, wtab, pa, pb);
             patch_and_store<K, NN>(c, U, z0, t, L, pa, L.inside, U[z0].src);
             patch_and_store<K, NN>(c, U, z0 + 1, t, L, pb, L.inside, U[z0 + 1].src);
             return;
@@ -1758,6 +1768,61 @@ __device__ __forceinline__ void rot_unit_tile(args_cref a, int z, int btx, int b
         if (uint32_t* flags = a.tile_flags)
             flags[t.flag_tile] = 1;
     sample_and_store<K, NN>(c, U, z, t, L, b, use_lds, boxw, wtab, src, spitch);
+}
+
+// ---- one tile of TWO units that carry the same rotation, without plan-time boxes (bicubic / Lanczos4): v1c_plan_run_auto ----
+// radius = "auto" on the device runs the kernels that reduce their boxes themselves; its units share the map (one transformer, one
+// radius: remapper.py:474-484), so the two eyes of a pair take ONE evaluation of the coordinates, one box geometry, and -- as in the
+// pair path of shared_map_tile -- one fetch of every pixel's weight rows for both (interleaved cells, kxk_pair_gather).
+// `red`: 16 ints; `boxw`: 2 kBoxBytes + 16 bytes of cells followed by kKxkExchangeBytes.  A pair whose boxes do not fit 24 KB per eye
+// (strong minification: rare) samples every pixel through the border-aware per-pixel sampler.
+template <int VAR_W, int K, int OWN, int NN = 0, typename WPtr>
+__device__ __forceinline__ void rot_shared_pair_tile(args_cref a, int zA, int zB, int btx, int bty, int* red, uint32_t* boxw, WPtr wtab)
+{
+    constexpr int NT = 256;
+    ctx_cref c = args_ctx(a);
+    const units_cptr U = args_units(a);
+    geom_cref g = c.g;
+    ray_cref P = c.ray;
+    const int tid = threadIdx.x;
+    const TileIds t = tile_ids(g, zA, tid, btx, bty, gridDim.x, NT / kLanesX);
+    RowCol rc;
+    load_rowcol<1>(P, t.xc, t.jc, rc);
+    const int ext = kxk_ext(g);
+    LaneCoords L;
+    lane_coords<VAR_W, 1, K, OWN, 0, 0, 0, NN>(c, U[zA].rot, rc, t.npx, P.radial, 0, P.n_int, L, ext);
+    const TileBox b = reduce_box<K, NT / 64>(L, red, tid);
+    const uint8_t* __restrict__ srcA = U[zA].src;
+    const uint8_t* __restrict__ srcB = U[zB].src;
+    const uint32_t pitchA = (uint32_t)U[zA].src_pitch, pitchB = (uint32_t)U[zB].src_pitch;
+    const bool fits = box_fits(b, srcA, pitchA, 4 * NT, kBoxBytes / 4) & box_fits(b, srcB, pitchB, 4 * NT, kBoxBytes / 4);
+    if (!fits) {  // (wave-uniform)
+        uint32_t px[kPX] = {0, 0, 0, 0};
+        patch_and_store<K, NN>(c, U, zA, t, L, px, 0u, srcA);
+        patch_and_store<K, NN>(c, U, zB, t, L, px, 0u, srcB);
+        return;
+    }
+    ChunkMap M;
+    make_chunk_map<NT>(b, tid, M);
+    Staged SA, SB;
+    if (ext && box_leaves_source(b, g)) {
+        stage_load_ext<true>(M, srcA, pitchA, g, SA);
+        stage_load_ext<true>(M, srcB, pitchB, g, SB);
+    } else {
+        stage_load<true, true>(M, srcA, pitchA, (uint32_t)(g.src_h - 1) * pitchA + (uint32_t)g.src_w * 3u, SA);
+        stage_load<true, true>(M, srcB, pitchB, (uint32_t)(g.src_h - 1) * pitchB + (uint32_t)g.src_w * 3u, SB);
+    }
+    stage_store_pair(M, SA, SB, boxw);
+    __syncthreads();
+    if (L.ok != (1u << t.npx) - 1)
+        if (uint32_t* flags = a.tile_flags) {
+            flags[t.flag_tile] = 1;
+            flags[t.flag_tile + (zB - zA) * t.flag_stride] = 1;
+        }
+    uint32_t pa[kPX], pb[kPX];
+    kxk_pair_gather<K>(tid, L, b, boxw, boxw + 2 * (kBoxBytes / 4) + 4, wtab, pa, pb);
+    patch_and_store<K, NN>(c, U, zA, t, L, pa, L.inside, srcA);
+    patch_and_store<K, NN>(c, U, zB, t, L, pb, L.inside, srcB);
 }
 
 // ---- a pair (apply_lr) of an unrotated chain: a tile AND its mirror image about the equator per workgroup ----
