@@ -76,7 +76,7 @@ WORKLOADS = {
     "C2NN": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=0,
                  desc="L+R 4096x4096 -> 8192x4096 SBS, PolynomialScaler, INTER_NEAREST (not a BASELINE config: the bilinear tile kernels "
                       "with coordinates 32 * cvRound(x))"),
-    # configurations off the BASELINE list -- reporting only: gray / BGRA run k_ray_lin_cn (raw LDS-DMA boxes), bilinear
+    # configurations off the BASELINE list -- reporting only: gray / BGRA run k_ray_lin_cn (raw LDS-DMA boxes; HISTORY.md 4.5), bilinear
     # BORDER_TRANSPARENT the BGR tile kernels
     "C2G": dict(size=4096, poly=[0, 1, -0.1], rot=None, interp=1, cn=1,
                 desc="L+R 4096x4096 GRAY -> 8192x4096 SBS, PolynomialScaler, bilinear (k_ray_lin_cn since r03; not a BASELINE config)"),
@@ -765,7 +765,7 @@ def main() -> None:
         if cfg["interp"] in (2, 4) and not frames and not single:
             # INTER_CUBIC / INTER_LANCZOS4 are not HBM-bound: K x K taps x 3 channels x 2 eyes exact integer multiply-accumulates per
             # output position, one v_perm_b32 + one v_dot2_i32_i16 per two of them (OpenCV's int16 weights admit no cheaper exact form:
-            # DESIGN.md 4.5).  Ceiling = the VALU issue time of the kernel's instruction stream: waves x VALU instructions per wave x 4
+            # HISTORY.md 4.5).  Ceiling = the VALU issue time of the kernel's instruction stream: waves x VALU instructions per wave x 4
             # cycles per wave-instruction on 1024 SIMDs at the ~2.1 GHz the part sustains.  The instruction count is MEASURED by this
             # run (a `--pmc SQ_INSTS_VALU SQ_WAVES` child pass of the same workload: "source": "live"); without rocprofv3 the object
             # says so and carries no ceiling.  `frac` stays the HBM fraction (the metric); `valu_int` says how close the launch is to

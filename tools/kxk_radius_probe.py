@@ -1,5 +1,5 @@
 """Time of a bicubic / Lanczos4 apply_lr pair against the radius: f * n / 2 for f = 1 (the image circle touches the frame of the source --
-radius="max" -- and whole tiles next to the poles take the per-pixel patch path) down to 0.9.  DESIGN.md 4.5; profiles/r04d_final/kxk_border_tiles.log."""
+radius="max" -- and whole tiles next to the poles take the per-pixel patch path) down to 0.9.  HISTORY.md 4.5; profiles/r04d_final/kxk_border_tiles.log."""
 import sys, time
 from pathlib import Path
 import torch

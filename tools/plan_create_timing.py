@@ -1,5 +1,5 @@
 """Plan creation time for a stream of images whose radius moves by half a pixel (radius="auto"): the first plan of a chain fits its radial tables,
-the following ones take them from the per-process cache.  V1C_LIB=<other build> for a comparison."""
+the following ones take them from the per-process cache (HISTORY.md 6).  V1C_LIB=<other build> for a comparison."""
 import sys
 from pathlib import Path
 import torch

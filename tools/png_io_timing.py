@@ -1,5 +1,5 @@
 """Time the PNG writer / reader of vr180_convert_amd._png against Pillow on an 8192 x 4096 side-by-side frame
-(codecs are outside the measured path; this is the end-to-end apply_lr(png -> png) figure of DESIGN.md 6)."""
+(codecs are outside the measured path; this is the end-to-end apply_lr(png -> png) figure of HISTORY.md 6)."""
 import io
 import sys
 import time

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
 
 // (kernels_mirror.hip: round 3 also built k_ray_lin3_pair_mirror_pipe -- two tile rows per workgroup, the second pair's boxes requested into the
 // buffers the first pair had just been sampled from -- bit-exact and 5 % slower than one pair per workgroup at equal occupancy
-// (profiles/r03a_mid): "the workgroups do not wait for their boxes".  Removed in round 4 with its A/B switch.)
+// (profiles/r03a_mid, HISTORY.md 4.4c): "the workgroups do not wait for their boxes".  Removed in round 4 with its A/B switch.)
 
 // ---- batches (units sharing one map) with the boxes by LDS-DMA: k_ray_lin3_batch_lean's loop on raw boxes ----
 // V1C_LEAN_RING box buffers of nwp KB in a ring: unit u is sampled from its buffer while the boxes of the next ring - 1 units
@@ -914,7 +914,7 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
 // `boxes` may be null (the units override the rotation): then boxes are reduced in-kernel.
 // (A persistent variant keeping OpenCV's 128 KB Lanczos4 weight table in LDS was tried: with one
 // 512-thread workgroup per CU it cannot hide LDS latency and its 128-byte weight rows land on 8
-// banks -- 6x slower than reading the weights through L2.  See DESIGN.md 4.5.)
+// banks -- 6x slower than reading the weights through L2.  See HISTORY.md 4.5.)
 // `shared_entry`: no lane needs more than pixel 1's table entry (proved by the caller).
 // `mpoly_all` (boxes == null only): the m-polynomial table is valid on every interval these units reach.
 // `rest_list` / `n_rest` / `lean_half` (boxes != null; list may be null): device copy of tile_rest_list() and the box

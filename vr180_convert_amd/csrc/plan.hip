@@ -680,7 +680,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                         p->mirror_raw_nwp = rawv == 1 ? tile_mirror_raw_passes(hb.data(), hm.data(), g) : rawv > 1 ? std::min(rawv, 16) : 0;
                         // pairs: the eyes one after the other through two buffers of twice the size (k_ray_lin3_pair_mirror_seq: 99.8 % of
                         // the tile pairs fit, C2 -0.4 ... -2.6 %, C1 -1.6 ... -3 % against the four-buffer kernel on three boxes,
-                        // DESIGN.md 4.4c); V1C_MIRROR_SEQ=0 (A/B): k_ray_lin3_pair_mirror_raw for pairs too; V1C_MIRROR_SEQ_KB=<n>: buffer size
+                        // HISTORY.md 4.4c); V1C_MIRROR_SEQ=0 (A/B): k_ray_lin3_pair_mirror_raw for pairs too; V1C_MIRROR_SEQ_KB=<n>: buffer size
                         const char* seqsw = tuning_env("V1C_MIRROR_SEQ");
                         const char* seqkb = tuning_env("V1C_MIRROR_SEQ_KB");
                         if (p->mirror_raw_nwp > 0 && !(seqsw && seqsw[0] == '0'))

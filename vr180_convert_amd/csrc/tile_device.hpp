@@ -1025,7 +1025,7 @@ __device__ __noinline__ uint32_t slow_pixel_table3_t(const uint8_t* src, int64_t
 // a property of the unit (dst and its pitch), wave-uniform -- see dst_rows_dword_aligned().
 // SYS = 1 (the mirror pair kernels): the streaming stores at SYSTEM scope (`sc0 sc1 nt`: written through to memory, nothing
 // kept in L2).  With plain `nt` a 128-byte line that two workgroups write half each leaves L2 twice in part (1.10 x the bytes of
-// the image: DESIGN.md 4.4c); at system scope a C2 launch writes 99 312 KB for its 98 304 KB of output and runs 2 - 4 % faster
+// the image: HISTORY.md 4.4c); at system scope a C2 launch writes 99 312 KB for its 98 304 KB of output and runs 2 - 4 % faster
 // (profiles/r03d_final/ab_store_policy.log).  The batch, rotation and Lanczos4 launches measured equal or slower with it (C4 +3.8 %)
 // and keep `nt`.  No builtin selects that policy without the waits of a volatile access, so the store is written by hand; the
 // `s_nop 1` inside the statement is the two wait states gfx940+ needs between a store of more than 8 bytes and a VALU write of its
@@ -1887,7 +1887,7 @@ __host__ __device__ inline bool mirror_raw_static_ok(const TileBox& b, const Til
 // global_load_lds_dwordx4 copies 16 bytes per lane from any dword-aligned address straight into LDS (lane-linear: unit
 // u = 256 * pass + tid at byte 16 u), so nothing of a box ever sits in a VGPR: all four boxes of the workgroup (two
 // eyes x tile and mirrored band) and the table slice are requested in the prologue and the coordinates are evaluated
-// WHILE they are in flight (with register staging that overlap costs the staging registers' occupancy: DESIGN 4.4).
+// WHILE they are in flight (with register staging that overlap costs the staging registers' occupancy: HISTORY.md 4.4).
 // The box stays packed BGR (row pitch upr x 16 bytes); a tap pair (6 bytes at byte 3 ix) is cut out of three dwords
 // read at the dword below it (ds_read2_b32 + ds_read_b32: b64 / b96 reads that are not naturally aligned are
 // microcoded, 64 cycles) with two v_alignbyte_b32, then blended as the global-memory fallback does (blend3<3>).
