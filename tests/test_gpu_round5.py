@@ -261,8 +261,9 @@ def test_apply_lr_auto_radius_is_graph_capturable_end_to_end(V, oracle_mod, dev)
     left, right = (torch.from_numpy(x).to(dev) for x in imgs[0])
     out = torch.zeros((512, 1024, 3), dtype=torch.uint8, device=dev)
     s = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(s):
-        V.apply_lr_tensors(t, left, right, out=out, size_output=(512, 512), radius="auto", auto_radius_on_device=True)  # (creates the plan)
+    # (the plan is created, and its first launch made, on ANOTHER stream than the one that records: the recorded launch must not wait
+    #  for an event of that stream)
+    V.apply_lr_tensors(t, left, right, out=out, size_output=(512, 512), radius="auto", auto_radius_on_device=True)
     torch.cuda.synchronize()
     n_plans = len(remapper._PLANS)
     graph = torch.cuda.CUDAGraph()

@@ -959,9 +959,14 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
             continue;
         }
         std::unique_lock<std::mutex> flags_lk(p->flags_mu, std::defer_lock);
+        bool capturing = false;  // (a recorded launch neither waits for nor records the plan's events: v1c_plan_run_auto's comment)
         if (d.need_fixup) {
             flags_lk.lock();
-            if (p->flags_pending && p->flags_stream != st)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cap) != hipSuccess)
+                cap = hipStreamCaptureStatusNone;
+            capturing = cap != hipStreamCaptureStatusNone;
+            if (!capturing && p->flags_pending && p->flags_stream != st)
                 HIP_TRY(hipStreamWaitEvent(st, p->flags_ev, 0));
         }
         uint32_t* flags = d.need_fixup ? p->ctx.tile_flags : nullptr;
@@ -1020,8 +1025,10 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
         p->last_launch.store(kind | (d.need_fixup ? V1C_LAUNCH_FIXUP : 0), std::memory_order_relaxed);
         if (d.need_fixup) {
             HIP_TRY(launch_remap(MODE_FIXUP, p->ctx, unit_args(u, n), n, st));
-            HIP_TRY(hipEventRecord(p->flags_ev, st));
-            p->flags_stream = st, p->flags_pending = true;
+            if (!capturing) {
+                HIP_TRY(hipEventRecord(p->flags_ev, st));
+                p->flags_stream = st, p->flags_pending = true;
+            }
         }
     }
     return V1C_OK;
@@ -1078,7 +1085,13 @@ extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* unit
         HIP_TRY(hipEventCreateWithFlags(&p->dyn_ev, hipEventDisableTiming));
         p->ctx_dyn = (KernelCtx*)dctx;
     }
-    if (p->dyn_pending && p->dyn_stream != st)
+    // (a launch that is being recorded into a graph neither waits for nor records the plan's event: an event recorded outside a capture
+    //  cannot be waited for inside one, nor the other way round -- whoever replays the graph orders it against other users of the plan)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess)
+        cap = hipStreamCaptureStatusNone;
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && p->dyn_pending && p->dyn_stream != st)
         HIP_TRY(hipStreamWaitEvent(st, p->dyn_ev, 0));
     HIP_TRY(launch_patch_radius(p->ctx_dyn, rad_dev, n_rad, r_limit, p->ctx.ray.cx32, p->ctx.ray.cy32, st));
     LaunchUnits lu{du, nullptr, n_units};
@@ -1091,8 +1104,10 @@ extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* unit
         HIP_TRY(launch_ray_lin3_tile(p->ctx, p->ctx_dyn, lu, nullptr, true, nullptr, p->half_dwords, shared, d.mpoly_all && !p->disable_mpoly, nullptr, 0,
                                      p->lean_half, p->strip_len, p->lean_raw_nwp, st, d.coords_bounded && !p->disable_coords_bounded, &kind, same_rot));
     }
-    HIP_TRY(hipEventRecord(p->dyn_ev, st));
-    p->dyn_stream = st, p->dyn_pending = true;
+    if (!capturing) {
+        HIP_TRY(hipEventRecord(p->dyn_ev, st));
+        p->dyn_stream = st, p->dyn_pending = true;
+    }
     p->last_launch.store(kind, std::memory_order_relaxed);
     return V1C_OK;
 }

@@ -335,6 +335,8 @@ V1C_HDF bool gen_vector(RP& P, RotPtr rot, double sl, double cl, double hl, doub
 {
     // (written so that everything that depends on the row only -- B_k, T_k's factors -- is common to the 4 pixels of a lane: the tile
     //  kernels unroll the pixel loop and the compiler evaluates those once)
+    // (one set of instantiations for both general modes: a lat_x-only build of the bilinear pair kernel needs 93 instead of 110 VGPRs --
+    //  5 instead of 4 waves per SIMD -- which did not seem worth 48 more kernels)
     if (P.gen_mode == 1) {
         // R (s_c, c_c s_r, c_c c_r) = R_k0 s_c + (R_k1 s_r + R_k2 c_r) c_c
         const double B0 = fma(rot[1], sl, rot[2] * cl), B1 = fma(rot[4], sl, rot[5] * cl), B2 = fma(rot[7], sl, rot[8] * cl);
