@@ -223,7 +223,7 @@ struct v1c_plan {
     bool flags_pending = false;
     std::atomic<int> last_launch{-1};   // V1C_LAUNCH_* of the most recent launch group of v1c_plan_run (tests: v1c_plan_last_launch)
     // v1c_plan_run_auto: a second device copy of the context whose Denormalize scale a small kernel rewrites from a device-resident radius
-    // in front of every such launch (created on first use); launches on different streams are ordered by an event, like the flag words
+    // in front of every such launch; launches on different streams are ordered by an event, like the flag words
     KernelCtx* ctx_dyn = nullptr;
     std::mutex dyn_mu;
     hipEvent_t dyn_ev = nullptr;
@@ -584,6 +584,21 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 }
                 p->ctx_dev = (KernelCtx*)dctx;
                 p->ring = (DevUnit*)ring;
+                // ... and the second copy v1c_plan_run_auto rewrites the Denormalize scale of (created here so that the call itself
+                // neither allocates nor synchronises: it may be the first thing a stream capture records)
+                void* ddyn = nullptr;
+                e = hipMalloc(&ddyn, sizeof(KernelCtx));
+                if (e == hipSuccess) {
+                    p->allocs.push_back(ddyn);
+                    e = hipMemcpy(ddyn, &p->ctx, sizeof(KernelCtx), hipMemcpyHostToDevice);
+                }
+                if (e == hipSuccess)
+                    e = hipEventCreateWithFlags(&p->dyn_ev, hipEventDisableTiming);
+                if (e != hipSuccess) {
+                    v1c_plan_destroy(p);
+                    return fail(V1C_E_HIP, std::string("plan context (dynamic radius): ") + hipGetErrorString(e));
+                }
+                p->ctx_dyn = (KernelCtx*)ddyn;
             }
             // source boxes of the tiled kernel, computed once (BGR, constant border, linear/cubic/lanczos4)
             const Geom& g = p->ctx.g;
@@ -1077,14 +1092,8 @@ extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* unit
     if (g.cn != 3 && !(shared && aligned && cn_kernel_supports(g)))
         return fail(V1C_E_UNSUPPORTED, "v1c_plan_run_auto: grayscale / BGRA need dword-aligned sources and one table entry per lane");
     std::lock_guard<std::mutex> lk(p->dyn_mu);
-    if (!p->ctx_dyn) {
-        void* dctx = nullptr;
-        HIP_TRY(hipMalloc(&dctx, sizeof(KernelCtx)));
-        p->allocs.push_back(dctx);
-        HIP_TRY(hipMemcpy(dctx, &p->ctx, sizeof(KernelCtx), hipMemcpyHostToDevice));
-        HIP_TRY(hipEventCreateWithFlags(&p->dyn_ev, hipEventDisableTiming));
-        p->ctx_dyn = (KernelCtx*)dctx;
-    }
+    if (!p->ctx_dyn)
+        return fail(V1C_E_UNSUPPORTED, "v1c_plan_run_auto: the plan has no tile kernels");
     // (a launch that is being recorded into a graph neither waits for nor records the plan's event: an event recorded outside a capture
     //  cannot be waited for inside one, nor the other way round -- whoever replays the graph orders it against other users of the plan)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
