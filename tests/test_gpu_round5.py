@@ -364,3 +364,28 @@ def test_capture_slots_can_be_released(V, dev):
             assert torch.equal(d, r)
         del graphs
         plan.release_captures()
+
+
+@pytest.mark.parametrize("workload,kinds", [("P1", {"mirror"}), ("P2", {"tile+fixup", "tile"}), ("P3L", {"tile"}), ("C0", {"tile"})])
+def test_bench_lines_of_the_round5_workloads(workload, kinds):
+    """bench.py's workloads for the chains of the reference's tests (P*) and its test size (C0): the line names a tiled kernel family,
+    its own parity check against the oracle finds no differing byte, and a Lanczos4 line measures its VALU ceiling live or says it did not."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1", "--traffic", "none",
+                        "--no-cold-extra", "--no-sustained"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert set(line["config"]["kernels"]) <= kinds, line["config"]["kernels"]
+    assert line["parity_vs_oracle"]["bytes_differing"] == 0, line["parity_vs_oracle"]
+    assert line["world_size_seen"] == 1
+    if workload in ("P3L", "C0"):
+        assert line["roofline"]["bound"] == "valu-int" and "source" in line["roofline"]["valu_int"]

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -452,7 +453,13 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
         p->ctx.chain = (const v1c_chain*)d;
     }
 
+    // (V1C_DEBUG=1, tuning build: where the time of a plan's creation goes)
+    const bool dbg_t = [] { const char* d = tuning_env("V1C_DEBUG"); return d && d[0] == '1'; }();
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now_ms();
+    double t_fit = t_start, t_up = t_start, t_boxes = t_start;
     RayPlanHost H = build_ray_plan_host(*chain, dst_w, dst_h, [](const TableSpec& sp) { return cached_radial_table(sp); });
+    t_fit = now_ms();
     p->ana = H.a;
     if (p->ana.ok) {
         p->ray_step = H.ray_step;
@@ -600,6 +607,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 }
                 p->ctx_dyn = (KernelCtx*)ddyn;
             }
+            t_up = now_ms();
             // source boxes of the tiled kernel, computed once (BGR, constant border, linear/cubic/lanczos4)
             const Geom& g = p->ctx.g;
             if (cn_kernel_supports(g) && p->plan_shared_entry && !p->disable_shared_entry && p->gen_mode == 0) {
@@ -668,6 +676,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     if (const char* dbg = tuning_env("V1C_DEBUG"); dbg && dbg[0] == '1')
                         std::fprintf(stderr, "[v1c] lean batch kernel: %d of %zu tiles left to the general kernel (raw box KB %d)\n", p->n_rest, hb.size() / 32, p->lean_raw_nwp);
                 }
+                t_boxes = now_ms();
                 // bilinear pairs of an unrotated chain whose rows mirror about an integer row (the default Normalize
                 // centre H / 2): boxes of the mirrored bands + the list of tiles that launch leaves to the pair kernel
                 {
@@ -760,6 +769,9 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
         v1c_plan_destroy(p);
         return fail(V1C_E_HIP, std::string("plan upload: ") + hipGetErrorString(e));
     }
+    if (dbg_t)
+        std::fprintf(stderr, "[v1c] plan_create: analysis + fits %.3f ms, tables / context / ring %.3f, tile boxes + sizing + rest list %.3f, mirror boxes + lists + sync %.3f\n",
+                     t_fit - t_start, t_up - t_fit, t_boxes - t_up, now_ms() - t_boxes);
     *out = p;
     return V1C_OK;
 }
