@@ -68,6 +68,29 @@ def test_kxk_footprints_crossing_the_edge_are_served_from_the_box(V, oracle_mod,
             assert np.array_equal(got, want[k]), (name, interp, len(group), k, int((got != want[k]).sum()))
 
 
+@pytest.mark.parametrize("border", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("interp", [4, 2])
+def test_kxk_footprints_crossing_the_edge_other_border_modes(V, oracle_mod, dev, interp, border):
+    """REPLICATE / REFLECT / WRAP / REFLECT_101 stage the pixel borderInterpolate maps every cell of the box to (TRANSPARENT keeps the
+    per-pixel sampler): noise to the edge, circle beyond the frame, odd width; pairs and a single image, every byte against the oracle."""
+    from vr180_convert_amd import remapper
+
+    O = oracle_mod
+    spec, (hs, ws), (wo, ho), radius = [("equirect_enc", True), ("poly", [0, 1, -0.05]), CS.EQUI], (333, 411), (576, 448), 215.0
+    imgs = [_noise(hs, ws, 600 + k) for k in range(2)]
+    xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+    fill = np.full((ho, wo, 3), 55, np.uint8)
+    want = [O.remap(im, xm, ym, interp, border, 0, dst=fill.copy()) for im in imgs]
+    srcs = [torch.from_numpy(i).to(dev) for i in imgs]
+    for group in (srcs, srcs[:1]):
+        dsts = [torch.from_numpy(fill.copy()).to(dev) for _ in group]
+        assert V.remap_tensors(CS.to_product(spec), group, dsts, radius=radius, interpolation=interp, boarder_mode=border) == ["ray"]
+        assert remapper.last_launch_kinds()[0].split("+")[0] == "tile"
+        for k, d in enumerate(dsts):
+            got = d.cpu().numpy()
+            assert np.array_equal(got, want[k]), (interp, border, len(group), k, int((got != want[k]).sum()))
+
+
 @pytest.mark.parametrize("interp", [4, 2])
 def test_kxk_edge_footprints_with_a_rotation_per_unit(V, oracle_mod, dev, interp):
     """Units that override the rotation reduce their boxes in the kernel: the same border-colour staging there."""

@@ -726,16 +726,19 @@ __device__ __forceinline__ void stage_load(const ChunkMap& M, const uint8_t* __r
     }
 }
 
-// ---- the same for a box that leaves the source (bicubic / Lanczos4, BORDER_CONSTANT): the border colour around the image ----
+// ---- the same for a box that leaves the source (bicubic / Lanczos4): the border around the image ----
 // remapBicubic / remapLanczos4 give a tap outside the source the border value (the constant-border branch: oracle/vr180_oracle.c:415-449,
 // sample_table in v1c_core.hpp).  A box staged with that colour in every cell outside the image lets the K x K gather serve such
 // footprints like any other: where the image circle touches the frame (radius = "max", what "auto" finds for a full-frame circle: the
 // reference's defaults, remapper.py:333,416) whole tiles next to the poles have every footprint cross the edge, and the per-pixel
 // patch path they took was a tail of ~30 waves that doubled the launch (C1L 0.189 against 0.092 ms with the circle 0.5 % inside).
 // Chunks are 4 pixels starting at a multiple of 4 columns: they straddle the right edge only (src_w not a multiple of 4).
+// (every border mode but TRANSPARENT, whose bicubic / Lanczos4 rule -- skip the pixel when its CENTRE tap is outside, reflect the other
+//  taps -- stays with the per-pixel sampler: REPLICATE / REFLECT / WRAP / REFLECT_101 stage, cell by cell, the pixel borderInterpolate
+//  maps the cell to -- exactly what sample_table's border branch reads for that tap)
 __device__ __forceinline__ int kxk_ext(geom_cref g)
 {
-    return g.border == V1C_BORDER_CONSTANT ? 1 : 0;
+    return g.border != V1C_BORDER_TRANSPARENT ? 1 : 0;
 }
 __device__ __forceinline__ bool box_leaves_source(const TileBox& b, geom_cref g)
 {
@@ -762,13 +765,26 @@ __device__ __forceinline__ void stage_load_ext(const ChunkMap& M, const uint8_t*
                 typedef u96 __attribute__((aligned(4), may_alias)) u96a4;
                 const u96 v = *(const u96a4*)(src + (__umul24((uint32_t)row, spitch) + (uint32_t)xb));
                 S.w0[q] = v.a, S.w1[q] = v.b, S.w2[q] = v.c;
-            } else if (row_in & (xb >= 0) & (xb < wb)) {  // the chunk straddles the right edge: pixel by pixel
+            } else if ((g.border == V1C_BORDER_CONSTANT) & row_in & (xb >= 0) & (xb < wb)) {  // the chunk straddles the right edge: pixel by pixel
                 uint32_t w[3] = {p0, p1, p2};
                 const uint32_t goff = __umul24((uint32_t)row, spitch) + (uint32_t)xb;
 #pragma unroll 1
                 for (int bb = 0; bb < 12; bb++)
                     if (xb + bb < wb)
                         w[bb >> 2] = (w[bb >> 2] & ~(0xffu << (8 * (bb & 3)))) | ((uint32_t)src[goff + bb] << (8 * (bb & 3)));
+                S.w0[q] = w[0], S.w1[q] = w[1], S.w2[q] = w[2];
+            } else if (g.border != V1C_BORDER_CONSTANT) {  // REPLICATE / REFLECT / WRAP / REFLECT_101: the pixel each cell maps to
+                const int yi = border_index(row, g.src_h, g.border);
+                uint32_t w[3] = {0u, 0u, 0u};
+#pragma unroll 1
+                for (int px = 0; px < 4; px++) {
+                    const int xi = border_index(xb / 3 + px, g.src_w, g.border);
+                    const uint8_t* s3 = src + (__umul24((uint32_t)yi, spitch) + (uint32_t)xi * 3u);
+                    for (int ch = 0; ch < 3; ch++) {
+                        const int bb = 3 * px + ch;
+                        w[bb >> 2] |= (uint32_t)s3[ch] << (8 * (bb & 3));
+                    }
+                }
                 S.w0[q] = w[0], S.w1[q] = w[1], S.w2[q] = w[2];
             } else {
                 S.w0[q] = p0, S.w1[q] = p1, S.w2[q] = p2;
