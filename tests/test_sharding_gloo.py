@@ -268,15 +268,22 @@ def test_row_band_chain_reproduces_the_rows_of_the_full_map(emul_lib, oracle_mod
     from vr180_convert_amd.chain import lower_for_get_map
 
     O = oracle_mod
-    spec = [("equirect_enc", True), ("rot", CS.ry(0.3)), ("poly", [0, 1, -0.1]), CS.EQUI]
-    t = CS.to_product(spec)
-    W, H, r0, r1 = 96, 80, 32, 64
-    full = O.Chain.from_buffer_copy(bytes(lower_for_get_map(t, radius=41.5, size_input=(90, 100), size_output=(W, H))))
-    band = O.Chain.from_buffer_copy(bytes(lower_for_get_map(t, radius=41.5, size_input=(90, 100), size_output=(W, H), row_band=(r0, r1))))
-    for mode in (0, 1):
-        rc, fx, fy, _ = emul_map(emul_lib, full, W, H, mode)
-        rc2, bx, by, _ = emul_map(emul_lib, band, W, r1 - r0, mode)
-        assert rc == 0 and rc2 == 0
-        assert np.array_equal(bx.view(np.uint32), fx[r0:r1].view(np.uint32)) and np.array_equal(by.view(np.uint32), fy[r0:r1].view(np.uint32))
+    W, H = 96, 80
+    # (round 5: planar chains too -- their radial table covers m = xn^2 + yn^2 up to the corners of the WHOLE grid, which a band learns
+    #  from its Normalize stage, so that every band evaluates the unsplit plan's polynomials -- and the general modes)
+    for spec in ([("equirect_enc", True), ("rot", CS.ry(0.3)), ("poly", [0, 1, -0.1]), CS.EQUI],
+                 [("fisheye_enc", "stereographic"), ("poly", [0, 1, -0.1]), CS.EQUI],
+                 [("fisheye_enc", "equidistant"), ("rot", CS.ry(0.3)), CS.EQUI],
+                 [("equirect_enc", False), CS.EQUI]):
+        t = CS.to_product(spec)
+        full = O.Chain.from_buffer_copy(bytes(lower_for_get_map(t, radius=41.5, size_input=(90, 100), size_output=(W, H))))
+        for r0, r1 in ((32, 64), (0, 16), (64, 80)):
+            band = O.Chain.from_buffer_copy(bytes(lower_for_get_map(t, radius=41.5, size_input=(90, 100), size_output=(W, H), row_band=(r0, r1))))
+            for mode in (0, 1):
+                rc, fx, fy, _ = emul_map(emul_lib, full, W, H, mode)
+                rc2, bx, by, _ = emul_map(emul_lib, band, W, r1 - r0, mode)
+                assert rc == 0 and rc2 == 0, (spec, mode)
+                assert np.array_equal(bx.view(np.uint32), fx[r0:r1].view(np.uint32)) and np.array_equal(by.view(np.uint32), fy[r0:r1].view(np.uint32)), (spec, r0, mode)
+    t = CS.to_product([("equirect_enc", True), ("rot", CS.ry(0.3)), ("poly", [0, 1, -0.1]), CS.EQUI])
     with pytest.raises(ValueError):
         lower_for_get_map(t, radius=41.5, size_input=(90, 100), size_output=(W, H), row_band=(64, 96))

@@ -559,6 +559,11 @@ def lower_for_get_map(transformer: TransformerBase, *, radius: float, size_input
         * DenormalizeTransformer(scale=(radius, radius), center=(size_input[1] // 2, size_input[0] // 2))
     )
     ops = full.lower(out_shape)
+    if row_band is not None and ops and ops[0].opcode == _abi.OP_NORMALIZE and ops[0].nparam == 3:
+        # the rows of the WHOLE grid in the band's row numbering (p[3] <= j' < p[4]): what a plan sizes from the reach of the output --
+        # the radial table of a planar chain covers m = xn^2 + yn^2 up to the corners -- it sizes for the whole grid, so that every band
+        # evaluates the very polynomials the unsplit plan does (include/vr180_remap.h: V1C_OP_NORMALIZE)
+        ops[0].p[3], ops[0].p[4], ops[0].nparam = float(-r0), float(h - r0), 5
     if len(ops) > _abi.MAX_OPS:
         raise NotLowerable(f"chain has {len(ops)} stages, the op list holds {_abi.MAX_OPS}")
     return _abi.chain(ops)

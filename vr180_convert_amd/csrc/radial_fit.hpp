@@ -42,6 +42,8 @@ struct RayAnalysis {
     int gen_mode = 0;        // RayParams::gen_mode: 0 classic, 1 lat_x, 2 pre-rotation radial stages
     double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // composition of consecutive rotate stages
     double norm_cx = 0, norm_cy = 0, norm_s = 1;  // Normalize
+    bool has_rows = false;                        // Normalize carries the row range of the whole grid (a row band: chain.py)
+    double row_lo = 0, row_hi = 0;
     double rx = 1, ry = 1, cx = 0, cy = 0;        // Denormalize
     std::vector<v1c_op> pre;                      // radial / zoom stages in front of the rotation (gen_mode 2)
     std::vector<v1c_op> radial;                   // radial / zoom stages behind it (all of them when nothing rotates)
@@ -89,6 +91,8 @@ inline RayAnalysis analyze_chain(const v1c_chain& ch)
     a.norm_cx = ch.ops[0].p[0];
     a.norm_cy = ch.ops[0].p[1];
     a.norm_s = ch.ops[0].p[2];
+    if (ch.ops[0].nparam >= 5 && ch.ops[0].p[4] > ch.ops[0].p[3])
+        a.has_rows = true, a.row_lo = ch.ops[0].p[3], a.row_hi = ch.ops[0].p[4];
     const v1c_op& dn = ch.ops[n - 1];
     a.rx = dn.p[0], a.ry = dn.p[1], a.cx = dn.p[2], a.cy = dn.p[3];
     int k = 1;
@@ -579,6 +583,12 @@ inline RayHostTables build_ray_host_tables(const RayAnalysis& a, int dst_w, int 
             t.m_reach = std::max(t.m_reach, t.row_h[j] + std::max(t.row_c[j] * h_max, t.row_c[j] * h_min));
         else  // m = 1 - col_c row_c  (col_h holds col_c)
             t.m_reach = std::max(t.m_reach, 1.0 - std::min(t.row_c[j] * h_max, t.row_c[j] * h_min));
+    }
+    if (a.base == 1 && a.has_rows) {
+        // a row band of a larger grid: the reach of the WHOLE grid (its first and last row: yn^2 is largest at one of them), so that
+        // every band fits the table the unsplit plan fits
+        const double y0 = (a.row_lo - a.norm_cy) / a.norm_s * 2, y1 = ((a.row_hi - 1) - a.norm_cy) / a.norm_s * 2;
+        t.m_reach = std::max(t.m_reach, std::max(y0 * y0, y1 * y1) + h_max);
     }
     t.t_max = a.base == 1 ? std::sqrt(t.m_reach) : 0.0;
     t.x_max = a.base == 1 ? std::sqrt(h_max) : 0.0;
