@@ -61,7 +61,10 @@ extern "C" {
 #define V1C_MAX_PARAMS 16
 
 enum v1c_opcode {
-    /* x=(x-p0)/p2*2 ; y=(y-p1)/p2*2            NormalizeTransformer.transform  transformer.py:153-164 */
+    /* x=(x-p0)/p2*2 ; y=(y-p1)/p2*2            NormalizeTransformer.transform  transformer.py:153-164
+     * optional (nparam = 5): p3 <= row < p4 = the rows of the WHOLE output grid in this plan's row numbering, when the
+     * plan serves a band of rows of a larger grid (one eye split over several GPUs): tables sized by the reach of the
+     * output are then sized for the whole grid and every band evaluates what the unsplit plan evaluates            */
     V1C_OP_NORMALIZE = 1,
     /* x=x*p0+p2 ; y=y*p1+p3                    DenormalizeTransformer.transform         :197-204 */
     V1C_OP_DENORMALIZE = 2,
@@ -191,6 +194,14 @@ int v1c_plan_run(v1c_plan* plan, void* stream, const v1c_unit* units, int n_unit
  * graph-capturable; one plan may be used from several streams (ordered by an event).                                              */
 int v1c_plan_run_auto(v1c_plan* plan, void* stream, const v1c_unit* units, int n_units,
                       const double* rad_dev, int n_rad);
+
+/* The same with the estimates taken from the units' OWN source images by the call itself: apply()'s
+ * get_radius_smart("auto", images) over the images it is about to remap (remapper.py:379-380;
+ * get_radius, transformer.py:108-140, `threshold` its parameter: the reference's default is 10).
+ * Two launches in all: one workgroup scans the centre line of every unit's source and sets the
+ * scale, then the remap.  Same chains, limits and error behaviour as v1c_plan_run_auto.          */
+int v1c_plan_run_auto_images(v1c_plan* plan, void* stream, const v1c_unit* units, int n_units,
+                             int threshold);
 
 /* Hand the plan's capture-owned unit buffers out again (see v1c_plan_run: a recorded launch of more
  * than 16 units keeps one of 4 for the graph that replays it).  Call it once every graph that

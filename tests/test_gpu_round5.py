@@ -210,6 +210,20 @@ def test_the_references_ten_test_calls_as_written(V, oracle_mod, tmp_path):
         assert np.array_equal(_io.imread(out), want), spec
 
 
+def test_row_bands_of_planar_and_general_mode_chains(V, oracle_mod):
+    """A single pair on 4 GPUs = bands of output rows, for the chains that are fused since round 5: the band's plan
+    learns the whole grid's rows from its Normalize stage (a planar chain's radial table covers m up to the corners of the WHOLE
+    output), so the assembled rows equal the oracle's byte for byte -- four workers on the one card of the test box."""
+    O = oracle_mod
+    left, right = _noise(300, 300, 41), _noise(300, 300, 42)
+    for spec in ([("fisheye_enc", "stereographic"), ("poly", [0, 1, -0.1]), CS.EQUI], [("fisheye_enc", "equidistant"), ("rot", CS.ry(0.3)), CS.EQUI],
+                 [("equirect_enc", False), CS.EQUI]):
+        for interp in (1, 4):
+            want = O.apply_lr(spec, left, right, size_output=(512, 448), interpolation=interp, radius="max")
+            got = V.remap_sharded(CS.to_product(spec), [(left, right)], size_output=(512, 448), interpolation=interp, radius="max", devices=[0] * 4)
+            assert np.array_equal(got[0], want), (spec, interp, int((got[0] != want).sum()))
+
+
 # ---------------------------------------------------------------------------- radius="auto" on the device
 def _disc(h, w, r, seed, cx=None, cy=None):
     """A noisy image circle of radius r on black (what get_radius looks for: transformer.py:125-140)."""
@@ -270,6 +284,29 @@ def test_auto_radius_on_the_device_equals_the_host_radius_path(V, oracle_mod, go
     assert remapper.last_auto_radius_form() == "exact"
     want = O.apply_lr(([("equirect_enc", True), ("rot", CS.ry(0.05)), CS.EQUI], spec), a, b, size_output=(512, 512), interpolation=interp, radius="auto")
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_auto_radius_estimated_by_the_launch_itself_equals_the_two_step_form(V, oracle_mod, dev):
+    """v1c_plan_run_auto_images (one workgroup scans every source's centre line and sets the scale: two launches per call) against
+    v1c_get_radius_async per image + v1c_plan_run_auto, and the oracle: centre COLUMN of square sources, centre ROW of landscape ones,
+    the two eyes as halves of one side-by-side tensor (a pitch of two rows) and -- a pitch each -- one half beside a contiguous image."""
+    from vr180_convert_amd import remapper
+
+    O = oracle_mod
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    t = CS.to_product(spec)
+    for (h, w), (r0, r1) in (((512, 512), (250, 231.5)), ((480, 640), (200, 236)), ((640, 480), (225, 239))):
+        a, b = _disc(h, w, r0, 11), _disc(h, w, r1, 12, cx=w / 2 - 7)
+        sbs = torch.from_numpy(np.concatenate([a, b], axis=1)).to(dev)
+        want = O.apply_lr(spec, a, b, size_output=(384, 384), interpolation=1, radius="auto")
+        for srcs in ([sbs[:, :w], sbs[:, w:]], [sbs[:, :w], torch.from_numpy(b).to(dev)]):
+            outs = []
+            for two_step in (False, True):
+                out = torch.zeros((384, 768, 3), dtype=torch.uint8, device=dev)
+                rad = remapper.auto_radius_tensor(srcs) if two_step else None
+                remapper.remap_tensors_auto(t, srcs, [out[:, :384], out[:, 384:]], rad=rad, interpolation=1, size_input=(h, w))
+                outs.append(out.cpu().numpy())
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], want), ((h, w), srcs[1].stride(0))
 
 
 def test_apply_lr_auto_radius_is_graph_capturable_end_to_end(V, oracle_mod, dev):

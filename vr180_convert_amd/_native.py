@@ -20,7 +20,7 @@ SYMBOLS = [
     "v1c_abi_version", "v1c_device_count", "v1c_last_error", "v1c_plan_create", "v1c_plan_destroy",
     "v1c_plan_path", "v1c_plan_run", "v1c_plan_get_map", "v1c_remap_fused", "v1c_remap_lut",
     "v1c_get_radius", "v1c_get_radius_async", "v1c_build_itab", "v1c_anaglyph", "v1c_fused_cache_size", "v1c_plan_last_launch",
-    "v1c_plan_release_captures", "v1c_plan_run_auto",
+    "v1c_plan_release_captures", "v1c_plan_run_auto", "v1c_plan_run_auto_images",
 ]
 
 
@@ -60,6 +60,7 @@ def lib() -> C.CDLL:
     try:
         L.v1c_plan_release_captures.argtypes = [vp]
         L.v1c_plan_run_auto.argtypes = [vp, vp, C.POINTER(_abi.Unit), i32, vp, i32]
+        L.v1c_plan_run_auto_images.argtypes = [vp, vp, C.POINTER(_abi.Unit), i32, i32]
     except AttributeError:  # (an older build behind V1C_LIB: A/B runs of tools/ab.sh only)
         pass
     L.v1c_plan_run.argtypes = [vp, vp, C.POINTER(_abi.Unit), i32]

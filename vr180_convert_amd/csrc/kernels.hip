@@ -326,28 +326,48 @@ hipError_t launch_anaglyph(const uint8_t* left, int64_t left_pitch, const uint8_
 // of uint8 values: sum / cn), d[i] = black[i + 1] - black[i] (:134), radius = (last i with d == -1  -  first i with d == +1) / 2 (:137-139;
 // the sign quirk of the reference -- a disc on black gives a NEGATIVE value -- is kept); no +1 or no -1 anywhere: the reference indexes an
 // empty array (IndexError) -> out[1] = 1, out[0] = NaN.
-__global__ __launch_bounds__(256) void k_get_radius(const uint8_t* __restrict__ line, int64_t step, int n, int cn, int threshold,
-                                                    double* __restrict__ out)
+// black[i] of one pixel of a line: transformer.py:133 (the float64 mean of the uint8 channels against the threshold)
+__device__ __forceinline__ int radius_black(const uint8_t* __restrict__ line, int64_t step, int i, int cn, int threshold)
 {
-    __shared__ int first_rise, last_fall;
+    const uint8_t* p = line + (int64_t)i * step;
+    int s = 0;
+    for (int k = 0; k < cn; k++)
+        s += p[k];
+    return ((double)s / (double)cn) < (double)threshold ? 1 : 0;
+}
+
+// One chunk of 256 differences d[i] = black[i + 1] - black[i], i in [i0, i0 + 256), by one workgroup of 256 threads: every pixel is read
+// once (the scan is bound by how many cache-line misses ONE compute unit keeps in flight: a centre column is a line per pixel) and
+// passed to its neighbour through `bl` (257 bytes of LDS).  lo / hi: the lane's own first +1 / last -1 (0x7fffffff / -1: none).
+__device__ __forceinline__ void radius_chunk(const uint8_t* __restrict__ line, int64_t step, int n, int cn, int threshold, int i0, uint8_t* bl,
+                                             int& lo, int& hi)
+{
+    const int i = i0 + (int)threadIdx.x;
+    bl[threadIdx.x] = i < n ? radius_black(line, step, i, cn, threshold) : 0;
     if (threadIdx.x == 0)
-        first_rise = 0x7fffffff, last_fall = -1;
+        bl[256] = i0 + 256 < n ? radius_black(line, step, i0 + 256, cn, threshold) : 0;
     __syncthreads();
-    auto black = [&](int i) {
-        const uint8_t* p = line + (int64_t)i * step;
-        int s = 0;
-        for (int k = 0; k < cn; k++)
-            s += p[k];
-        return ((double)s / (double)cn) < (double)threshold ? 1 : 0;
-    };
-    int lo = 0x7fffffff, hi = -1;
-    for (int i = threadIdx.x; i + 1 < n; i += 256) {
-        const int d = black(i + 1) - black(i);
+    if (i + 1 < n) {
+        const int d = (int)bl[threadIdx.x + 1] - (int)bl[threadIdx.x];
         if (d == 1)
             lo = min(lo, i);
         if (d == -1)
             hi = max(hi, i);
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_get_radius(const uint8_t* __restrict__ line, int64_t step, int n, int cn, int threshold,
+                                                    double* __restrict__ out)
+{
+    __shared__ int first_rise, last_fall;
+    __shared__ uint8_t bl[257];
+    if (threadIdx.x == 0)
+        first_rise = 0x7fffffff, last_fall = -1;
+    __syncthreads();
+    int lo = 0x7fffffff, hi = -1;
+    for (int i0 = 0; i0 + 1 < n; i0 += 256)
+        radius_chunk(line, step, n, cn, threshold, i0, bl, lo, hi);
     if (lo != 0x7fffffff)
         atomicMin(&first_rise, lo);
     if (hi >= 0)
@@ -375,6 +395,19 @@ hipError_t launch_get_radius(const uint8_t* img, int h, int w, int64_t pitch, in
 // outside the source instead (scale 0, centre at -40 000 px: every pixel the border colour under BORDER_CONSTANT, inside the range the
 // kernels' coordinate proofs hold for)), clamps it to the magnitude the plan's proofs were taken for and writes the numbers of the
 // plan-resident context the kernels read: stream-ordered, graph-capturable, no host round trip.
+__device__ __forceinline__ void patch_ctx_radius(KernelCtx* ctx, double r, bool bad, double r_limit, double cx32, double cy32)
+{
+    r = fmin(fmax(r, -r_limit), r_limit);
+    if (bad || !(r == r)) {
+        r = 0.0;
+        cx32 = cy32 = -1280000.0;
+    }
+    ctx->ray.rx = r, ctx->ray.ry = r;
+    ctx->ray.rx32 = 32.0 * r, ctx->ray.ry32 = 32.0 * r;
+    ctx->ray.cx32 = cx32, ctx->ray.cy32 = cy32;
+    ctx->ray.cx = cx32 * 0.03125, ctx->ray.cy = cy32 * 0.03125;
+}
+
 __global__ void k_patch_radius(KernelCtx* ctx, const double* __restrict__ rad, int n, double r_limit, double cx32, double cy32)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
@@ -385,15 +418,67 @@ __global__ void k_patch_radius(KernelCtx* ctx, const double* __restrict__ rad, i
         r = rad[2 * k] > r ? rad[2 * k] : r;  // Python's max(): keeps the first of equal values, NaN never wins
         bad |= rad[2 * k + 1] != 0.0;
     }
-    r = fmin(fmax(r, -r_limit), r_limit);
-    if (bad || !(r == r)) {
-        r = 0.0;
-        cx32 = cy32 = -1280000.0;
+    patch_ctx_radius(ctx, r, bad, r_limit, cx32, cy32);
+}
+
+// Both steps in ONE launch for the images of the call itself (v1c_plan_run_auto_images).  The first form of this -- an estimate launch
+// of one workgroup per image, then the patch launch -- spent 16 - 20 us per image in the scan: one compute unit has only so many misses
+// in flight.  Here up to kAutoBlocks workgroups take 256-pixel chunks of the lines in turn; their results meet in `scratch` (plan-resident:
+// [k] first +1 of image k, [16 + k] last -1, [32] a ticket counter) and the workgroup that draws the last ticket takes the maximum,
+// patches the context and leaves the scratch words as it found them (0x7fffffff / -1 / 0) for the next launch.
+__global__ __launch_bounds__(256) void k_auto_radius(KernelCtx* ctx, int* __restrict__ scratch, AutoLines im, double r_limit, double cx32,
+                                                     double cy32)
+{
+    __shared__ int first_rise[kInlineUnits], last_fall[kInlineUnits];
+    __shared__ uint8_t bl[257];
+    __shared__ int is_last;
+    if (threadIdx.x < kInlineUnits)
+        first_rise[threadIdx.x] = 0x7fffffff, last_fall[threadIdx.x] = -1;
+    __syncthreads();
+    const int per_line = (im.n - 1 + 255) / 256, total = per_line * im.count;
+    for (int q = blockIdx.x; q < total; q += gridDim.x) {
+        const int k = q / per_line;
+        int lo = 0x7fffffff, hi = -1;
+        radius_chunk(im.line[k], im.step[k], im.n, im.cn, im.threshold, (q - k * per_line) * 256, bl, lo, hi);
+        if (lo != 0x7fffffff)
+            atomicMin(&first_rise[k], lo);
+        if (hi >= 0)
+            atomicMax(&last_fall[k], hi);
     }
-    ctx->ray.rx = r, ctx->ray.ry = r;
-    ctx->ray.rx32 = 32.0 * r, ctx->ray.ry32 = 32.0 * r;
-    ctx->ray.cx32 = cx32, ctx->ray.cy32 = cy32;
-    ctx->ray.cx = cx32 * 0.03125, ctx->ray.cy = cy32 * 0.03125;
+    __syncthreads();
+    if ((int)threadIdx.x < im.count) {
+        if (first_rise[threadIdx.x] != 0x7fffffff)
+            atomicMin(&scratch[threadIdx.x], first_rise[threadIdx.x]);
+        if (last_fall[threadIdx.x] >= 0)
+            atomicMax(&scratch[kInlineUnits + threadIdx.x], last_fall[threadIdx.x]);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_last = atomicAdd(&scratch[2 * kInlineUnits], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!is_last || threadIdx.x != 0)
+        return;
+    __threadfence();
+    double r = 0.0;
+    bool bad = false;
+    for (int k = 0; k < im.count; k++) {
+        const int fr = __hip_atomic_exchange(&scratch[k], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lf = __hip_atomic_exchange(&scratch[kInlineUnits + k], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double rk = (double)(lf - fr) / 2.0;
+        r = (k == 0 || rk > r) ? rk : r;  // Python's max(): keeps the first of equal values
+        bad |= fr == 0x7fffffff || lf < 0;
+    }
+    __hip_atomic_store(&scratch[2 * kInlineUnits], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    patch_ctx_radius(ctx, r, bad, r_limit, cx32, cy32);
+}
+
+hipError_t launch_auto_radius(KernelCtx* ctx_dev, int* scratch_dev, const AutoLines& im, double r_limit, double cx32, double cy32, hipStream_t stream)
+{
+    const int total = ((im.n - 1 + 255) / 256) * im.count;
+    hipLaunchKernelGGL(k_auto_radius, dim3(std::max(1, std::min(total, kAutoBlocks))), dim3(256), 0, stream, ctx_dev, scratch_dev, im, r_limit, cx32,
+                       cy32);
+    return hipGetLastError();
 }
 
 hipError_t launch_patch_radius(KernelCtx* ctx_dev, const double* rad_dev, int n, double r_limit, double cx32, double cy32, hipStream_t stream)

@@ -131,5 +131,23 @@ hipError_t launch_get_radius(const uint8_t* img, int h, int w, int64_t pitch, in
 
 // v1c_plan_run_auto: the Denormalize scale of the device context `ctx_dev` from n (radius, status) pairs in device memory
 hipError_t launch_patch_radius(KernelCtx* ctx_dev, const double* rad_dev, int n, double r_limit, double cx32, double cy32, hipStream_t stream);
+// get_radius of up to kInlineUnits images of one geometry + the patch above in one launch (v1c_plan_run_auto_images): `line[k]` = first
+// pixel of image k's centre row (w > h) or centre column (transformer.py:126-129), `step[k]` bytes from pixel to pixel along it, `n`
+// pixels.  `scratch_dev`: kAutoScratchInts plan-resident ints, [0, 16) = 0x7fffffff, [16, 32) = -1, [32] = 0 (auto_scratch_init) before the
+// first launch; every launch leaves them so.
+constexpr int kAutoBlocks = 64;
+constexpr int kAutoScratchInts = 2 * kInlineUnits + 1;
+struct AutoLines {
+    const uint8_t* line[kInlineUnits];
+    int64_t step[kInlineUnits];
+    int n, cn, threshold, count;
+};
+inline void auto_scratch_init(int* host)
+{
+    for (int k = 0; k < kInlineUnits; k++)
+        host[k] = 0x7fffffff, host[kInlineUnits + k] = -1;
+    host[2 * kInlineUnits] = 0;
+}
+hipError_t launch_auto_radius(KernelCtx* ctx_dev, int* scratch_dev, const AutoLines& im, double r_limit, double cx32, double cy32, hipStream_t stream);
 
 }  // namespace v1c

@@ -226,6 +226,7 @@ struct v1c_plan {
     // v1c_plan_run_auto: a second device copy of the context whose Denormalize scale a small kernel rewrites from a device-resident radius
     // in front of every such launch; launches on different streams are ordered by an event, like the flag words
     KernelCtx* ctx_dyn = nullptr;
+    int* auto_scratch = nullptr;        // behind it: the words the workgroups of k_auto_radius meet in (kernels.hpp: auto_scratch_init)
     std::mutex dyn_mu;
     hipEvent_t dyn_ev = nullptr;
     hipStream_t dyn_stream = nullptr;
@@ -594,10 +595,16 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                 // ... and the second copy v1c_plan_run_auto rewrites the Denormalize scale of (created here so that the call itself
                 // neither allocates nor synchronises: it may be the first thing a stream capture records)
                 void* ddyn = nullptr;
-                e = hipMalloc(&ddyn, sizeof(KernelCtx));
+                const size_t ctx_bytes = (sizeof(KernelCtx) + 15) & ~(size_t)15;
+                e = hipMalloc(&ddyn, ctx_bytes + kAutoScratchInts * sizeof(int));
                 if (e == hipSuccess) {
                     p->allocs.push_back(ddyn);
                     e = hipMemcpy(ddyn, &p->ctx, sizeof(KernelCtx), hipMemcpyHostToDevice);
+                }
+                if (e == hipSuccess) {
+                    int init[kAutoScratchInts];
+                    auto_scratch_init(init);
+                    e = hipMemcpy((char*)ddyn + ctx_bytes, init, sizeof(init), hipMemcpyHostToDevice);
                 }
                 if (e == hipSuccess)
                     e = hipEventCreateWithFlags(&p->dyn_ev, hipEventDisableTiming);
@@ -606,6 +613,7 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     return fail(V1C_E_HIP, std::string("plan context (dynamic radius): ") + hipGetErrorString(e));
                 }
                 p->ctx_dyn = (KernelCtx*)ddyn;
+                p->auto_scratch = (int*)((char*)ddyn + ctx_bytes);
             }
             t_up = now_ms();
             // source boxes of the tiled kernel, computed once (BGR, constant border, linear/cubic/lanczos4)
@@ -1067,9 +1075,10 @@ extern "C" int v1c_plan_run(v1c_plan* p, void* stream, const v1c_unit* units, in
 // used: the launch runs the kernels that reduce their source boxes themselves (the per-unit-rotation family, identity where nothing
 // rotates), reads the scale from a second plan-resident context a one-thread kernel has just rewritten, and is only taken when the
 // plan proves -- for ANY radius up to r_limit in magnitude -- that no fix-up pass is needed.  Launch-only: graph-capturable.
-extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* units, int n_units, const double* rad_dev, int n_rad)
+// (`rad_dev` null: the estimates are taken by the launch itself from the units' own source images with `threshold`)
+static int run_auto(v1c_plan* p, void* stream, const v1c_unit* units, int n_units, const double* rad_dev, int n_rad, int threshold)
 {
-    if (!p || !units || n_units <= 0 || !rad_dev || n_rad <= 0)
+    if (!p || !units || n_units <= 0 || (rad_dev && n_rad <= 0))
         return fail(V1C_E_INVALID, "v1c_plan_run_auto: bad arguments");
     if (n_units > kInlineUnits)
         return fail(V1C_E_UNSUPPORTED, "v1c_plan_run_auto: at most 16 units per call");
@@ -1114,7 +1123,19 @@ extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* unit
     const bool capturing = cap != hipStreamCaptureStatusNone;
     if (!capturing && p->dyn_pending && p->dyn_stream != st)
         HIP_TRY(hipStreamWaitEvent(st, p->dyn_ev, 0));
-    HIP_TRY(launch_patch_radius(p->ctx_dyn, rad_dev, n_rad, r_limit, p->ctx.ray.cx32, p->ctx.ray.cy32, st));
+    if (rad_dev) {
+        HIP_TRY(launch_patch_radius(p->ctx_dyn, rad_dev, n_rad, r_limit, p->ctx.ray.cx32, p->ctx.ray.cy32, st));
+    } else {
+        AutoLines im;
+        std::memset(&im, 0, sizeof(im));
+        const bool use_row = g.src_w > g.src_h;  // transformer.py:126-129
+        for (int k = 0; k < n_units; k++)
+            im.line[k] = use_row ? du[k].src + (int64_t)(g.src_h / 2) * du[k].src_pitch : du[k].src + (int64_t)(g.src_w / 2) * g.cn;
+        im.n = use_row ? g.src_w : g.src_h, im.cn = g.cn, im.threshold = threshold, im.count = n_units;
+        for (int k = 0; k < n_units; k++)
+            im.step[k] = use_row ? (int64_t)g.cn : du[k].src_pitch;
+        HIP_TRY(launch_auto_radius(p->ctx_dyn, p->auto_scratch, im, r_limit, p->ctx.ray.cx32, p->ctx.ray.cy32, st));
+    }
     LaunchUnits lu{du, nullptr, n_units};
     int kind = V1C_LAUNCH_GENERIC;
     if (g.cn != 3) {
@@ -1131,6 +1152,21 @@ extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* unit
     }
     p->last_launch.store(kind, std::memory_order_relaxed);
     return V1C_OK;
+}
+
+extern "C" int v1c_plan_run_auto(v1c_plan* p, void* stream, const v1c_unit* units, int n_units, const double* rad_dev, int n_rad)
+{
+    if (!rad_dev)
+        return fail(V1C_E_INVALID, "v1c_plan_run_auto: bad arguments");
+    return run_auto(p, stream, units, n_units, rad_dev, n_rad, 0);
+}
+
+// ... and with the estimates taken from the units' own sources by the same call: apply()'s `get_radius_smart(radius, images)` over the
+// images it is about to remap (remapper.py:379-380), threshold as get_radius's parameter (transformer.py:109: default 10).  Two launches
+// in all -- one workgroup that scans every image's centre line and sets the scale, then the remap.
+extern "C" int v1c_plan_run_auto_images(v1c_plan* p, void* stream, const v1c_unit* units, int n_units, int threshold)
+{
+    return run_auto(p, stream, units, n_units, nullptr, 0, threshold);
 }
 
 extern "C" int v1c_plan_get_map(v1c_plan* p, void* stream, float* xmap, float* ymap, int64_t map_pitch,

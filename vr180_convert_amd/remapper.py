@@ -169,13 +169,19 @@ class Plan:
                 except KeyError:  # another thread emptied it
                     break
 
-    def run_auto(self, srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor], rad: torch.Tensor, rots: Sequence[Any] | None = None) -> None:
+    def run_auto(self, srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor], rad: torch.Tensor | None = None,
+                 rots: Sequence[Any] | None = None, threshold: int = 10) -> None:
         """``v1c_plan_run_auto``: the launch with the radius read from device memory -- ``rad`` = float64 ``(n, 2)`` (radius, status)
-        pairs as ``v1c_get_radius_async`` writes them; the launch uses their maximum.  Raises NotImplementedError for chains /
-        geometries the device-resident form does not serve (the caller then takes the radius to the host)."""
+        pairs as ``v1c_get_radius_async`` writes them; the launch uses their maximum.  ``rad=None``: the estimates are taken from
+        ``srcs`` themselves by the same call (``v1c_plan_run_auto_images``, ``threshold`` = get_radius's).  Raises NotImplementedError
+        for chains / geometries the device-resident form does not serve (the caller then takes the radius to the host)."""
+        units = marshal_units(srcs, dsts, rots, src_hw=self.src_hw, dst_wh=self.dst_wh, cn=self.cn, device=self.device)
+        if rad is None:
+            rc = _native.lib().v1c_plan_run_auto_images(self._h, _stream_ptr(self.device), units, len(srcs), int(threshold))
+            _native.check(rc, "v1c_plan_run_auto_images")
+            return
         if rad.dtype != torch.float64 or rad.dim() != 2 or rad.shape[1] != 2 or not rad.is_contiguous() or rad.device != self.device:
             raise ValueError("rad must be a contiguous float64 (n, 2) tensor on the plan's device")
-        units = marshal_units(srcs, dsts, rots, src_hw=self.src_hw, dst_wh=self.dst_wh, cn=self.cn, device=self.device)
         rc = _native.lib().v1c_plan_run_auto(self._h, _stream_ptr(self.device), units, len(srcs), rad.data_ptr(), int(rad.shape[0]))
         _native.check(rc, "v1c_plan_run_auto")
 
@@ -672,8 +678,8 @@ def remap_tensors_auto(transformer: TransformerBase, srcs: Sequence[torch.Tensor
                        rad: torch.Tensor | None = None, interpolation: int = INTER_LANCZOS4, boarder_mode: int = BORDER_CONSTANT,
                        boarder_value: Any = 0, size_input: tuple[int, int] | None = None) -> None:
     """``remap_tensors`` with ``radius="auto"`` -- the reference's default, remapper.py:333 -- and the radius never leaving the device:
-    estimated per image by ``v1c_get_radius_async`` (or given as ``rad``, ``auto_radius_tensor``), the maximum taken and the
-    Denormalize scale set by a one-thread kernel in front of the remap launch (``v1c_plan_run_auto``).  No stream synchronisation, no
+    estimated from ``srcs`` (or given as ``rad``, ``auto_radius_tensor``), the maximum taken and the Denormalize scale set by ONE small
+    launch in front of the remap launch (``v1c_plan_run_auto_images`` / ``v1c_plan_run_auto``).  No stream synchronisation, no
     plan per image (ONE plan serves every radius: it is keyed on the nominal radius "max"), graph-capturable once the plan exists.
     Where the reference raises IndexError (an image without a black border) the output is the border colour.
     Raises NotImplementedError for chains the device-resident form does not serve (see include/vr180_remap.h)."""
@@ -687,9 +693,7 @@ def remap_tensors_auto(transformer: TransformerBase, srcs: Sequence[torch.Tensor
     chain = _lower_cached(transformer, radius=nominal, size_input=size_in, size_output=dst_wh)
     plan = _plan_for(chain, src_hw=src_hw, dst_wh=dst_wh, cn=int(srcs[0].shape[2]), interpolation=interpolation,
                      border_mode=boarder_mode, border_value=boarder_value, device=dev)
-    if rad is None:
-        rad = auto_radius_tensor(srcs)
-    plan.run_auto(srcs, dsts, rad)
+    plan.run_auto(srcs, dsts, rad)  # (rad None: the call estimates from `srcs` itself -- one small launch in front of the remap)
     _TLS.plans = [plan]
 
 
