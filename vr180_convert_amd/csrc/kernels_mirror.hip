@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 NE raw boxes (or the general code's cell buffers)
+    if (V1C_PRIO & 4)
+        __builtin_amdgcn_s_setprio(3);
     args_cref a = kernel_args<kMirrorHeadBytes>();
     const int tid = threadIdx.x;
     // grid: first `rest_rows` rows of workgroups for the tiles this path leaves out (general pair code: they take longest, so
@@ -181,6 +183,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V1C_RAW_WAV
     const int nq = raw_box_dma(q, mq, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, raw_q);  // ... and of the mirrored band
     if (NE == 2)
         raw_box_dma(q, mq, U[NE - 1].src, (uint32_t)U[NE - 1].src_pitch, lane, wave, raw_q + box_bytes);
+    if (V1C_PRIO & 4)
+        __builtin_amdgcn_s_setprio(0);
     // Barriers without __syncthreads()' fence (it would wait for every load in flight): each wave waits for its own part of
     // what the barrier publishes -- vmcnt counts in issue order -- then joins.
     wait_vm_barrier(NE * (nb + nq));  // table slice landed (this wave's box loads may still be in flight)
@@ -240,6 +244,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];  // 2 raw boxes of a.kb KB (or the general code's cell buffers)
+    if (V1C_PRIO & 4)
+        __builtin_amdgcn_s_setprio(3);
     args_cref a = kernel_args<kMirrorHeadBytes>();
     const int tid = threadIdx.x;
     const unsigned tiles_x = gx_rest & 0xffffu, rest_rows = REST ? gx_rest >> 16 : 0u;
@@ -293,6 +299,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REST ? V1C_
     const RawLanes mb = raw_lanes(b.cpr, lane), mq = raw_lanes(q.cpr, lane);
     const int nb = raw_box_dma(b, mb, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, raw_b);
     const int nq = raw_box_dma(q, mq, U[0].src, (uint32_t)U[0].src_pitch, lane, wave, raw_q);
+    if (V1C_PRIO & 4)
+        __builtin_amdgcn_s_setprio(0);
     wait_vm_barrier(nb + nq);  // table slice
     const uint32_t pitch_b = (uint32_t)raw_units_per_row(b.cpr) * 16u, pitch_q = (uint32_t)raw_units_per_row(q.cpr) * 16u;
     uint32_t ta_b[kPX], ta_q[kPX];

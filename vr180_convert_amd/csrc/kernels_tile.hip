@@ -182,6 +182,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
     constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) double tabw[kTabSlice * kRadialCoefs];
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_box[];
+    if (V1C_PRIO & 8)
+        __builtin_amdgcn_s_setprio(3);
     args_cref a = kernel_args();
     touch_args(a);
     const int tid = threadIdx.x;
@@ -242,6 +244,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ROT ? 4 : (
             done_at[i] = issued;
         }
     }
+    if (V1C_PRIO & 8)
+        __builtin_amdgcn_s_setprio(0);
     wait_vm_barrier(issued - 1);  // table slice landed
     const uint32_t pitch = (uint32_t)raw_units_per_row(b.cpr) * 16u;
     uint32_t ta[kPX];

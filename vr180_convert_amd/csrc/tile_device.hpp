@@ -39,6 +39,18 @@
 
 #include "kernels.hpp"
 
+// V1C_PRIO (bits): s_setprio 3 from a workgroup's first instruction until its box / table loads are requested (back to 0 behind them) --
+// 1: bicubic / Lanczos4 tile kernels, 2: bilinear tile kernels, 4: mirror kernels, 8: batch kernel.  A workgroup that has just started
+// is the youngest on its SIMD: without the priority its few load instructions queue behind the older workgroups' tap arithmetic and
+// the memory latency starts late.  Round 5, one box, interleaved (profiles/r05g_prio/): C4 1.256 -> 1.204 ms, C1L 0.0912 -> 0.0880, C2R
+// 0.0677 -> 0.0653, P3 0.0502 -> 0.0481, C2NN 0.0530 -> 0.0519, C3 0.1741 -> 0.1727, C2 / C1 / C1S / P1 / P2 / C2L within 0.6 %.  Measured and
+// not kept: the kernels without plan-time boxes at priority through coordinates and box reduction (C5 +3 %), priority around the
+// mirror pair kernel's second-eye requests and the batch ring's refills (C2 +1.5 %, C1 +2 %), priority 1 for the mirror kernel's
+// gather + store phases (C1 +9 %) or for its coordinates (C1 +3 %, P1 -3.5 %, C2 +1 %), the gray / BGRA kernels (+-0.3 %).
+#ifndef V1C_PRIO
+#define V1C_PRIO 15
+#endif
+
 namespace v1c {
 
 
@@ -1371,6 +1383,8 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
     const uint32_t upitch1 = PAIR ? (uint32_t)U[z1].src_pitch : 0u;
     // everything the tile needs from global memory is requested up front: the boxes of the first
     // two units, the radial-table slice and the row / column table entries (one exposed latency)
+    if (((V1C_PRIO & 1) && K != 2) || ((V1C_PRIO & 2) && K == 2))  // (A/B: a workgroup's load phase in front of other workgroups' arithmetic)
+        __builtin_amdgcn_s_setprio(3);
     const TileBox b = load_tile_box(boxes, t.box_tile);
     const bool tail = box_touches_image_end(b, g);
     // bicubic / Lanczos4 with BORDER_CONSTANT: footprints that cross the edge of the source are served from the box too (lane_coords' `ext`;
@@ -1460,6 +1474,8 @@ __device__ __forceinline__ void shared_map_tile(args_cref a, int n_units, int up
         ((d2*)tabw)[tid] = tv;
     V1C_STAMP(1);  // wait for the loads + expand + LDS stores
     __syncthreads();
+    if (((V1C_PRIO & 1) && K != 2) || ((V1C_PRIO & 2) && K == 2))
+        __builtin_amdgcn_s_setprio(0);
     V1C_STAMP(2);  // barrier
     const bool interior = tab_lds & (b.interior != 0);  // wave-uniform: no validity / inside tests needed
     // Interior tile of a bilinear batch whose every unit can be staged (the common case by far): a
