@@ -766,12 +766,13 @@ def main() -> None:
             # INTER_CUBIC / INTER_LANCZOS4 are not HBM-bound: K x K taps x 3 channels x 2 eyes exact integer multiply-accumulates per
             # output position, one v_perm_b32 + one v_dot2_i32_i16 per two of them (OpenCV's int16 weights admit no cheaper exact form:
             # HISTORY.md 4.5).  Ceiling = the VALU issue time of the kernel's instruction stream: waves x VALU instructions per wave x 4
-            # cycles per wave-instruction on 1024 SIMDs at the ~2.1 GHz the part sustains.  The instruction count is MEASURED by this
+            # cycles per wave-instruction on 1024 SIMDs at the part's MAXIMUM clock, 2.4 GHz (MI355X_MICROARCH.md; under load it holds 1.9 - 2.3: a
+            # ceiling at a sustained clock -- 2.1 GHz until round 5 -- put bicubic above 1).  The instruction count is MEASURED by this
             # run (a `--pmc SQ_INSTS_VALU SQ_WAVES` child pass of the same workload: "source": "live"); without rocprofv3 the object
             # says so and carries no ceiling.  `frac` stays the HBM fraction (the metric); `valu_int` says how close the launch is to
             # what actually bounds it.
             line["roofline"]["bound"] = "valu-int"
-            cyc, clk = 4.0, 2.1e9
+            cyc, clk = 4.0, 2.4e9
             vi = None
             if world == 1 and not child and args.traffic == "live":
                 vi = measure_valu_per_wave(args.workload)
