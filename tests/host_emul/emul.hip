@@ -109,6 +109,66 @@ int emul_get_map(const v1c_chain* ch, const double* rot_or_null, int w, int h, i
     return 0;
 }
 
+// The lane of 4 adjacent pixels that starts at column i4 of row j, as tile_device.hpp's lane_coords evaluates it with OWN = 1: pixel 1's
+// table entry for every pixel within the entry's validated range, the pixel's own entry otherwise.  out[8 k + 0..7] for pixel k: table
+// coordinate t, own index, z relative to pixel 1's entry, level of pixel 1's entry, G by the shared rule, G by the own entry, x, y (own).
+int emul_lane_probe(const v1c_chain* ch, int w, int h, int j, int i4, double* out)
+{
+    RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
+        return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
+    });
+    if (!H.a.ok || !H.usable)
+        return 1;
+    const RayAnalysis& a = H.a;
+    const RadialTable& T = H.table;
+    const RayHostTables& ht = H.ht;
+    RayParams P{};
+    P.radial = T.coef.data();
+    P.inv_step = T.inv_step, P.n_int = T.n_int, P.var_is_w = T.var_is_w;
+    P.gen_mode = a.gen_mode;
+    if (H.has_pre) {
+        P.pre_s = H.pre_s.coef.data(), P.pre_c = H.pre_c.coef.data();
+        P.pre_var_is_w = H.pre_s.var_is_w, P.pre_inv_step = H.pre_s.inv_step, P.pre_n_int = H.pre_s.n_int;
+    }
+    double tt[4], mm[4], fx[4], fy[4];
+    int idx[4];
+    for (int k = 0; k < 4; k++) {
+        const int i = i4 + k;
+        double m;
+        if (a.gen_mode) {
+            gen_vector(P, a.rot, ht.row_s[j], ht.row_c[j], ht.row_h[j], ht.col_s[i], ht.col_h[i], fx[k], fy[k], m);
+        } else {
+            fx[k] = fy[k] = 0;
+            m = fma(ht.row_c[j], ht.col_h[i], ht.row_h[j]);
+        }
+        mm[k] = m;
+        const double u = T.var_is_w ? fast_sqrt_half(m) : m;
+        tt[k] = u * T.inv_step;
+        idx[k] = std::min(table_index(tt[k]), T.n_int - 1);
+    }
+    const int ic = idx[1];
+    const double* e = T.coef.data() + (size_t)ic * kRadialCoefs;
+    uint64_t bits;
+    std::memcpy(&bits, &e[kRadialDegree], 8);
+    const int level = (int)(bits & 3);
+    for (int k = 0; k < 4; k++) {
+        const double zk = tt[k] - ((double)ic + 0.5);
+        const bool usec = std::fabs(zk) <= 0.5 + level;
+        double gs = e[kRadialDegree];
+        for (int q = kRadialDegree - 1; q >= 0; q--)
+            gs = fma(gs, zk, e[q]);
+        const double* pc = T.coef.data() + (size_t)idx[k] * kRadialCoefs;
+        const double zo = tt[k] - ((double)idx[k] + 0.5);
+        double go = pc[kRadialDegree];
+        for (int q = kRadialDegree - 1; q >= 0; q--)
+            go = fma(go, zo, pc[q]);
+        out[8 * k + 0] = tt[k], out[8 * k + 1] = idx[k], out[8 * k + 2] = zk, out[8 * k + 3] = level;
+        out[8 * k + 4] = usec ? gs : go, out[8 * k + 5] = go;
+        out[8 * k + 6] = fma(go * 32.0 * a.rx, fx[k], 32.0 * a.cx) / 32.0, out[8 * k + 7] = fma(go * 32.0 * a.ry, fy[k], 32.0 * a.cy) / 32.0;
+    }
+    return 0;
+}
+
 // What the plan derives from a chain and an output size (radial_fit.hpp: build_ray_plan_host), for tests that assert which path a
 // chain takes: out[0] = analysis ok, [1] = usable, [2] = base, [3] = gen_mode, [4] = main table fn, [5] = its variable (0 m / 1 w),
 // [6] = intervals, [7] = first interval below level 1, [8] = below level 2, [9] = first flagged, [10] = one entry per lane provable

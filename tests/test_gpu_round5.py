@@ -449,3 +449,31 @@ def test_bench_lines_of_the_round5_workloads(workload, kinds):
     assert line["world_size_seen"] == 1
     if workload in ("P3L", "C0"):
         assert line["roofline"]["bound"] == "valu-int" and "source" in line["roofline"]["valu_int"]
+
+
+def test_lane_whose_second_pixel_is_outside_the_pre_tables(V, oracle_mod, dev):
+    """tools/fuzz.py --seed 34, case 1974 (round 5): a Zoom in front of two rotations (general mode 2), 154 x 1427 from 192 x 192.  In row
+    872 the base variable of columns <= 93 lies outside the S / Cm tables (fix-up pass), columns 94 and 95 are good pixels of the same
+    lane: pixel 1's arbitrary table index pointed one entry beside the tile's LDS slice, the clamped read returned the neighbouring
+    entry, and the two good pixels evaluated it about the wrong centre -- 0.4 px off.  Bytes against the oracle, every interpolation."""
+    from vr180_convert_amd import remapper
+
+    O = oracle_mod
+    spec = [("equirect_enc", True), ("zoom", 1.7738941798002221),
+            ("rot", [[0.9982728060815481, 0.058690132718145105, 0.002621633002223754], [-0.05872470490000005, 0.9981458957992685, 0.01600561568587129],
+                     [-0.0016774005126221434, -0.016131925508209265, 0.9998684650027312]]),
+            ("rot", [[0.9999105236968615, -0.00792577709040616, 0.010776207949987819], [0.007884260865708426, 0.999961353887725, 0.003889622299068912],
+                     [-0.010806619770753778, -0.003804311835424161, 0.999934369936642]]), ("fisheye_dec", "equidistant")]
+    wo, ho, ws, hs, radius = 154, 1427, 192, 192, 96.0
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (hs, ws, 3), dtype=np.uint8)
+    fill = rng.integers(0, 256, (ho, wo, 3), dtype=np.uint8)
+    xm, ym = O.get_map(spec, radius=radius, size_input=(hs, ws), size_output=(wo, ho))
+    t = CS.to_product(spec)
+    for interp, border in ((1, 0), (2, 5), (4, 0), (0, 0)):
+        want = O.remap(img, xm, ym, interp, border, (1, 2, 3), dst=fill.copy())
+        dst = torch.from_numpy(fill.copy()).to(dev)
+        V.remap_tensors(t, [torch.from_numpy(img).to(dev)], [dst], radius=radius, interpolation=interp, boarder_mode=border, boarder_value=(1, 2, 3))
+        assert remapper.last_launch_kinds()[0].startswith("tile"), remapper.last_launch_kinds()
+        d = np.argwhere((dst.cpu().numpy() != want).any(axis=2))
+        assert len(d) == 0, (interp, border, d[:4].tolist())

@@ -172,3 +172,24 @@ def test_sampler_equals_oracle(emul_lib, product_lib, oracle_mod, cn):
                     C.c_void_p(cv.ctypes.data), C.c_void_p(None if it is None else it.ctypes.data))
                 assert rc == 0
                 assert np.array_equal(ref, out), (cn, interp, border, bv)
+
+
+@pytest.mark.parametrize("name", ["c2_poly", "c4_rot_poly", "apply_equirectangular", "transformer_rotator"])
+def test_an_entrys_level_covers_the_lanes_it_is_shared_by(emul_lib, oracle_mod, name):
+    """The tile kernels evaluate a lane's 4 pixels with pixel 1's table entry wherever the entry's level (the two low mantissa bits of
+    c7: valid on |z| <= 0.5 + level) says so.  emul_lane_probe applies that rule on the host: G by the shared rule against G by the
+    pixel's own entry -- both within 1.5e-15 of the function, so within 4e-15 of each other -- for lanes all over the image."""
+    spec, out, inp, radius = CS.SMALL_CASES[name]
+    ch = oracle_mod.chain_from_spec(spec, radius=radius, size_input=inp, size_output=out)
+    buf = (C.c_double * 32)()
+    shared = 0
+    for j in range(0, out[1], max(1, out[1] // 23)):
+        for i4 in range(0, out[0] - 3, 4 * max(1, out[0] // 92)):
+            if emul_lib.emul_lane_probe(C.byref(ch), out[0], out[1], j, i4, buf) != 0:
+                pytest.skip("not a fused chain")
+            for k in range(4):
+                t, idx, z1, level, gs, go = buf[8 * k:8 * k + 6]
+                if np.isfinite(gs) and np.isfinite(go):
+                    assert abs(gs - go) <= 4e-15 * max(abs(go), 1.0), (name, j, i4 + k, z1, level, gs, go)
+                    shared += abs(z1) > 0.5 and abs(z1) <= 0.5 + level
+    assert shared > 0 or name == "transformer_rotator"

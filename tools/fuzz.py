@@ -120,14 +120,15 @@ KINDS: dict = {}  # kernel family -> launch groups it served (remapper.last_laun
 SINGULAR = [0]  # differing pixels among the ill-conditioned ones that are left out (module docstring)
 
 
-def dump_diff(k, got, want, maps, pmaps=None) -> None:
+def dump_diff(k, got, want, maps, pmaps=None, fill=None) -> None:
     """where unit k differs: counts, bounding box, the first pixels with their map coordinates (the oracle's and the product's)"""
     d = np.argwhere((got != want).any(axis=2))
     print(f"  unit {k}: {len(d)} pixels differ, rows {d[:, 0].min()}..{d[:, 0].max()}, cols {d[:, 1].min()}..{d[:, 1].max()}; "
           f"rows mod 16 {sorted(set((d[:, 0] % 16).tolist()))[:16]}, cols//4 mod 16 {sorted(set(((d[:, 1] // 4) % 16).tolist()))[:16]}")
     for (j, i) in d[:12]:
         pm = "" if pmaps is None else f" product map=({pmaps[0][j, i]!r}, {pmaps[1][j, i]!r})"
-        print(f"    (row {j}, col {i}) map=({maps[0][j, i]!r}, {maps[1][j, i]!r}){pm} got={got[j, i].tolist()} want={want[j, i].tolist()}")
+        fl = "" if fill is None else f" prefill={fill[j, i].tolist()}"
+        print(f"    (row {j}, col {i}) map=({maps[0][j, i]!r}, {maps[1][j, i]!r}){pm} got={got[j, i].tolist()} want={want[j, i].tolist()}{fl}")
 
 
 def ill_conditioned(spec, radius, size_in, size_out) -> np.ndarray:
@@ -308,7 +309,7 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
                 pm = V.get_map(CS.to_product(sp_k), radius=radius, size_input=sizes[k] if tuple_t else (hs, ws), size_output=(wo, ho))
             except Exception as e:  # noqa: BLE001
                 print("  (product map unavailable:", e, ")")
-            dump_diff(k, got[k], want, maps, pm)
+            dump_diff(k, got[k], want, maps, pm, fill)
     return desc, bad
 
 

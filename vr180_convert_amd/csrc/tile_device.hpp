@@ -476,12 +476,17 @@ __device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowC
         // validity level of the entry (radial_fit.hpp): the polynomial holds on |z| <= 0.5 + level
         const double zlim = 0.5 + (double)(__double2loint(e[kRadialDegree]) & 3);
         const double zc = (double)ic + 0.5;
+        // (OWN: pixel 1's entry serves the others only if it is the entry that was read -- its index inside the slice.  A slice holds the
+        //  entries of the tile's IN-TABLE pixels; a pixel 1 that is not one of them -- general mode 2: its base variable outside the S / Cm
+        //  tables, its m therefore arbitrary -- can point just beside the slice, the clamped read returns the neighbouring entry, and a
+        //  good pixel within that entry's range took its polynomial about the wrong centre: 0.4 px off, tools/fuzz.py seed 34 case 1974)
+        const bool ic_read = (unsigned)(ic - tab0) < (unsigned)tabn;
         unsigned own = 0;  // pixels that must use their own entry
 #pragma unroll
         for (int k = 0; k < kPX; k++) {
             const double zk = tt[k] - zc;
             if (OWN) {
-                const bool usec = fabs(zk) <= zlim;
+                const bool usec = (fabs(zk) <= zlim) & ic_read;
                 own |= (!usec & (bool)((in_table >> k) & 1)) ? 1u << k : 0u;
             }
             double gk = e[kRadialDegree];
