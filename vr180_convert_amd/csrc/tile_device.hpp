@@ -46,7 +46,8 @@
 // 0.0677 -> 0.0653, P3 0.0502 -> 0.0481, C2NN 0.0530 -> 0.0519, C3 0.1741 -> 0.1727, C2 / C1 / C1S / P1 / P2 / C2L within 0.6 %.  Measured and
 // not kept: the kernels without plan-time boxes at priority through coordinates and box reduction (C5 +3 %), priority around the
 // mirror pair kernel's second-eye requests and the batch ring's refills (C2 +1.5 %, C1 +2 %), priority 1 for the mirror kernel's
-// gather + store phases (C1 +9 %) or for its coordinates (C1 +3 %, P1 -3.5 %, C2 +1 %), the gray / BGRA kernels (+-0.3 %).
+// gather + store phases (C1 +9 %) or for its coordinates (C1 +3 %, P1 -3.5 %, C2 +1 %), the gray / BGRA kernels (+-0.3 %), the K x K
+// kernels keeping the priority through their coordinates (C4 +2.6 %).
 #ifndef V1C_PRIO
 #define V1C_PRIO 15
 #endif
