@@ -116,6 +116,7 @@ def make_view(rng, arr: np.ndarray, dev, allow_unaligned: bool):
 
 DUMP = [False]
 HOT = [0.3]  # share of the chain cases drawn from the shapes the tuned kernels serve (--hot)
+GEN2 = [0.0]  # share of the chain cases forced into general mode 2 (--gen2)
 KINDS: dict = {}  # kernel family -> launch groups it served (remapper.last_launch_kinds): which kernels the run reached
 SINGULAR = [0]  # differing pixels among the ill-conditioned ones that are left out (module docstring)
 
@@ -222,6 +223,37 @@ def one_case(rng, dev, big: float) -> tuple[str, int]:
         if not pair and wo * ho * n > 2.5e7:
             n = max(1, int(2.5e7 // (wo * ho)))
         use_rot = rot_units
+        unaligned_views = rng.random() < 0.15
+    if GEN2[0] > 0 and rng.random() < GEN2[0]:  # (no draw when the option is off: earlier seeds replay as they ran)
+        # general mode 2 on purpose (--gen2): radial stages / zooms IN FRONT of a rotation, so that the point enters 3-D through the S / Cm
+        # tables -- with outputs far from square and zooms that push the base variable out of those tables for part of the image (lanes
+        # whose pixels are split between the tile kernel and the fix-up pass: case 1974 of seed 34 was such a lane)
+        enc = ("equirect_enc", bool(rng.random() < 0.8)) if rng.random() < 0.7 else ("fisheye_enc", MODELS[int(rng.integers(5))])
+        pre = []
+        for _ in range(int(rng.choice([1, 1, 2]))):
+            k = rng.random()
+            if k < 0.5:
+                pre.append(("zoom", float(rng.uniform(0.5, 2.6))))
+            elif k < 0.8:
+                pre.append(("poly", [0.0, 1.0, float(rng.uniform(-0.2, 0.2))]))
+            else:
+                pre.append(("inverse", ("zoom", float(rng.uniform(0.5, 2.0)))))
+        rots = [("rot", rand_rot(rng, rng.random() < 0.5).tolist()) for _ in range(int(rng.choice([1, 1, 2])))]
+        post = [("poly", [0.0, 1.0, float(rng.uniform(-0.12, 0.06))])] if rng.random() < 0.3 else []
+        dec = ("fisheye_dec", "equidistant") if rng.random() < 0.7 else ("fisheye_dec", MODELS[int(rng.integers(5))])
+        spec = [enc] + pre + rots + post + [dec]
+        rot_at, use_rot = None, False
+        cn = int(rng.choice([3, 3, 3, 1, 4]))
+        interp = int(rng.choice([1, 1, 1, 0, 2, 4]))
+        border = int(rng.choice([0, 0, 0, 1, 4, 5]))
+        wo, ho = int(rng.integers(64, 1300)), int(rng.integers(64, 1500))
+        if interp in (2, 4):
+            wo, ho = min(wo, 1000), min(ho, 1000)
+        hs = int(rng.integers(60, 1200))
+        ws = hs + (0 if rng.random() < 0.5 else int(rng.integers(-hs // 3, hs // 2)))
+        radius = float(rng.uniform(0.3, 0.7) * min(ws, hs))
+        pair = rng.random() < 0.4
+        n = 2 if pair else int(rng.choice([1, 1, 2, 3]))
         unaligned_views = rng.random() < 0.15
     rots = [rand_rot(rng, False) for _ in range(n)] if use_rot else None
     # units of different source sizes behind one transformer: the map is for images[0] (remapper.py:385), every image is
@@ -583,6 +615,7 @@ def main() -> int:
     ap.add_argument("--big", type=float, default=0.15, help="share of sizes drawn from 1200 - 2700")
     ap.add_argument("--lut", type=float, default=0.15, help="share of cases that fuzz cv2.remap alone (v1c_remap_lut) on random maps")
     ap.add_argument("--hot", type=float, default=0.3, help="share of the chain cases drawn from the shapes the tuned kernels are selected for")
+    ap.add_argument("--gen2", type=float, default=0.0, help="share of the chain cases with radial stages / zooms in front of a rotation (general mode 2)")
     ap.add_argument("--api", type=float, default=0.1, help="share of cases through apply() / apply_lr() on host arrays")
     ap.add_argument("--auto", type=float, default=0.06, help="share of cases through apply_lr_tensors(radius='auto') with the radius on the device")
     ap.add_argument("--fused", type=float, default=0.06, help="share of cases through v1c_remap_fused by raw ctypes")
@@ -593,6 +626,7 @@ def main() -> int:
     a = ap.parse_args()
     DUMP[0] = a.dump
     HOT[0] = a.hot
+    GEN2[0] = a.gen2
     dev = torch.device("cuda", 0)
     log = open(a.log, "a") if a.log else None
 
