@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Differential fuzz WITHOUT a GPU: random chains and output sizes through the product's plan derivation and per-pixel code compiled
+for the host (tests/host_emul: radial_fit.hpp's analysis, table fits and proofs, v1c_core.hpp's ray path with the interpreter as its
+per-pixel fallback -- what the kernels and plan.hip are made of) against the oracle's float64 chain, bucket by bucket.
+
+    python3 tools/fuzz_cpu.py [--seconds 300] [--seed 1] [--gen2 0.3] [--hot 0.3]
+
+What it covers: which chains the plan accepts (base 0 / 1 / 2, general modes 1 / 2), the S / Cm and G tables with their flagged
+intervals, the row / column tables, the fix-up rule (a pixel the ray path declines takes the interpreter).  What it cannot cover: the
+tile kernels' lane logic (shared table entries, LDS slices, boxes) -- that is tools/fuzz.py on a GPU box.  Chains come from
+tools/fuzz.py's grammar (rand_spec, the hot shapes, --gen2); pixels where the chain amplifies a perturbation of the output position by
+1e6 or more are left out and counted (tools/fuzz.py: ill_conditioned).  Exit code 1 if a bucket differed elsewhere."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "tests" / "host_emul"))
+sys.path.insert(0, str(ROOT / "tools"))
+
+import build as emul_build  # noqa: E402
+import fuzz as F  # noqa: E402  (the grammar; importing it needs no GPU)
+from oracle import oracle as O  # noqa: E402
+
+
+def emul_map(E, ch, W, H, mode):
+    xm = np.empty((H, W), np.float32)
+    ym = np.empty((H, W), np.float32)
+    st = (C.c_longlong * 5)()
+    rc = E.emul_get_map(C.byref(ch), C.c_void_p(None), W, H, mode, C.c_void_p(xm.ctypes.data), C.c_void_p(ym.ctypes.data), st)
+    return rc, xm, ym, list(st)
+
+
+def buckets(x, y):
+    ok = np.isfinite(x) & np.isfinite(y)
+    bx = np.where(ok, np.rint(np.where(ok, x, 0).astype(np.float64) * 32), -2.0 ** 40)
+    by = np.where(ok, np.rint(np.where(ok, y, 0).astype(np.float64) * 32), -2.0 ** 40)
+    return bx, by
+
+
+def draw(rng, gen2: float, hot: float):
+    spec, _ = F.rand_spec(rng)
+    r = rng.random()
+    if r < gen2:
+        enc = ("equirect_enc", bool(rng.random() < 0.8)) if rng.random() < 0.7 else ("fisheye_enc", F.MODELS[int(rng.integers(5))])
+        pre = []
+        for _ in range(int(rng.choice([1, 1, 2]))):
+            k = rng.random()
+            pre.append(("zoom", float(rng.uniform(0.5, 2.6))) if k < 0.5 else ("poly", [0.0, 1.0, float(rng.uniform(-0.2, 0.2))]) if k < 0.8
+                       else ("inverse", ("zoom", float(rng.uniform(0.5, 2.0)))))
+        rots = [("rot", F.rand_rot(rng, rng.random() < 0.5).tolist()) for _ in range(int(rng.choice([1, 1, 2])))]
+        post = [("poly", [0.0, 1.0, float(rng.uniform(-0.12, 0.06))])] if rng.random() < 0.3 else []
+        dec = ("fisheye_dec", "equidistant") if rng.random() < 0.7 else ("fisheye_dec", F.MODELS[int(rng.integers(5))])
+        spec = [enc] + pre + rots + post + [dec]
+    elif r < gen2 + hot:
+        fam = rng.random()
+        enc = ("equirect_enc", fam >= 0.3) if fam < 0.6 else ("fisheye_enc", F.MODELS[int(rng.integers(5))])
+        mid = []
+        if rng.random() < 0.3:
+            mid.append(("poly", [0.0, 1.0, float(rng.uniform(-0.15, 0.08))]))
+        if rng.random() < 0.3:
+            mid.insert(int(rng.integers(0, len(mid) + 1)), ("rot", F.rand_rot(rng, rng.random() < 0.5).tolist()))
+        dec = ("fisheye_dec", "equidistant") if rng.random() < 0.7 else ("fisheye_dec", F.MODELS[int(rng.integers(5))])
+        spec = [enc] + mid + [dec]
+    wo, ho = int(rng.integers(16, 700)), int(rng.integers(16, 700))
+    if rng.random() < 0.5:
+        ho = wo
+    hs = int(rng.integers(40, 2000))
+    ws = hs if rng.random() < 0.5 else max(8, hs + int(rng.integers(-hs // 3, hs // 2)))
+    rsel = rng.random()
+    radius = min(ws, hs) / 2 if rsel < 0.5 else float(rng.uniform(0.2, 1.6) * min(ws, hs) / 2) if rsel < 0.92 else -float(rng.uniform(5, 100))
+    return spec, (wo, ho), (hs, ws), float(radius)
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--gen2", type=float, default=0.3)
+    ap.add_argument("--hot", type=float, default=0.3)
+    a = ap.parse_args()
+    E = C.CDLL(str(emul_build.build()))
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    n = fused = reported = 0
+    left_out = 0
+    modes: dict = {}
+    while time.time() - t0 < a.seconds:
+        spec, out, inp, radius = draw(rng, a.gen2, a.hot)
+        n += 1
+        try:
+            ch = O.chain_from_spec(spec, radius=radius, size_input=inp, size_output=out)
+        except Exception:  # noqa: BLE001  (a chain the oracle's lowering rejects: not a case)
+            continue
+        info = (C.c_longlong * 12)()
+        E.emul_plan_info(C.byref(ch), out[0], out[1], info)
+        if not (info[0] and info[1]):
+            continue
+        rc, xm, ym, st = emul_map(E, ch, out[0], out[1], 1)
+        if rc != 0:
+            continue
+        fused += 1
+        key = f"base{info[2]}/gen{info[3]}"
+        modes[key] = modes.get(key, 0) + 1
+        ox, oy = O.get_map(spec, radius=radius, size_input=inp, size_output=out)
+        bx, by = buckets(xm, ym)
+        rx, ry = buckets(ox, oy)
+        d = (bx != rx) | (by != ry)
+        if d.any():
+            sing = F.ill_conditioned(spec, radius, inp, out)
+            left_out += int((d & sing).sum())
+            d &= ~sing
+        if d.any():
+            reported += 1
+            j, i = np.argwhere(d)[0]
+            print(f"[case {n}] {int(d.sum())} buckets differ, first at ({j}, {i}): emul ({xm[j, i]!r}, {ym[j, i]!r}) oracle ({ox[j, i]!r}, {oy[j, i]!r}) "
+                  f"spec={spec!r} out={out} src={inp} radius={radius!r} fixup_pixels={st[1]}", flush=True)
+    print(f"fuzz_cpu seed {a.seed}: {n} cases, {fused} fused ({modes}), {reported} reported; {left_out} differing ill-conditioned pixels left out; "
+          f"{time.time() - t0:.0f} s")
+    return 1 if reported else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
