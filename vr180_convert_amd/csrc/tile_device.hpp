@@ -994,7 +994,9 @@ __device__ __noinline__ uint64_t blend_table_pair(lds_cell_ptr cells, uint32_t l
 
 // Border-aware K x K sampler for the pixels whose footprint leaves the source (same arithmetic as
 // sample_table<3, K> in v1c_core.hpp; the row loop rolled, a row's taps together: see inside.  The
-// callee's VGPRs count against the kernel -- 117 for K = 8, four waves per SIMD).
+// callee's VGPRs count against the kernel -- 117 for K = 8, four waves per SIMD.  With a row's taps in two round trips of four the
+// Lanczos4 pair kernels need 88 and run five: C2L +3.3 %, P1L +3 %, C4 +0.6 %, C1L +-0 -- a fifth wave only adds to the LDS queue
+// (profiles/r05g_prio/ab_lanczos4_five_waves_per_simd.log).)
 template <int K>
 // (border mode and the packed BGR border value as plain scalars: a Geom passed by value to a
 // non-inlined function had its byte members mis-read -- cval[2] came back as 63)
