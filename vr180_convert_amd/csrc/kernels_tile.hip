@@ -734,7 +734,16 @@ static void launch_tile_k(const KernelCtx& c, const KernelCtx* cdev, const Launc
         grid = tile_grid(c.g, 256, (n_units + 1) / 2);
     }
     // two box buffers (+ the K x K pair path's exchange buffer: 1 KB per wave, see shared_map_tile)
-    const size_t lds = bx ? (size_t)half_dwords * 8 + 16 + (K != 2 && pair ? kKxkExchangeBytes : 0) + lds_pad : 0;
+    size_t lds = bx ? (size_t)half_dwords * 8 + 16 + (K != 2 && pair ? kKxkExchangeBytes : 0) + lds_pad : 0;
+    // Lanczos4 pairs: at most three workgroups per CU.  Their gather keeps the LDS pipe busier than anything else in the engine (8 x 8 cells
+    // of two eyes per pixel); a fourth resident workgroup -- which boxes below ~36 KB would admit -- only lengthens its queue: C2L 0.3050 ->
+    // 0.2965 ms with the launch padded to three, C1L and C4 (boxes of 41 - 44 KB: three anyway) slower by 7 - 11 % at two, bicubic faster with
+    // every workgroup it can get (profiles/r05g_prio/ab_lds_pad*.log).
+#ifndef V1C_K8_MIN_LDS
+#define V1C_K8_MIN_LDS 40960
+#endif
+    if (bx && K == 8 && pair)
+        lds = std::max(lds, (size_t)V1C_K8_MIN_LDS);
     // (An LDS-DMA form of the plain pair kernel -- k_ray_lin3_pair_mirror_raw without the mirror image -- was built and removed:
     // bit-identical, but 0.0535 against 0.0511 ms on an unrotated 4080^2 pair and 0.0733 against 0.0684 ms on a rotated
     // 4096^2 pair (94 VGPRs): with one tile per workgroup the interleaved cells' single ds_read2_b64 per tap row wins.)
