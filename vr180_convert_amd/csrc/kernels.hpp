@@ -109,7 +109,7 @@ int tile_mirror_raw_passes(const void* host_boxes, const void* host_mboxes, cons
 hipError_t launch_ray_lin3_pair_mirror(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, const void* boxes,
                                        const void* mboxes, int half_dwords, int mirror_h, const uint32_t* rest_list, int n_rest, int raw_nwp,
                                        hipStream_t stream, int seq_kb);
-int tile_half_dwords(const void* host_boxes, size_t n_tiles, int max_chunks = 1024);
+int tile_half_dwords(const void* host_boxes, size_t n_tiles, int max_chunks, bool occupancy_classes);
 // `coords_bounded` (launches without boxes): the host has bounded |32 x|, |32 y| < 2^21 for every pixel of every unit
 // (radial_table_g_bound): k_ray_lin3_rot_pair_raw evaluates its speculative coordinates without the clamps of the cvRound trick
 hipError_t launch_ray_lin3_tile(const KernelCtx& c, const KernelCtx* cdev, const LaunchUnits& lu, uint32_t* flags, bool use_rot, const void* boxes,

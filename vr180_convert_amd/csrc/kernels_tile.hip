@@ -482,18 +482,40 @@ constexpr int kMaxHalfDwords = 8192;  // 32 KB per buffer
 // second round (shared_map_tile) -- worth its LDS for bicubic / Lanczos4, whose global-memory path samples tap by tap (a lat_x Lanczos4
 // pair: 1.09 -> 0.12 ms), not for bilinear launches, where the larger buffers cost every tile occupancy (the same pair bilinear:
 // 0.050 -> 0.060 ms with them)
-int tile_half_dwords(const void* host_boxes, size_t n_tiles, int max_chunks)
+int tile_half_dwords(const void* host_boxes, size_t n_tiles, int max_chunks, bool occupancy_classes)
 {
     const TileBox* b = (const TileBox*)host_boxes;
     int m = 256;
+    size_t stageable = 0;
     for (size_t i = 0; i < n_tiles; i++) {
         if (b[i].cpr <= 0 || b[i].cpr > kMaxCpr || b[i].nrows * b[i].cpr > max_chunks)
             continue;
         const int need = b[i].nrows * (b[i].cpr * 4 + 4);
         if (need <= kMaxHalfDwords)
-            m = std::max(m, need);
+            m = std::max(m, need), stageable++;
     }
-    return (m + 3) & ~3;
+    m = (m + 3) & ~3;
+    // Bilinear / nearest pairs: the pair code's 74 VGPRs allow six workgroups per CU, its LDS (two buffers of `half` dwords + 4 KB of
+    // table) decides how many there are -- and the launch wants them more than it wants the largest boxes staged: a rotated 4096^2 pair
+    // whose largest box needs 3 744 dwords (four workgroups) ran 0.0659 ms, 0.0617 with the buffers capped at 2 688 (six; the 3 % of
+    // the tiles beyond them gather from global memory).  The smallest class that still stages 98 % of the tiles; chains whose boxes are
+    // large throughout (lat_x, planar + rotation: capped they lose 6 - 10 %) keep the maximum.  profiles/r05g_prio/ab_half_cap.log
+    if (occupancy_classes && stageable > 0) {
+        static const int classes[] = {2880, 3568};  // six / five workgroups per CU: (160 KB / n - 4 160 B static) / 8
+        for (int cap : classes) {
+            if (cap >= m)
+                break;
+            size_t fit = 0;
+            for (size_t i = 0; i < n_tiles; i++) {
+                if (b[i].cpr <= 0 || b[i].cpr > kMaxCpr || b[i].nrows * b[i].cpr > max_chunks)
+                    continue;
+                fit += b[i].nrows * (b[i].cpr * 4 + 4) <= cap;
+            }
+            if (fit * 100 >= stageable * 98)
+                return cap;
+        }
+    }
+    return m;
 }
 
 // Box buffer size (dwords) of the lean batch kernel: capped so that 6 workgroups -- what its 80 VGPRs

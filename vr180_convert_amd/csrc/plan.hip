@@ -659,7 +659,8 @@ extern "C" int v1c_plan_create(v1c_plan** out, int device, const v1c_chain* chai
                     v1c_plan_destroy(p);
                     return fail(V1C_E_HIP, std::string("tile boxes readback: ") + hipGetErrorString(e));
                 }
-                p->half_dwords = tile_half_dwords(hb.data(), hb.size() / 32, (p->gen_mode != 0 && (g.interp == V1C_INTER_LANCZOS4 || g.interp == V1C_INTER_CUBIC)) ? 2048 : 1024);
+                p->half_dwords = tile_half_dwords(hb.data(), hb.size() / 32, (p->gen_mode != 0 && (g.interp == V1C_INTER_LANCZOS4 || g.interp == V1C_INTER_CUBIC)) ? 2048 : 1024,
+                                                  g.interp == V1C_INTER_LINEAR || g.interp == V1C_INTER_NEAREST);
                 if (const char* e = tuning_env("V1C_HALF_CAP"); e && std::atoi(e) >= 256)  // A/B: cap the LDS box buffers
                     p->half_dwords = std::min(p->half_dwords, std::atoi(e));
                 {
