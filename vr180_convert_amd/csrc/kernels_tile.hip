@@ -610,11 +610,23 @@ int tile_lean_raw_passes(const void* host_boxes, const Geom& g)
             continue;
         hist[std::min((b[i].nrows * raw_units_per_row(b[i].cpr) + 63) / 64, kRawMaxWavePasses + 1)]++, n++;
     }
+    // ... and then as much more as the CU holds the same number of workgroups with (two buffers + 4 KB of table each; six is what the
+    // kernel's registers allow): the 2 % beyond the quantile ride the general pair code, a few of them less is free -- C3 with 10 instead
+    // of 9 KB: 0.1765 -> 0.1745 ms, with 12 (five workgroups) 0.1814 (profiles/r05g_prio/ab_lean_raw_kb.log)
+    auto per_cu = [](int k) { return std::min(163840 / (2 * 1024 * k + 4224), 6); };
+    int largest = 0;
+    for (int k = 0; k <= kRawMaxWavePasses; k++)
+        if (hist[k])
+            largest = k;
     size_t acc = 0;
     for (int k = 0; k <= kRawMaxWavePasses; k++) {
         acc += hist[k];
-        if (acc * 100 >= n * 98)
-            return std::max(k, 4);
+        if (acc * 100 >= n * 98) {
+            int kk = std::max(k, 4);
+            while (kk < largest && kk < kRawMaxWavePasses && per_cu(kk + 1) == per_cu(kk))
+                kk++;
+            return kk;
+        }
     }
     return kRawMaxWavePasses;
 }
