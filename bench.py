@@ -454,7 +454,8 @@ def new_radius_cost(cfg, dev, V, transformer_builder):
         except Exception as e:  # noqa: BLE001 - must never break the bench line
             out[key] = repr(e)
     out["new_radius_note"] = ("radius='auto' per L+R pair whose image circle differs from the previous pair's, wall ms per call: on the device "
-                              "(v1c_plan_run_auto: no sync, one plan) / exact (estimates to the host, plan per radius)")
+                              "(v1c_plan_run_auto_images: no sync, one plan) / exact (estimates to the host: a sync; the launch that reads the radius from "
+                              "device memory for a circle that moved, a plan of its own for one that repeats)")
     return out
 
 

@@ -309,6 +309,32 @@ def test_auto_radius_estimated_by_the_launch_itself_equals_the_two_step_form(V, 
             assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], want), ((h, w), srcs[1].stride(0))
 
 
+def test_exact_auto_radius_takes_no_plan_per_radius(V, oracle_mod, dev):
+    """The exact form of radius="auto" (estimates to the host: IndexError like the reference) on a stream whose image circle moves: every
+    new radius is served by the launch that reads it from device memory (ONE plan), bytes equal to the oracle's apply_lr; a circle that
+    repeats gets a plan of its own -- the planned kernels -- on its second call."""
+    from vr180_convert_amd import remapper
+
+    O = oracle_mod
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.1]), CS.EQUI]
+    t = CS.to_product(spec)
+    remapper.clear_caches()
+    n_plans = []
+    pairs = [(_disc(512, 512, r0, 20 + k), _disc(512, 512, r1, 30 + k)) for k, (r0, r1) in enumerate(((250, 240), (231.5, 244), (199, 180.5)))]
+    for a, b in pairs + pairs[-1:]:
+        got = V.apply_lr_tensors(t, torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), size_output=(512, 512), interpolation=1,
+                                 radius="auto", auto_radius_on_device=False)
+        assert remapper.last_auto_radius_form() == "exact"
+        n_plans.append((len(remapper._PLANS), remapper.last_launch_kinds()[0]))
+        want = O.apply_lr(spec, a, b, size_output=(512, 512), interpolation=1, radius="auto")
+        assert np.array_equal(got.cpu().numpy(), want), n_plans
+    assert [n for n, _ in n_plans] == [1, 1, 1, 2], n_plans
+    assert all(k in ("rot_pair", "tile") for _, k in n_plans[:3]) and n_plans[3][1] in ("mirror", "tile"), n_plans
+    with pytest.raises(IndexError):
+        V.apply_lr_tensors(t, torch.full((512, 512, 3), 90, dtype=torch.uint8, device=dev), torch.from_numpy(pairs[0][0]).to(dev),
+                           size_output=(512, 512), interpolation=1, radius="auto", auto_radius_on_device=False)
+
+
 def test_apply_lr_auto_radius_is_graph_capturable_end_to_end(V, oracle_mod, dev):
     """radius="auto" -- the reference's default -- recorded into a graph: estimate, maximum, scale and remap are four launches and no
     synchronisation.  The graph is replayed on NEW pixels with ANOTHER image circle in the same buffers: the radius follows the image."""
