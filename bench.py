@@ -436,7 +436,7 @@ def new_radius_cost(cfg, dev, V, transformer_builder):
     yy, xx = torch.meshgrid(torch.arange(size, device=dev), torch.arange(size, device=dev), indexing="ij")
     rr = (xx - size / 2) ** 2 + (yy - size / 2) ** 2
     base = torch.randint(40, 256, (size, size, 3), dtype=torch.uint8, device=dev)
-    n_img = 12
+    n_img = 22  # (a first pair to create the plan, then 10 timed pairs)
     imgs = [base * (rr <= (size / 2 - 3 - 1.5 * k) ** 2)[..., None].to(torch.uint8) for k in range(n_img)]
     sbs = torch.empty((size, 2 * size, 3), dtype=torch.uint8, device=dev)
     t = transformer_builder(cfg)
