@@ -169,6 +169,91 @@ int emul_lane_probe(const v1c_chain* ch, int w, int h, int j, int i4, double* ou
     return 0;
 }
 
+// Host model of how the tile kernels evaluate the radial table in one 64 x 16 tile (tile_device.hpp: lane_coords with OWN = 1, fed by
+// the slice k_tile_boxes sizes): the tile's slice = the entries of its IN-TABLE pixels when there are at most 64 of them (else the whole
+// table); every lane of 4 adjacent pixels reads the entry of its pixel 1 as slice element ic - tab0 CLAMPED into the slice, and
+// shared_entry_serves (v1c_core.hpp: the kernels' own rule) decides which of the lane's pixels take that entry instead of their own.
+// out[0] = largest |G_lane - G_own| / max(|G_own|, 1) over the tile's in-table pixels (both are within 1.5e-15 of the function when the
+// rule is right), out[1] = in-table pixels, out[2] = pixels served by a shared entry, out[3] = lanes whose pixel 1 points outside the
+// slice, out[4] = slice entries (0: whole table).  `ignore_read` = 1: the rule as it was before round 5's fix (the index test dropped).
+int emul_tile_lane_model(const v1c_chain* ch, int w, int h, int tx, int ty, int ignore_read, double* out)
+{
+    RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
+        return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
+    });
+    for (int q = 0; q < 5; q++)
+        out[q] = 0;
+    if (!H.a.ok || !H.usable)
+        return 1;
+    const RayAnalysis& a = H.a;
+    const RadialTable& T = H.table;
+    const RayHostTables& ht = H.ht;
+    RayParams P{};
+    P.radial = T.coef.data();
+    P.inv_step = T.inv_step, P.n_int = T.n_int, P.var_is_w = T.var_is_w;
+    P.gen_mode = a.gen_mode;
+    if (H.has_pre) {
+        P.pre_s = H.pre_s.coef.data(), P.pre_c = H.pre_c.coef.data();
+        P.pre_var_is_w = H.pre_s.var_is_w, P.pre_inv_step = H.pre_s.inv_step, P.pre_n_int = H.pre_s.n_int;
+    }
+    constexpr int TW = 64, TH = 16;
+    double tt[TH][TW];
+    int idx[TH][TW];
+    bool in_table[TH][TW];
+    int lo = 0x7fffffff, hi = -1;
+    for (int r = 0; r < TH; r++)
+        for (int c = 0; c < TW; c++) {
+            const int j = std::min(ty * TH + r, h - 1), i = std::min(tx * TW + c, w - 1);
+            double m, fx, fy;
+            bool ok = true;
+            if (a.gen_mode) {
+                ok = gen_vector(P, a.rot, ht.row_s[j], ht.row_c[j], ht.row_h[j], ht.col_s[i], ht.col_h[i], fx, fy, m);
+            } else if (a.has_rot) {
+                const double* R = a.rot;
+                m = 1.0 - fma(R[6] * ht.row_c[j], ht.col_s[i], fma(R[8] * ht.row_c[j], ht.col_c[i], R[7] * ht.row_s[j]));
+            } else {
+                m = fma(ht.row_c[j], ht.col_h[i], ht.row_h[j]);
+            }
+            const double u = T.var_is_w ? fast_sqrt_half(m) : m;
+            tt[r][c] = u * T.inv_step;
+            const int ir = table_index(tt[r][c]);
+            in_table[r][c] = ok && (unsigned)ir < (unsigned)T.n_int;
+            idx[r][c] = std::min(ir, T.n_int - 1);
+            if (in_table[r][c])
+                lo = std::min(lo, idx[r][c]), hi = std::max(hi, idx[r][c]);
+        }
+    int tab0 = 0, tabn = T.n_int;
+    if (lo <= hi && hi - lo + 1 <= 64)
+        tab0 = lo, tabn = hi - lo + 1, out[4] = tabn;
+    for (int r = 0; r < TH; r++)
+        for (int c4 = 0; c4 < TW; c4 += 4) {
+            const int ic = idx[r][c4 + 1];
+            const int rel = std::min(std::max(ic - tab0, 0), tabn - 1);
+            const double* e = T.coef.data() + (size_t)(tab0 + rel) * kRadialCoefs;
+            out[3] += (unsigned)(ic - tab0) >= (unsigned)tabn;
+            for (int k = 0; k < 4; k++) {
+                if (!in_table[r][c4 + k])
+                    continue;
+                const double zk = tt[r][c4 + k] - ((double)ic + 0.5);
+                const bool usec = ignore_read ? shared_entry_serves(zk, e[kRadialDegree], 0, 0, 1) : shared_entry_serves(zk, e[kRadialDegree], ic, tab0, tabn);
+                const double* pc = T.coef.data() + (size_t)idx[r][c4 + k] * kRadialCoefs;
+                const double zo = tt[r][c4 + k] - ((double)idx[r][c4 + k] + 0.5);
+                double go = pc[kRadialDegree], gs = e[kRadialDegree];
+                for (int q = kRadialDegree - 1; q >= 0; q--)
+                    go = fma(go, zo, pc[q]), gs = fma(gs, zk, e[q]);
+                out[1] += 1;
+                if (!std::isfinite(go))
+                    continue;  // (a flagged interval: NaN coefficients, the pixel goes to the fix-up pass either way)
+                if (usec) {
+                    out[2] += 1;
+                    const double d = std::fabs(gs - go) / std::max(std::fabs(go), 1.0);
+                    out[0] = std::max(out[0], std::isfinite(gs) ? d : 1e300);
+                }
+            }
+        }
+    return 0;
+}
+
 // What the plan derives from a chain and an output size (radial_fit.hpp: build_ray_plan_host), for tests that assert which path a
 // chain takes: out[0] = analysis ok, [1] = usable, [2] = base, [3] = gen_mode, [4] = main table fn, [5] = its variable (0 m / 1 w),
 // [6] = intervals, [7] = first interval below level 1, [8] = below level 2, [9] = first flagged, [10] = one entry per lane provable

@@ -193,3 +193,55 @@ def test_an_entrys_level_covers_the_lanes_it_is_shared_by(emul_lib, oracle_mod, 
                     assert abs(gs - go) <= 4e-15 * max(abs(go), 1.0), (name, j, i4 + k, z1, level, gs, go)
                     shared += abs(z1) > 0.5 and abs(z1) <= 0.5 + level
     assert shared > 0 or name == "transformer_rotator"
+
+
+FUZZ_1974 = [("equirect_enc", True), ("zoom", 1.7738941798002221),
+             ("rot", [[0.9982728060815481, 0.058690132718145105, 0.002621633002223754], [-0.05872470490000005, 0.9981458957992685, 0.01600561568587129],
+                      [-0.0016774005126221434, -0.016131925508209265, 0.9998684650027312]]),
+             ("rot", [[0.9999105236968615, -0.00792577709040616, 0.010776207949987819], [0.007884260865708426, 0.999961353887725, 0.003889622299068912],
+                      [-0.010806619770753778, -0.003804311835424161, 0.999934369936642]]), ("fisheye_dec", "equidistant")]
+
+
+def lane_model(E, ch, w, h, tx, ty, ignore_read=0):
+    buf = (C.c_double * 5)()
+    rc = E.emul_tile_lane_model(C.byref(ch), w, h, tx, ty, ignore_read, buf)
+    return rc, dict(zip(["err", "in_table", "shared", "pixel1_outside_slice", "slice"], list(buf)))
+
+
+def test_lane_model_reproduces_and_clears_the_shared_entry_bug(emul_lib, oracle_mod):
+    """tools/fuzz.py seed 34 case 1974 on the HOST: the model of a tile's table slice and of lane_coords' entry sharing
+    (emul_tile_lane_model; the sharing rule itself is the kernels' own function, v1c_core.hpp: shared_entry_serves).  Tile (1, 54) of that
+    case has 44 lanes whose pixel 1 points outside the tile's slice; without the index test of round 5's fix two good pixels take the
+    clamped neighbour's polynomial -- 0.47 % off in G, 0.4 px --, with it every shared pixel agrees with its own entry."""
+    ch = oracle_mod.chain_from_spec(FUZZ_1974, radius=96.0, size_input=(192, 192), size_output=(154, 1427))
+    rc, old = lane_model(emul_lib, ch, 154, 1427, 1, 54, ignore_read=1)
+    assert rc == 0 and old["pixel1_outside_slice"] > 0 and old["err"] > 1e-3, old
+    rc, new = lane_model(emul_lib, ch, 154, 1427, 1, 54)
+    assert rc == 0 and new["shared"] > 0 and new["err"] <= 4e-15, new
+
+
+def test_lane_model_on_general_mode_chains(emul_lib, oracle_mod):
+    """The same model over tiles of random chains with radial stages / zooms in front of a rotation (lanes split between the table and the
+    fix-up pass) and of the classic shapes: whatever entry a lane shares, it gives what the pixel's own entry gives."""
+    rng = np.random.default_rng(11)
+    from vr180_convert_amd.quat import as_rotation_matrix, from_rotation_vector
+
+    tiles = shared = outside = 0
+    for case in range(14):
+        pre = [("zoom", float(rng.uniform(0.5, 2.6)))] if rng.random() < 0.6 else [("poly", [0.0, 1.0, float(rng.uniform(-0.2, 0.2))])]
+        rot = ("rot", np.asarray(as_rotation_matrix(from_rotation_vector(rng.normal(0, 0.3, 3))), float).tolist())
+        enc = ("equirect_enc", True) if rng.random() < 0.7 else ("fisheye_enc", "equidistant")
+        spec = [enc] + (pre if case % 4 else []) + [rot, ("fisheye_dec", "equidistant")]
+        w, h = int(rng.integers(100, 900)), int(rng.integers(100, 1500))
+        src = int(rng.integers(100, 800))
+        ch = oracle_mod.chain_from_spec(spec, radius=float(rng.uniform(0.3, 0.7) * src), size_input=(src, src), size_output=(w, h))
+        for _ in range(6):
+            tx, ty = int(rng.integers(0, (w + 63) // 64)), int(rng.integers(0, (h + 15) // 16))
+            rc, m = lane_model(emul_lib, ch, w, h, tx, ty)
+            if rc != 0:
+                break
+            tiles += 1
+            shared += m["shared"]
+            outside += m["pixel1_outside_slice"]
+            assert m["err"] <= 4e-15, (spec, (w, h), src, (tx, ty), m)
+    assert tiles > 40 and shared > 1000, (tiles, shared, outside)

@@ -474,20 +474,17 @@ __device__ __forceinline__ void lane_coords(ctx_cref c, rot_cptr rot, const RowC
                 e[2 * q] = v.x, e[2 * q + 1] = v.y;
             }
         }
-        // validity level of the entry (radial_fit.hpp): the polynomial holds on |z| <= 0.5 + level
-        const double zlim = 0.5 + (double)(__double2loint(e[kRadialDegree]) & 3);
+        // pixel 1's entry serves a pixel inside the range the entry was validated on -- if it is the entry that was read (v1c_core.hpp:
+        // shared_entry_serves; a pixel 1 outside the table -- general mode 2: its base variable outside the S / Cm tables, its m
+        // arbitrary -- can point beside the slice, and two good pixels of such a lane once took the clamped neighbour's polynomial about
+        // the wrong centre: 0.4 px off, tools/fuzz.py seed 34 case 1974)
         const double zc = (double)ic + 0.5;
-        // (OWN: pixel 1's entry serves the others only if it is the entry that was read -- its index inside the slice.  A slice holds the
-        //  entries of the tile's IN-TABLE pixels; a pixel 1 that is not one of them -- general mode 2: its base variable outside the S / Cm
-        //  tables, its m therefore arbitrary -- can point just beside the slice, the clamped read returns the neighbouring entry, and a
-        //  good pixel within that entry's range took its polynomial about the wrong centre: 0.4 px off, tools/fuzz.py seed 34 case 1974)
-        const bool ic_read = (unsigned)(ic - tab0) < (unsigned)tabn;
         unsigned own = 0;  // pixels that must use their own entry
 #pragma unroll
         for (int k = 0; k < kPX; k++) {
             const double zk = tt[k] - zc;
             if (OWN) {
-                const bool usec = (fabs(zk) <= zlim) & ic_read;
+                const bool usec = shared_entry_serves(zk, e[kRadialDegree], ic, tab0, tabn);
                 own |= (!usec & (bool)((in_table >> k) & 1)) ? 1u << k : 0u;
             }
             double gk = e[kRadialDegree];

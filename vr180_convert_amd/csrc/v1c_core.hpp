@@ -15,6 +15,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/vr180_remap.h"
 
@@ -322,6 +323,24 @@ V1C_HDF double fast_sqrt_half(double m)
 #else
     return sqrt(a);
 #endif
+}
+
+// The tile kernels' rule for letting ONE radial-table entry serve several pixels of a lane (tile_device.hpp: lane_coords reads the entry
+// of the lane's pixel 1 and evaluates the others with it where this says so; the host model of tests/host_emul runs the same
+// function).  `zk` = the pixel's table coordinate relative to the centre of entry `ic`; `c7` = that entry's highest coefficient, whose
+// two low mantissa bits hold the range the entry was validated on (|z| <= 0.5 + level: radial_fit.hpp); the entry was read as element
+// ic - tab0 -- CLAMPED into [0, tabn) -- of the slice [tab0, tab0 + tabn) a workgroup keeps in LDS: when ic lies outside the slice the
+// coefficients are another entry's and nothing may share them (a pixel 1 that is outside the table can point anywhere).
+V1C_HDF bool shared_entry_serves(double zk, double c7, int ic, int tab0, int tabn)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int level = __double2loint(c7) & 3;
+#else
+    uint64_t bits;
+    memcpy(&bits, &c7, 8);
+    const int level = (int)(bits & 3u);
+#endif
+    return (fabs(zk) <= 0.5 + (double)level) & ((unsigned)(ic - tab0) < (unsigned)tabn);
 }
 
 // The rotated ray of the general modes (RayParams::gen_mode): fx, fy = its x / y components, m = 1 - its z component.  `q` = the
