@@ -176,11 +176,8 @@ int emul_lane_probe(const v1c_chain* ch, int w, int h, int j, int i4, double* ou
 // out[0] = largest |G_lane - G_own| / max(|G_own|, 1) over the tile's in-table pixels (both are within 1.5e-15 of the function when the
 // rule is right), out[1] = in-table pixels, out[2] = pixels served by a shared entry, out[3] = lanes whose pixel 1 points outside the
 // slice, out[4] = slice entries (0: whole table).  `ignore_read` = 1: the rule as it was before round 5's fix (the index test dropped).
-int emul_tile_lane_model(const v1c_chain* ch, int w, int h, int tx, int ty, int ignore_read, double* out)
+static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty, int ignore_read, double* out)
 {
-    RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
-        return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
-    });
     for (int q = 0; q < 5; q++)
         out[q] = 0;
     if (!H.a.ok || !H.usable)
@@ -251,6 +248,33 @@ int emul_tile_lane_model(const v1c_chain* ch, int w, int h, int tx, int ty, int 
                 }
             }
         }
+    return 0;
+}
+
+int emul_tile_lane_model(const v1c_chain* ch, int w, int h, int tx, int ty, int ignore_read, double* out)
+{
+    const RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
+        return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
+    });
+    return lane_model_of_tile(H, w, h, tx, ty, ignore_read, out);
+}
+
+// ... over every tile of the output (one plan): out[0] = the largest error, out[1 .. 3] summed, out[4] = tiles with a slice
+int emul_lane_model_all(const v1c_chain* ch, int w, int h, int ignore_read, double* out)
+{
+    const RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
+        return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
+    });
+    double acc[5] = {0, 0, 0, 0, 0}, t[5];
+    for (int ty = 0; ty < (h + 15) / 16; ty++)
+        for (int tx = 0; tx < (w + 63) / 64; tx++) {
+            if (lane_model_of_tile(H, w, h, tx, ty, ignore_read, t) != 0)
+                return 1;
+            acc[0] = std::max(acc[0], t[0]);
+            acc[1] += t[1], acc[2] += t[2], acc[3] += t[3], acc[4] += t[4] > 0;
+        }
+    for (int q = 0; q < 5; q++)
+        out[q] = acc[q];
     return 0;
 }
 

@@ -6,8 +6,9 @@ per-pixel fallback -- what the kernels and plan.hip are made of) against the ora
     python3 tools/fuzz_cpu.py [--seconds 300] [--seed 1] [--gen2 0.3] [--hot 0.3]
 
 What it covers: which chains the plan accepts (base 0 / 1 / 2, general modes 1 / 2), the S / Cm and G tables with their flagged
-intervals, the row / column tables, the fix-up rule (a pixel the ray path declines takes the interpreter).  What it cannot cover: the
-tile kernels' lane logic (shared table entries, LDS slices, boxes) -- that is tools/fuzz.py on a GPU box.  Chains come from
+intervals, the row / column tables, the fix-up rule (a pixel the ray path declines takes the interpreter).  The tile kernels' table
+slices and entry sharing are covered through a host MODEL (emul_lane_model_all: the sharing rule itself is the kernels' function); what
+it cannot cover are the kernels themselves -- boxes, staging, the sampler's LDS paths: that is tools/fuzz.py on a GPU box.  Chains come from
 tools/fuzz.py's grammar (rand_spec, the hot shapes, --gen2); pixels where the chain amplifies a perturbation of the output position by
 1e6 or more are left out and counted (tools/fuzz.py: ill_conditioned).  Exit code 1 if a bucket differed elsewhere."""
 from __future__ import annotations
@@ -93,6 +94,7 @@ def main() -> int:
     n = fused = reported = 0
     left_out = 0
     modes: dict = {}
+    lanes = [0.0, 0.0]  # pixels served by a shared entry, lanes whose pixel 1 points outside the slice
     while time.time() - t0 < a.seconds:
         spec, out, inp, radius = draw(rng, a.gen2, a.hot)
         n += 1
@@ -118,12 +120,21 @@ def main() -> int:
             sing = F.ill_conditioned(spec, radius, inp, out)
             left_out += int((d & sing).sum())
             d &= ~sing
+        # the tile kernels' table slices and entry sharing, modelled on the host over every tile (tests/host_emul: emul_lane_model_all)
+        lm = (C.c_double * 5)()
+        if E.emul_lane_model_all(C.byref(ch), out[0], out[1], 0, lm) == 0:
+            lanes[0] += lm[2]
+            lanes[1] += lm[3]
+            if lm[0] > 4e-15:
+                reported += 1
+                print(f"[case {n}] lane model: a shared entry is {lm[0]:.3e} off its pixel's own: spec={spec!r} out={out} src={inp} radius={radius!r}", flush=True)
         if d.any():
             reported += 1
             j, i = np.argwhere(d)[0]
             print(f"[case {n}] {int(d.sum())} buckets differ, first at ({j}, {i}): emul ({xm[j, i]!r}, {ym[j, i]!r}) oracle ({ox[j, i]!r}, {oy[j, i]!r}) "
                   f"spec={spec!r} out={out} src={inp} radius={radius!r} fixup_pixels={st[1]}", flush=True)
-    print(f"fuzz_cpu seed {a.seed}: {n} cases, {fused} fused ({modes}), {reported} reported; {left_out} differing ill-conditioned pixels left out; "
+    print(f"fuzz_cpu seed {a.seed}: {n} cases, {fused} fused ({modes}), {reported} reported; {left_out} differing ill-conditioned pixels left out; lane model: {lanes[0]:.0f} pixels on a shared entry, "
+          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice; "
           f"{time.time() - t0:.0f} s")
     return 1 if reported else 0
 
