@@ -175,10 +175,12 @@ int emul_lane_probe(const v1c_chain* ch, int w, int h, int j, int i4, double* ou
 // shared_entry_serves (v1c_core.hpp: the kernels' own rule) decides which of the lane's pixels take that entry instead of their own.
 // out[0] = largest |G_lane - G_own| / max(|G_own|, 1) over the tile's in-table pixels (both are within 1.5e-15 of the function when the
 // rule is right), out[1] = in-table pixels, out[2] = pixels served by a shared entry, out[3] = lanes whose pixel 1 points outside the
-// slice, out[4] = slice entries (0: whole table).  `ignore_read` = 1: the rule as it was before round 5's fix (the index test dropped).
+// slice, out[4] = slice entries (0: whole table), out[5] = in-table pixels with a finite own entry that the rule does NOT let share (what
+// the OWN = 0 kernels -- selected when the plan proves "one entry per lane": ray_entry_is_shared -- would evaluate wrongly).
+// `ignore_read` = 1: the rule as it was before round 5's fix (the index test dropped).
 static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty, int ignore_read, double* out)
 {
-    for (int q = 0; q < 5; q++)
+    for (int q = 0; q < 6; q++)
         out[q] = 0;
     if (!H.a.ok || !H.usable)
         return 1;
@@ -245,6 +247,8 @@ static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty
                     out[2] += 1;
                     const double d = std::fabs(gs - go) / std::max(std::fabs(go), 1.0);
                     out[0] = std::max(out[0], std::isfinite(gs) ? d : 1e300);
+                } else {
+                    out[5] += 1;
                 }
             }
         }
@@ -265,15 +269,15 @@ int emul_lane_model_all(const v1c_chain* ch, int w, int h, int ignore_read, doub
     const RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
         return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
     });
-    double acc[5] = {0, 0, 0, 0, 0}, t[5];
+    double acc[6] = {0, 0, 0, 0, 0, 0}, t[6];
     for (int ty = 0; ty < (h + 15) / 16; ty++)
         for (int tx = 0; tx < (w + 63) / 64; tx++) {
             if (lane_model_of_tile(H, w, h, tx, ty, ignore_read, t) != 0)
                 return 1;
             acc[0] = std::max(acc[0], t[0]);
-            acc[1] += t[1], acc[2] += t[2], acc[3] += t[3], acc[4] += t[4] > 0;
+            acc[1] += t[1], acc[2] += t[2], acc[3] += t[3], acc[4] += t[4] > 0, acc[5] += t[5];
         }
-    for (int q = 0; q < 5; q++)
+    for (int q = 0; q < 6; q++)
         out[q] = acc[q];
     return 0;
 }

@@ -203,9 +203,9 @@ FUZZ_1974 = [("equirect_enc", True), ("zoom", 1.7738941798002221),
 
 
 def lane_model(E, ch, w, h, tx, ty, ignore_read=0):
-    buf = (C.c_double * 5)()
+    buf = (C.c_double * 6)()
     rc = E.emul_tile_lane_model(C.byref(ch), w, h, tx, ty, ignore_read, buf)
-    return rc, dict(zip(["err", "in_table", "shared", "pixel1_outside_slice", "slice"], list(buf)))
+    return rc, dict(zip(["err", "in_table", "shared", "pixel1_outside_slice", "slice", "not_shared"], list(buf)))
 
 
 def test_lane_model_reproduces_and_clears_the_shared_entry_bug(emul_lib, oracle_mod):
@@ -245,3 +245,18 @@ def test_lane_model_on_general_mode_chains(emul_lib, oracle_mod):
             outside += m["pixel1_outside_slice"]
             assert m["err"] <= 4e-15, (spec, (w, h), src, (tx, ty), m)
     assert tiles > 40 and shared > 1000, (tiles, shared, outside)
+
+
+@pytest.mark.parametrize("name,size", [("c2_poly", 1024), ("lr_rotator", 2048), ("c5_calib_left", 1024), ("apply_equirectangular", 832), ("apply_rectilinear", 1024)])
+def test_one_entry_per_lane_where_the_plan_says_so(emul_lib, oracle_mod, name, size):
+    """Where the plan proves "one table entry serves a lane's 4 pixels" (ray_entry_is_shared: what selects the OWN = 0 kernels, which use
+    pixel 1's entry WITHOUT a per-pixel test -- every BASELINE configuration) the host model of the tiles must find no in-table pixel
+    the sharing rule would refuse, and every shared value within 4e-15 of the pixel's own entry."""
+    spec = CS.SMALL_CASES[name][0]
+    ch = oracle_mod.chain_from_spec(spec, radius=size / 2, size_input=(size, size), size_output=(size, size))
+    info = plan_info(emul_lib, ch, size, size)
+    assert info["ok"] and info["usable"] and info["shared_entry"], info
+    buf = (C.c_double * 6)()
+    assert emul_lib.emul_lane_model_all(C.byref(ch), size, size, 0, buf) == 0
+    err, in_table, shared, outside, slices, not_shared = list(buf)
+    assert in_table > 0.5 * size * size and not_shared == 0 and err <= 4e-15, list(buf)

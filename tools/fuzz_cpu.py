@@ -95,6 +95,7 @@ def main() -> int:
     left_out = 0
     modes: dict = {}
     lanes = [0.0, 0.0]  # pixels served by a shared entry, lanes whose pixel 1 points outside the slice
+    proven = 0  # cases whose plan proves one entry per lane
     while time.time() - t0 < a.seconds:
         spec, out, inp, radius = draw(rng, a.gen2, a.hot)
         n += 1
@@ -121,20 +122,24 @@ def main() -> int:
             left_out += int((d & sing).sum())
             d &= ~sing
         # the tile kernels' table slices and entry sharing, modelled on the host over every tile (tests/host_emul: emul_lane_model_all)
-        lm = (C.c_double * 5)()
+        lm = (C.c_double * 6)()
         if E.emul_lane_model_all(C.byref(ch), out[0], out[1], 0, lm) == 0:
             lanes[0] += lm[2]
             lanes[1] += lm[3]
             if lm[0] > 4e-15:
                 reported += 1
                 print(f"[case {n}] lane model: a shared entry is {lm[0]:.3e} off its pixel's own: spec={spec!r} out={out} src={inp} radius={radius!r}", flush=True)
+            if info[10] and lm[5] > 0:  # the plan proves one entry per lane (OWN = 0 kernels): no pixel may need its own
+                reported += 1
+                print(f"[case {n}] lane model: the plan says one entry per lane, {lm[5]:.0f} pixels need their own: spec={spec!r} out={out} src={inp} radius={radius!r}", flush=True)
+            proven += bool(info[10])
         if d.any():
             reported += 1
             j, i = np.argwhere(d)[0]
             print(f"[case {n}] {int(d.sum())} buckets differ, first at ({j}, {i}): emul ({xm[j, i]!r}, {ym[j, i]!r}) oracle ({ox[j, i]!r}, {oy[j, i]!r}) "
                   f"spec={spec!r} out={out} src={inp} radius={radius!r} fixup_pixels={st[1]}", flush=True)
     print(f"fuzz_cpu seed {a.seed}: {n} cases, {fused} fused ({modes}), {reported} reported; {left_out} differing ill-conditioned pixels left out; lane model: {lanes[0]:.0f} pixels on a shared entry, "
-          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice; "
+          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice, {proven} plans proving one entry per lane; "
           f"{time.time() - t0:.0f} s")
     return 1 if reported else 0
 
