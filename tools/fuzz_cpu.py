@@ -96,6 +96,7 @@ def main() -> int:
     modes: dict = {}
     lanes = [0.0, 0.0]  # pixels served by a shared entry, lanes whose pixel 1 points outside the slice
     proven = 0  # cases whose plan proves one entry per lane
+    nofix = 0  # ... no fix-up pass
     while time.time() - t0 < a.seconds:
         spec, out, inp, radius = draw(rng, a.gen2, a.hot)
         n += 1
@@ -121,6 +122,11 @@ def main() -> int:
             sing = F.ill_conditioned(spec, radius, inp, out)
             left_out += int((d & sing).sum())
             d &= ~sing
+        # the plan says no fix-up pass is needed (the kernels then carry no flag words): no pixel may have declined the ray path
+        if info[11] and st[1] > 0:
+            reported += 1
+            print(f"[case {n}] the plan proves 'no fix-up pass', {st[1]} pixels took the interpreter: spec={spec!r} out={out} src={inp} radius={radius!r}", flush=True)
+        nofix += bool(info[11])
         # the tile kernels' table slices and entry sharing, modelled on the host over every tile (tests/host_emul: emul_lane_model_all)
         lm = (C.c_double * 6)()
         if E.emul_lane_model_all(C.byref(ch), out[0], out[1], 0, lm) == 0:
@@ -139,7 +145,7 @@ def main() -> int:
             print(f"[case {n}] {int(d.sum())} buckets differ, first at ({j}, {i}): emul ({xm[j, i]!r}, {ym[j, i]!r}) oracle ({ox[j, i]!r}, {oy[j, i]!r}) "
                   f"spec={spec!r} out={out} src={inp} radius={radius!r} fixup_pixels={st[1]}", flush=True)
     print(f"fuzz_cpu seed {a.seed}: {n} cases, {fused} fused ({modes}), {reported} reported; {left_out} differing ill-conditioned pixels left out; lane model: {lanes[0]:.0f} pixels on a shared entry, "
-          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice, {proven} plans proving one entry per lane; "
+          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice, {proven} plans proving one entry per lane, {nofix} no fix-up pass; "
           f"{time.time() - t0:.0f} s")
     return 1 if reported else 0
 
