@@ -156,7 +156,9 @@ const char* v1c_last_error(void);
  * pixels where the CHAIN is ill-conditioned (a map coordinate moving by >= 1e6 x the perturbation of the output position: the pole of
  * a rectilinear projection, stacked polynomials taking an angle to 1e12 rad): there the last bit of the platform's sin / cos / atan2
  * decides the bucket.  BORDER_CONSTANT / BORDER_TRANSPARENT outputs are unaffected (such coordinates lie 1e6+ px outside the source);
- * under the four source-reading border modes those pixels may differ from the reference's.  INTEGRATION.md section 2.             */
+ * under the four source-reading border modes those pixels may differ from the reference's.  (And a coordinate whose exact value is
+ * a tie of the float64 -> float32 rounding to within a few ulps can land in the neighbouring bucket: measure zero, seen once in 30 000
+ * random chains.)  INTEGRATION.md section 2.                                                                                  */
 
 /* Build a reusable plan for one (chain, geometry, interpolation, border) combination.
  * Replaces: chain construction + np.meshgrid + MultiTransformer.transform + astype(float32)
