@@ -260,3 +260,30 @@ def test_one_entry_per_lane_where_the_plan_says_so(emul_lib, oracle_mod, name, s
     assert emul_lib.emul_lane_model_all(C.byref(ch), size, size, 0, buf) == 0
     err, in_table, shared, outside, slices, not_shared = list(buf)
     assert in_table > 0.5 * size * size and not_shared == 0 and err <= 4e-15, list(buf)
+
+
+def test_the_float32_tie_case_differs_only_at_ties(emul_lib, oracle_mod):
+    """The one measure-zero exception to bucket equality (tools/fuzz_cpu.py seed 10 case 49): FisheyeEncoder("stereographic")
+    * FisheyeDecoder("rectilinear"), 658 x 658 from 1626 x 1626 -- one pixel and its three mirror images have a float64 coordinate 3 ulps
+    from a float32 midpoint, and the table path rounds them the other way than libm.  Nothing else differs."""
+    spec = [("fisheye_enc", "stereographic"), ("fisheye_dec", "rectilinear")]
+    out, inp, radius = (658, 658), (1626, 1626), 813.0
+    ch = oracle_mod.chain_from_spec(spec, radius=radius, size_input=inp, size_output=out)
+    rc, xm, ym, _ = emul_map(emul_lib, ch, out[0], out[1], 1)
+    assert rc == 0
+    ox, oy = oracle_mod.get_map(spec, radius=radius, size_input=inp, size_output=out)
+    fx, fy = oracle_mod.get_map(ch, radius=radius, size_input=inp, size_output=out, f64=True)
+
+    def bucket(v):
+        ok = np.isfinite(v)
+        return np.where(ok, np.rint(np.where(ok, v, 0).astype(np.float64) * 32), -2.0 ** 40)
+
+    d = (bucket(xm) != bucket(ox)) | (bucket(ym) != bucket(oy))
+    tie = np.zeros_like(d)
+    for v in (fx, fy):
+        f = v.astype(np.float32)
+        up, dn = np.nextafter(f, np.float32(np.inf)), np.nextafter(f, np.float32(-np.inf))
+        with np.errstate(invalid="ignore", over="ignore"):
+            m1, m2 = (f.astype(np.float64) + up.astype(np.float64)) / 2, (f.astype(np.float64) + dn.astype(np.float64)) / 2
+            tie |= np.minimum(np.abs(v - m1), np.abs(v - m2)) <= 1e-14 * np.abs(v)
+    assert int(d.sum()) <= 8 and not (d & ~tie).any(), (int(d.sum()), np.argwhere(d & ~tie)[:4].tolist())
