@@ -178,9 +178,13 @@ int emul_lane_probe(const v1c_chain* ch, int w, int h, int j, int i4, double* ou
 // slice, out[4] = slice entries (0: whole table), out[5] = in-table pixels with a finite own entry that the rule does NOT let share (what
 // the OWN = 0 kernels -- selected when the plan proves "one entry per lane": ray_entry_is_shared -- would evaluate wrongly).
 // `ignore_read` = 1: the rule as it was before round 5's fix (the index test dropped).
-static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty, int ignore_read, double* out)
+// (`mp`, `mp_first`, `mp_lv`: the m-polynomial twin of a w-table as plan.hip sets it up, or null.  out[6] = pixels of m-polynomial tiles
+//  checked, out[7] = the largest |G_mpoly - G_own| / max(|G_own|, 1) over them and over BOTH interval indices an fp32 root within 0.01 of
+//  pixel 1's exact table coordinate can give, out[8] = such candidate indices outside the tile's slice [i0 - 1, i1 + 1] or below the level.)
+static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty, int ignore_read, double* out, const MPolyTable* mp = nullptr,
+                              int mp_first = 0, int mp_lv = 0)
 {
-    for (int q = 0; q < 6; q++)
+    for (int q = 0; q < 9; q++)
         out[q] = 0;
     if (!H.a.ok || !H.usable)
         return 1;
@@ -196,10 +200,11 @@ static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty
         P.pre_var_is_w = H.pre_s.var_is_w, P.pre_inv_step = H.pre_s.inv_step, P.pre_n_int = H.pre_s.n_int;
     }
     constexpr int TW = 64, TH = 16;
-    double tt[TH][TW];
+    double tt[TH][TW], mm[TH][TW];
     int idx[TH][TW];
     bool in_table[TH][TW];
     int lo = 0x7fffffff, hi = -1;
+    bool all_in = true;
     for (int r = 0; r < TH; r++)
         for (int c = 0; c < TW; c++) {
             const int j = std::min(ty * TH + r, h - 1), i = std::min(tx * TW + c, w - 1);
@@ -214,9 +219,11 @@ static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty
                 m = fma(ht.row_c[j], ht.col_h[i], ht.row_h[j]);
             }
             const double u = T.var_is_w ? fast_sqrt_half(m) : m;
+            mm[r][c] = m;
             tt[r][c] = u * T.inv_step;
             const int ir = table_index(tt[r][c]);
             in_table[r][c] = ok && (unsigned)ir < (unsigned)T.n_int;
+            all_in = all_in && in_table[r][c];
             idx[r][c] = std::min(ir, T.n_int - 1);
             if (in_table[r][c])
                 lo = std::min(lo, idx[r][c]), hi = std::max(hi, idx[r][c]);
@@ -252,6 +259,40 @@ static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty
                 }
             }
         }
+    // m-polynomial tiles (k_tile_boxes: every pixel in the table, its intervals from mp_first + 1 on, the slice with one entry either side
+    // within 64): lane_coords<..., MPOLY> takes pixel 1's interval from an fp32 root -- off by one near a boundary -- and evaluates all
+    // 4 pixels with that entry's polynomial in m - m_c
+    if (mp && all_in && lo - 1 >= mp_first && hi - lo + 3 <= 64 && (tx + 1) * TW <= w && (ty + 1) * TH <= h) {
+        for (int r = 0; r < TH; r++)
+            for (int c4 = 0; c4 < TW; c4 += 4) {
+                const double t1 = tt[r][c4 + 1];
+                const int cand[2] = {(int)std::floor(t1 - 0.01), (int)std::floor(t1 + 0.01)};
+                for (int q = 0; q < 2; q++) {
+                    const int ic = cand[q];
+                    if (q == 1 && ic == cand[0])
+                        continue;
+                    if (ic < lo - 1 || ic > hi + 1 || ic < 0 || ic >= T.n_int || mp->level[ic] < mp_lv) {
+                        out[8] += 1;
+                        continue;
+                    }
+                    const double* e = mp->coef.data() + (size_t)ic * kRadialCoefs;
+                    for (int k = 0; k < 4; k++) {
+                        const double dk = mm[r][c4 + k] - e[kRadialCoefs - 1];
+                        double gk = e[kRadialCoefs - 2];
+                        for (int d = kRadialCoefs - 3; d >= 0; d--)
+                            gk = fma(gk, dk, e[d]);
+                        const double* pc = T.coef.data() + (size_t)idx[r][c4 + k] * kRadialCoefs;
+                        const double zo = tt[r][c4 + k] - ((double)idx[r][c4 + k] + 0.5);
+                        double go = pc[kRadialDegree];
+                        for (int d = kRadialDegree - 1; d >= 0; d--)
+                            go = fma(go, zo, pc[d]);
+                        out[6] += 1;
+                        const double dd = std::fabs(gk - go) / std::max(std::fabs(go), 1.0);
+                        out[7] = std::max(out[7], std::isfinite(gk) && std::isfinite(go) ? dd : 1e300);
+                    }
+                }
+            }
+    }
     return 0;
 }
 
@@ -260,24 +301,45 @@ int emul_tile_lane_model(const v1c_chain* ch, int w, int h, int tx, int ty, int 
     const RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
         return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
     });
-    return lane_model_of_tile(H, w, h, tx, ty, ignore_read, out);
+    double t[9];
+    const int rc = lane_model_of_tile(H, w, h, tx, ty, ignore_read, t);
+    for (int q = 0; q < 6; q++)
+        out[q] = t[q];
+    return rc;
 }
 
-// ... over every tile of the output (one plan): out[0] = the largest error, out[1 .. 3] summed, out[4] = tiles with a slice
+// ... over every tile of the output (one plan): out[0] = the largest error, out[1 .. 3], [5] summed, out[4] = tiles with a slice,
+// out[6 .. 8] = the m-polynomial model (pixels checked, largest error, candidate indices the tile's slice / levels do not cover)
 int emul_lane_model_all(const v1c_chain* ch, int w, int h, int ignore_read, double* out)
 {
     const RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
         return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
     });
-    double acc[6] = {0, 0, 0, 0, 0, 0}, t[6];
+    // the m-polynomial twin, set up as plan.hip does (plans that prove one entry per lane for a w- or m-table, level = shared_entry_level)
+    const MPolyTable* mp = nullptr;
+    MPolyTable M;
+    int mp_first = 0, mp_lv = 0;
+    if (H.a.ok && H.usable) {
+        const double reach = H.a.has_rot ? H.reach_rot : H.reach_norot;
+        const bool safe = H.a.has_rot ? (H.reach_rot < 2.0 && H.pre_safe && ray_reach_is_safe(H.table, reach)) : ray_reach_is_safe(H.table, reach);
+        if (safe && ray_entry_is_shared(H.table, reach, H.step)) {
+            mp_lv = shared_entry_level(H.table, H.step);
+            M = fit_mpoly_table(H.a.radial, H.table);
+            mp_first = mp_lv > 0 ? mpoly_first_ok(M, H.table, reach, mp_lv) : H.table.n_int;
+            if (mp_first < H.table.n_int / 2)
+                mp = &M;
+        }
+    }
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t[9];
     for (int ty = 0; ty < (h + 15) / 16; ty++)
         for (int tx = 0; tx < (w + 63) / 64; tx++) {
-            if (lane_model_of_tile(H, w, h, tx, ty, ignore_read, t) != 0)
+            if (lane_model_of_tile(H, w, h, tx, ty, ignore_read, t, mp, mp_first, mp_lv) != 0)
                 return 1;
             acc[0] = std::max(acc[0], t[0]);
             acc[1] += t[1], acc[2] += t[2], acc[3] += t[3], acc[4] += t[4] > 0, acc[5] += t[5];
+            acc[6] += t[6], acc[7] = std::max(acc[7], t[7]), acc[8] += t[8];
         }
-    for (int q = 0; q < 6; q++)
+    for (int q = 0; q < 9; q++)
         out[q] = acc[q];
     return 0;
 }

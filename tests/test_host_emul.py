@@ -256,10 +256,13 @@ def test_one_entry_per_lane_where_the_plan_says_so(emul_lib, oracle_mod, name, s
     ch = oracle_mod.chain_from_spec(spec, radius=size / 2, size_input=(size, size), size_output=(size, size))
     info = plan_info(emul_lib, ch, size, size)
     assert info["ok"] and info["usable"] and info["shared_entry"], info
-    buf = (C.c_double * 6)()
+    buf = (C.c_double * 9)()
     assert emul_lib.emul_lane_model_all(C.byref(ch), size, size, 0, buf) == 0
-    err, in_table, shared, outside, slices, not_shared = list(buf)
+    err, in_table, shared, outside, slices, not_shared, mp_pixels, mp_err, mp_uncovered = list(buf)
     assert in_table > 0.5 * size * size and not_shared == 0 and err <= 4e-15, list(buf)
+    # the m-polynomial twin (lane_coords<..., MPOLY>: the interval of pixel 1 from an fp32 root, off by one near a boundary): both candidate
+    # entries inside the tile's slice and of the plan's level, their polynomial in m within 4e-15 of the pixel's own entry
+    assert mp_pixels > 0.5 * size * size and mp_uncovered == 0 and mp_err <= 4e-15, list(buf)
 
 
 def test_the_float32_tie_case_differs_only_at_ties(emul_lib, oracle_mod):

@@ -97,6 +97,7 @@ def main() -> int:
     modes: dict = {}
     lanes = [0.0, 0.0]  # pixels served by a shared entry, lanes whose pixel 1 points outside the slice
     proven = 0  # cases whose plan proves one entry per lane
+    mpoly_px = 0.0  # pixel checks of the m-polynomial model
     nofix = 0  # ... no fix-up pass
     while time.time() - t0 < a.seconds:
         spec, out, inp, radius = draw(rng, a.gen2, a.hot)
@@ -142,7 +143,7 @@ def main() -> int:
             print(f"[case {n}] the plan proves 'no fix-up pass', {st[1]} pixels took the interpreter: spec={spec!r} out={out} src={inp} radius={radius!r}", flush=True)
         nofix += bool(info[11])
         # the tile kernels' table slices and entry sharing, modelled on the host over every tile (tests/host_emul: emul_lane_model_all)
-        lm = (C.c_double * 6)()
+        lm = (C.c_double * 9)()
         if E.emul_lane_model_all(C.byref(ch), out[0], out[1], 0, lm) == 0:
             lanes[0] += lm[2]
             lanes[1] += lm[3]
@@ -152,6 +153,10 @@ def main() -> int:
             if info[10] and lm[5] > 0:  # the plan proves one entry per lane (OWN = 0 kernels): no pixel may need its own
                 reported += 1
                 print(f"[case {n}] lane model: the plan says one entry per lane, {lm[5]:.0f} pixels need their own: spec={spec!r} out={out} src={inp} radius={radius!r}", flush=True)
+            if lm[7] > 4e-15 or lm[8] > 0:  # the m-polynomial twin: either candidate entry of an fp32 index, inside the slice and the level
+                reported += 1
+                print(f"[case {n}] lane model, m-polynomials: error {lm[7]:.3e}, {lm[8]:.0f} candidate entries not covered: spec={spec!r} out={out} src={inp} radius={radius!r}", flush=True)
+            mpoly_px += lm[6]
             proven += bool(info[10])
         if d.any():
             reported += 1
@@ -159,7 +164,7 @@ def main() -> int:
             print(f"[case {n}] {int(d.sum())} buckets differ, first at ({j}, {i}): emul ({xm[j, i]!r}, {ym[j, i]!r}) oracle ({ox[j, i]!r}, {oy[j, i]!r}) "
                   f"spec={spec!r} out={out} src={inp} radius={radius!r} fixup_pixels={st[1]}", flush=True)
     print(f"fuzz_cpu seed {a.seed}: {n} cases, {fused} fused ({modes}), {reported} reported; {left_out} differing ill-conditioned pixels and {ties} at float32 ties left out; lane model: {lanes[0]:.0f} pixels on a shared entry, "
-          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice, {proven} plans proving one entry per lane, {nofix} no fix-up pass; "
+          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice, {proven} plans proving one entry per lane ({mpoly_px:.0f} m-polynomial pixel checks), {nofix} no fix-up pass; "
           f"{time.time() - t0:.0f} s")
     return 1 if reported else 0
 
