@@ -335,6 +335,27 @@ def test_exact_auto_radius_takes_no_plan_per_radius(V, oracle_mod, dev):
                            size_output=(512, 512), interpolation=1, radius="auto", auto_radius_on_device=False)
 
 
+@pytest.mark.parametrize("interp", [1, 4])
+def test_auto_radius_of_one_three_and_four_images(V, oracle_mod, dev, interp):
+    """remap_tensors_auto with 1, 3 and 4 images of one call (apply() of a list, remapper.py:379-398: ONE radius = the maximum of the
+    images' estimates, one map): the scan launch walks every image's centre line, odd counts leave the pair kernels."""
+    from vr180_convert_amd import remapper
+
+    O = oracle_mod
+    spec = [("equirect_enc", True), ("poly", [0, 1, -0.05]), CS.EQUI]
+    t = CS.to_product(spec)
+    imgs = [_disc(400, 400, r, 40 + k) for k, r in enumerate((180.5, 190, 150, 192))]
+    for n in (1, 3, 4):
+        srcs = [torch.from_numpy(im).to(dev) for im in imgs[:n]]
+        dsts = [torch.zeros((448, 448, 3), dtype=torch.uint8, device=dev) for _ in range(n)]
+        remapper.remap_tensors_auto(t, srcs, dsts, interpolation=interp)
+        r_ref = max(O.get_radius(im) for im in imgs[:n])
+        xm, ym = O.get_map(spec, radius=r_ref, size_input=(400, 400), size_output=(448, 448))
+        for k in range(n):
+            want = O.remap(imgs[k], xm, ym, interp, 0, 0)
+            assert np.array_equal(dsts[k].cpu().numpy(), want), (n, k, r_ref)
+
+
 def test_apply_lr_auto_radius_is_graph_capturable_end_to_end(V, oracle_mod, dev):
     """radius="auto" -- the reference's default -- recorded into a graph: estimate, maximum, scale and remap are four launches and no
     synchronisation.  The graph is replayed on NEW pixels with ANOTHER image circle in the same buffers: the radius follows the image."""
