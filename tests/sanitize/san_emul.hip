@@ -76,6 +76,13 @@ int main()
         fails += variant < 9 ? rc != 0 : rc == 0;  // everything but the decoder chain has a fused form
         long long info[12];
         fails += emul_plan_info(&ch, W, H, info) != 0;
+        if (rc == 0) {  // the host model of the tiles' table slices, entry sharing and m-polynomial lanes (partial tiles at these sizes)
+            double lm[9];
+            fails += emul_lane_model_all(&ch, W, H, 0, lm) != 0;
+            fails += emul_tile_lane_model(&ch, W, H, 0, 0, 1, lm) != 0;
+            double probe[32];
+            fails += emul_lane_probe(&ch, W, H, H / 2, 0, probe) != 0;
+        }
         if (variant == 1) {  // per-unit rotation override
             const double r2[9] = {1, 0, 0, 0, 0.96, -0.28, 0, 0.28, 0.96};
             fails += emul_get_map(&ch, r2, W, H, 1, xm, ym, st) != 0;
