@@ -182,7 +182,7 @@ int emul_lane_probe(const v1c_chain* ch, int w, int h, int j, int i4, double* ou
 //  checked, out[7] = the largest |G_mpoly - G_own| / max(|G_own|, 1) over them and over BOTH interval indices an fp32 root within 0.01 of
 //  pixel 1's exact table coordinate can give, out[8] = such candidate indices outside the tile's slice [i0 - 1, i1 + 1] or below the level.)
 static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty, int ignore_read, double* out, const MPolyTable* mp = nullptr,
-                              int mp_first = 0, int mp_lv = 0)
+                              int mp_first = 0, int mp_lv = 0, const double* rot_override = nullptr)
 {
     for (int q = 0; q < 9; q++)
         out[q] = 0;
@@ -212,8 +212,8 @@ static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty
             bool ok = true;
             if (a.gen_mode) {
                 ok = gen_vector(P, a.rot, ht.row_s[j], ht.row_c[j], ht.row_h[j], ht.col_s[i], ht.col_h[i], fx, fy, m);
-            } else if (a.has_rot) {
-                const double* R = a.rot;
+            } else if (a.has_rot || rot_override) {
+                const double* R = rot_override ? rot_override : a.rot;
                 m = 1.0 - fma(R[6] * ht.row_c[j], ht.col_s[i], fma(R[8] * ht.row_c[j], ht.col_c[i], R[7] * ht.row_s[j]));
             } else {
                 m = fma(ht.row_c[j], ht.col_h[i], ht.row_h[j]);
@@ -262,16 +262,17 @@ static int lane_model_of_tile(const RayPlanHost& H, int w, int h, int tx, int ty
     // m-polynomial tiles (k_tile_boxes: every pixel in the table, its intervals from mp_first + 1 on, the slice with one entry either side
     // within 64): lane_coords<..., MPOLY> takes pixel 1's interval from an fp32 root -- off by one near a boundary -- and evaluates all
     // 4 pixels with that entry's polynomial in m - m_c
-    if (mp && all_in && lo - 1 >= mp_first && hi - lo + 3 <= 64 && (tx + 1) * TW <= w && (ty + 1) * TH <= h) {
+    const bool sliced = mp_first >= 0;  // (a launch without boxes reads the whole table: emul_unit_rotation_check)
+    if (mp && all_in && (!sliced || (lo - 1 >= mp_first && hi - lo + 3 <= 64)) && (tx + 1) * TW <= w && (ty + 1) * TH <= h) {
         for (int r = 0; r < TH; r++)
             for (int c4 = 0; c4 < TW; c4 += 4) {
                 const double t1 = tt[r][c4 + 1];
-                const int cand[2] = {(int)std::floor(t1 - 0.01), (int)std::floor(t1 + 0.01)};
+                const int cand[2] = {std::max((int)std::floor(t1 - 0.01), 0), (int)std::floor(t1 + 0.01)};  // (an fp32 root is never negative)
                 for (int q = 0; q < 2; q++) {
                     const int ic = cand[q];
                     if (q == 1 && ic == cand[0])
                         continue;
-                    if (ic < lo - 1 || ic > hi + 1 || ic < 0 || ic >= T.n_int || mp->level[ic] < mp_lv) {
+                    if ((sliced && (ic < lo - 1 || ic > hi + 1)) || ic < 0 || ic >= T.n_int || mp->level[ic] < mp_lv) {
                         out[8] += 1;
                         continue;
                     }
@@ -341,6 +342,72 @@ int emul_lane_model_all(const v1c_chain* ch, int w, int h, int ignore_read, doub
         }
     for (int q = 0; q < 9; q++)
         out[q] = acc[q];
+    return 0;
+}
+
+// A unit that overrides the rotation of a classic chain (per-frame calibration, cli.py:308-319; BASELINE config 5; v1c_plan_run_auto): what
+// plan.hip's decide_launch CLAIMS for it from closed forms -- the rotated reach stays in valid table intervals ("covered": no fix-up
+// pass, no flag words), one entry serves a lane (the kernels without a per-pixel test), every |32 x|, |32 y| < 2^21 (the rounding trick
+// without clamps) -- against what the pixels DO.  out[0] = front hemisphere, [1] covered, [2] shared, [3] coordinates bounded (claims);
+// [4] = pixels that decline the ray path, [5] = in-table pixels the sharing rule refuses, [6] = largest |32 x|, |32 y|, [7] = largest
+// shared-entry error (facts); [8 .. 10] = the m-polynomial model where the launch may use that table (pixel checks, largest error,
+// candidate entries below the level).  (The claims restate decide_launch: plan.hip is host code of the device library.)
+int emul_unit_rotation_check(const v1c_chain* ch, const double* rot, int w, int h, double* out)
+{
+    for (int q = 0; q < 11; q++)
+        out[q] = 0;
+    const RayPlanHost H = build_ray_plan_host(*ch, w, h, [](const TableSpec& sp) {
+        return build_radial_table(*sp.stages, sp.n_int, sp.fn, sp.m_max, sp.force_var, sp.m_front);
+    });
+    if (!H.a.ok || !H.usable || H.a.gen_mode != 0 || H.a.base != 0)
+        return 1;
+    const RadialTable& T = H.table;
+    const double reach = rotated_reach(rot);
+    const bool front = H.ht.front_hemisphere;
+    const bool covered = front && ray_reach_is_safe(T, reach);
+    const bool shared = covered && ray_entry_is_shared(T, reach, H.step);
+    const double gb = covered ? radial_table_g_bound(T, radial_table_g_bounds(T), reach) : INFINITY;
+    const bool bounded = shared && gb * std::fabs(32.0 * H.a.rx) + std::fabs(32.0 * H.a.cx) < 2097152.0 &&
+                         gb * std::fabs(32.0 * H.a.ry) + std::fabs(32.0 * H.a.cy) < 2097152.0;
+    out[0] = front, out[1] = covered, out[2] = shared, out[3] = bounded;
+    // the m-polynomial twin for such a launch ("mpoly_all": k_ray_lin3_rot_pair_raw<..., MP = 1> reads it for every tile): the plan has
+    // one when ITS rotation proves one entry per lane, the unit may use it when every interval up to its reach (+ 2) has the level
+    const MPolyTable* mp = nullptr;
+    MPolyTable M;
+    int mp_lv = 0;
+    {
+        const double preach = H.a.has_rot ? H.reach_rot : H.reach_norot;
+        const bool psafe = H.a.has_rot ? (H.reach_rot < 2.0 && H.pre_safe && ray_reach_is_safe(T, preach)) : ray_reach_is_safe(T, preach);
+        if (psafe && ray_entry_is_shared(T, preach, H.step) && shared) {
+            mp_lv = shared_entry_level(T, H.step);
+            M = fit_mpoly_table(H.a.radial, T);
+            const int first = mp_lv > 0 ? mpoly_first_ok(M, T, preach, mp_lv) : T.n_int;
+            int upto = -1;
+            while (upto + 1 < T.n_int && M.level[upto + 1] >= mp_lv)
+                upto++;
+            const double u_reach = (T.var_is_w ? std::sqrt(reach / 2) : reach) * (1 + 1e-9);
+            if (first < T.n_int / 2 && std::min(T.n_int - 1, (int)(u_reach * T.inv_step) + 2) <= upto)
+                mp = &M;
+        }
+    }
+    std::vector<float> xm((size_t)w * h), ym((size_t)w * h);
+    long long st[5];
+    if (emul_get_map(ch, rot, w, h, 1, xm.data(), ym.data(), st) != 0)
+        return 2;
+    out[4] = (double)st[1];
+    double t[9];
+    for (int ty = 0; ty < (h + 15) / 16; ty++)
+        for (int tx = 0; tx < (w + 63) / 64; tx++) {
+            // (mp_first = -1: no tile is excluded for its intervals -- the launch has no boxes, the claim is about the whole reach)
+            if (lane_model_of_tile(H, w, h, tx, ty, 0, t, mp, -1, mp_lv, rot) != 0)
+                return 3;
+            out[5] += t[5], out[7] = std::max(out[7], t[0]);
+            if (mp)
+                out[8] += t[6], out[9] = std::max(out[9], t[7]), out[10] += t[8];
+        }
+    if (covered)  // (pixels that declined carry the interpreter's coordinates: anything)
+        for (size_t i = 0; i < xm.size(); i++)
+            out[6] = std::max(out[6], (double)std::max(std::fabs(32.0f * xm[i]), std::fabs(32.0f * ym[i])));
     return 0;
 }
 

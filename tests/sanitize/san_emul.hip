@@ -86,6 +86,8 @@ int main()
         if (variant == 1) {  // per-unit rotation override
             const double r2[9] = {1, 0, 0, 0, 0.96, -0.28, 0, 0.28, 0.96};
             fails += emul_get_map(&ch, r2, W, H, 1, xm, ym, st) != 0;
+            double claims[11];
+            fails += emul_unit_rotation_check(&ch, r2, W, H, claims) > 1;  // (1: not a classic chain)
         }
     }
     // sampler: every interpolation x border x cn, coordinates far outside / NaN / inf / huge, odd pitches;

@@ -290,3 +290,33 @@ def test_the_float32_tie_case_differs_only_at_ties(emul_lib, oracle_mod):
             m1, m2 = (f.astype(np.float64) + up.astype(np.float64)) / 2, (f.astype(np.float64) + dn.astype(np.float64)) / 2
             tie |= np.minimum(np.abs(v - m1), np.abs(v - m2)) <= 1e-14 * np.abs(v)
     assert int(d.sum()) <= 8 and not (d & ~tie).any(), (int(d.sum()), np.argwhere(d & ~tie)[:4].tolist())
+
+
+def test_claims_about_units_that_override_the_rotation(emul_lib, oracle_mod):
+    """Per-frame calibration rotations (BASELINE config 5) and v1c_plan_run_auto run kernels that trust three closed-form claims of the
+    host (plan.hip: decide_launch) without testing a pixel: the rotated reach stays in valid table intervals, one table entry serves a
+    lane, every |32 x|, |32 y| < 2^21.  emul_unit_rotation_check restates the claims and counts what the pixels do, for small and large
+    random rotations of equidistant / polynomial / stereographic chains."""
+    from vr180_convert_amd.quat import as_rotation_matrix, from_rotation_vector
+
+    rng = np.random.default_rng(21)
+    claimed = [0, 0, 0]
+    mp_total = 0
+    for case in range(18):
+        mid = [("poly", [0.0, 1.0, float(rng.uniform(-0.15, 0.05))])] if case % 3 == 1 else []
+        dec = ("fisheye_dec", "stereographic") if case % 3 == 2 else CS.EQUI
+        spec = [("equirect_enc", True), ("rot", np.eye(3).tolist())] + mid + [dec]
+        size = int(rng.integers(300, 1500))
+        ch = oracle_mod.chain_from_spec(spec, radius=float(rng.uniform(0.35, 0.6) * size), size_input=(size, size), size_output=(size, size))
+        R = np.ascontiguousarray(np.asarray(as_rotation_matrix(from_rotation_vector(rng.normal(0, 0.04 if case % 2 else 0.6, 3))), float).reshape(9))
+        buf = (C.c_double * 11)()
+        assert emul_lib.emul_unit_rotation_check(C.byref(ch), C.c_void_p(R.ctypes.data), size, size, buf) == 0
+        front, covered, shared, bounded, declined, refused, cmax, err, mp_px, mp_err, mp_uncovered = list(buf)
+        assert mp_uncovered == 0 and mp_err <= 4e-15, (spec, size, R.tolist(), list(buf))
+        mp_total += mp_px
+        assert front == 1
+        assert not covered or declined == 0, (spec, size, R.tolist(), list(buf))
+        assert not shared or (refused == 0 and err <= 4e-15), (spec, size, R.tolist(), list(buf))
+        assert not bounded or cmax < 2097152.0, (spec, size, R.tolist(), list(buf))
+        claimed = [claimed[0] + covered, claimed[1] + shared, claimed[2] + bounded]
+    assert min(claimed) >= 4 and mp_total > 1e6, (claimed, mp_total)

@@ -99,7 +99,31 @@ def main() -> int:
     proven = 0  # cases whose plan proves one entry per lane
     mpoly_px = 0.0  # pixel checks of the m-polynomial model
     nofix = 0  # ... no fix-up pass
+    units = [0, 0.0]  # unit-rotation cases, claims made in them
     while time.time() - t0 < a.seconds:
+        if rng.random() < 0.15:
+            # a unit that overrides the rotation of a classic chain (per-frame calibration; v1c_plan_run_auto): the host's closed-form claims
+            # (covered / one entry per lane / coordinates bounded: plan.hip decide_launch, restated by emul_unit_rotation_check) against the pixels
+            mid = [("poly", [0.0, 1.0, float(rng.uniform(-0.15, 0.08))])] if rng.random() < 0.4 else []
+            dec = ("fisheye_dec", "equidistant") if rng.random() < 0.7 else ("fisheye_dec", F.MODELS[int(rng.integers(5))])
+            spec = [("equirect_enc", True), ("rot", np.eye(3).tolist())] + mid + [dec]
+            size = int(rng.integers(64, 1300))
+            wo = size if rng.random() < 0.7 else max(16, size + int(rng.integers(-100, 100)))
+            rad = float(rng.uniform(0.3, 0.62) * size)
+            R = np.ascontiguousarray(F.rand_rot(rng, rng.random() < 0.4).reshape(9))
+            try:
+                ch = O.chain_from_spec(spec, radius=rad, size_input=(size, size), size_output=(wo, size))
+            except Exception:  # noqa: BLE001
+                continue
+            ub = (C.c_double * 11)()
+            if E.emul_unit_rotation_check(C.byref(ch), C.c_void_p(R.ctypes.data), wo, size, ub) == 0:
+                units[0] += 1
+                units[1] += ub[1] + ub[2] + ub[3]
+                if (ub[1] and ub[4] > 0) or (ub[2] and (ub[5] > 0 or ub[7] > 4e-15)) or (ub[3] and not ub[6] < 2097152.0) or ub[9] > 4e-15 or ub[10] > 0:
+                    reported += 1
+                    print(f"[unit rotation] claims {list(ub)[:4]} contradicted by the pixels {list(ub)[4:]}: spec={spec!r} out=({wo},{size}) radius={rad!r} R={R.tolist()!r}",
+                          flush=True)
+            continue
         spec, out, inp, radius = draw(rng, a.gen2, a.hot)
         n += 1
         try:
@@ -164,7 +188,7 @@ def main() -> int:
             print(f"[case {n}] {int(d.sum())} buckets differ, first at ({j}, {i}): emul ({xm[j, i]!r}, {ym[j, i]!r}) oracle ({ox[j, i]!r}, {oy[j, i]!r}) "
                   f"spec={spec!r} out={out} src={inp} radius={radius!r} fixup_pixels={st[1]}", flush=True)
     print(f"fuzz_cpu seed {a.seed}: {n} cases, {fused} fused ({modes}), {reported} reported; {left_out} differing ill-conditioned pixels and {ties} at float32 ties left out; lane model: {lanes[0]:.0f} pixels on a shared entry, "
-          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice, {proven} plans proving one entry per lane ({mpoly_px:.0f} m-polynomial pixel checks), {nofix} no fix-up pass; "
+          f"{lanes[1]:.0f} lanes with pixel 1 outside the slice, {proven} plans proving one entry per lane ({mpoly_px:.0f} m-polynomial pixel checks), {nofix} no fix-up pass; {units[0]} unit-rotation cases with {units[1]:.0f} claims; "
           f"{time.time() - t0:.0f} s")
     return 1 if reported else 0
 
