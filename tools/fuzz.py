@@ -6,11 +6,12 @@ strips, rest lists, the unit ring), cn 1 / 3 / 4, every interpolation and border
 and destination views (dword-aligned or not), per-unit rotations, apply_lr pairs; a share of the cases (--lut) runs cv2.remap alone
 (v1c_remap_lut) on random float32 maps sprinkled with NaN, infinities, 2^15 / 2^26 / 2^31-scale values and ties of the 1/32 grid.
 
-    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--lut 0.15] [--hot 0.3] [--api 0.1] [--auto 0.06] [--fused 0.06] [--log gpurun_out/fuzz.log]
+    python3 tools/fuzz.py [--seconds 300] [--seed 1] [--big 0.15] [--lut 0.15] [--hot 0.3] [--gen2 0] [--api 0.1] [--auto 0.06] [--fused 0.06] [--log gpurun_out/fuzz.log]
 
 Round 5 added to the grammar: hot shapes of the chains that left the interpreter (planar fisheye -> fisheye, is_latitude_y=False, a
 rotation behind radial stages), outputs of 64 ... 416 px, launches recorded into a graph and replayed, radius='auto' with the radius on
-the device (--auto) and v1c_remap_fused through raw ctypes (--fused).
+the device (--auto) and v1c_remap_fused through raw ctypes (--fused); --gen2: chains forced into general mode 2 (radial stages / zooms in front
+of a rotation, lanes split between the tile kernel and the fix-up pass: what case 1974 of seed 34 was).  tools/fuzz_cpu.py is the GPU-less half.
 
 Ill-conditioned pixels are left out and counted: where the chain amplifies a perturbation of the output position by 1e6 or more
 (measured on the oracle's fp64 map, `ill_conditioned`), the last bits of every intermediate -- they differ between glibc and the
